@@ -1,0 +1,224 @@
+"""Pins the CPU oracle (oracle/nsol_oracle.py) against golden vectors that the
+reference itself produced (tools/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import nsol_oracle as orc
+from conftest import rel_l2
+
+TIGHT = 1e-12
+
+
+def _zshape(shape):
+    return (len(shape) * shape[0],) + tuple(shape[1:]) if len(shape) > 1 \
+        else tuple(shape)
+
+
+@pytest.mark.parametrize("k", ["1d", "2d", "3d"])
+@pytest.mark.parametrize("tag", ["unit", "sp"])
+def test_grad_and_adjoint_match_reference(golden, k, tag):
+    g = golden("ops")
+    sp = None if tag == "unit" else g["spacing_" + k]
+    x, p = g["x_" + k], g["p_" + k]
+    assert np.array_equal(orc.grad(x, sp), g["grad_%s_%s" % (k, tag)])
+    assert np.allclose(orc.grad_adj(p, sp), g["gradadj_%s_%s" % (k, tag)],
+                       rtol=0, atol=1e-14)
+    d = x.ndim
+    spv = np.ones(d) if sp is None else sp
+    for a, nm in enumerate(["dx", "dy", "dz"][:d]):
+        ax = d - 1 - a
+        assert np.array_equal(orc.d_forward(x, ax, spv[a]),
+                              g["%s_%s_%s" % (nm, k, tag)])
+        assert np.array_equal(orc.d_forward_adj(x, ax, spv[a]),
+                              g["%sadj_%s_%s" % (nm, k, tag)])
+
+
+def test_gaussian_taps_match_reference(golden):
+    g = golden("ops")
+    assert np.allclose(orc.gaussian_taps(1, 2.0), g["taps_1d"], atol=1e-16)
+    assert np.allclose(orc.gaussian_taps(1, 2.0, 1.5, 4), g["taps_1d_sp"],
+                       atol=1e-16)
+    assert np.allclose(orc.gaussian_taps(2, np.diag([2., 2.])), g["taps_2d"],
+                       atol=1e-16)
+    assert np.allclose(orc.gaussian_taps(2, g["cov_2d_aniso"]),
+                       g["taps_2d_aniso"], atol=1e-16)
+    assert np.allclose(orc.gaussian_taps(2, g["cov_2d_full"]),
+                       g["taps_2d_full"], atol=1e-16)
+    assert np.allclose(orc.gaussian_taps(3, np.diag([2., 2., 2.])),
+                       g["taps_3d"], atol=1e-17)
+    t = orc.gaussian_taps(3, g["cov_3d_aniso"])
+    assert t.shape == g["taps_3d_aniso"].shape
+    assert np.allclose(t, g["taps_3d_aniso"], atol=1e-17)
+    assert np.allclose(
+        orc.gaussian_taps(3, np.diag([4., 4., 4.]), g["spacing_3d"], 2),
+        g["taps_3d_sp"], atol=1e-17)
+
+
+def test_blur_matches_reference(golden):
+    g = golden("ops")
+    assert rel_l2(orc.gaussian_blur(g["x_1d"], 2.0), g["blur_1d"]) < TIGHT
+    assert rel_l2(orc.gaussian_blur(g["x_2d"], np.diag([2., 2.])),
+                  g["blur_2d"]) < TIGHT
+    assert rel_l2(orc.gaussian_blur(g["x_2d"], g["cov_2d_aniso"]),
+                  g["blur_2d_aniso"]) < TIGHT
+    assert rel_l2(orc.gaussian_blur(g["x_2d"], g["cov_2d_full"]),
+                  g["blur_2d_full"]) < TIGHT
+    # axis 0 of x_3d has 7 samples but 11 taps: multiple wrap-around
+    assert rel_l2(orc.gaussian_blur(g["x_3d"], np.diag([2., 2., 2.])),
+                  g["blur_3d"]) < TIGHT
+    assert rel_l2(orc.gaussian_blur(g["x_3d_b"], g["cov_3d_aniso"]),
+                  g["blur_3d_aniso"]) < TIGHT
+    assert rel_l2(orc.gaussian_blur(g["x_3d_b"], np.diag([4., 4., 4.]),
+                                    g["spacing_3d"], 2),
+                  g["blur_3d_sp"]) < TIGHT
+
+
+@pytest.mark.parametrize("mode", ["wrap", "constant", "nearest", "reflect",
+                                  "mirror"])
+def test_user_kernel_convolution_modes(golden, mode):
+    g = golden("ops")
+    out = orc.convolve_nd(g["x_3d_b"], g["userker_3d"], mode)
+    assert rel_l2(out, g["userconv_3d_" + mode]) < TIGHT
+    if mode == "wrap":
+        assert rel_l2(orc.convolve_nd(g["x_2d"], g["userker_2d"], mode),
+                      g["userconv_2d_wrap"]) < TIGHT
+
+
+def test_separable_factors():
+    t = orc.gaussian_taps(3, np.diag([1., 4., 9.]))
+    f = orc.separable_factors(t)
+    assert f is not None and [v.size for v in f] == list(t.shape)
+    rebuilt = np.multiply.outer(np.multiply.outer(f[0], f[1]), f[2])
+    assert np.max(np.abs(rebuilt - t)) < 1e-16
+    assert orc.separable_factors(
+        orc.gaussian_taps(2, np.array([[2., .6], [.6, 1.]]))) is None
+
+
+def test_prox_and_loss_match_reference(golden):
+    g = golden("ops")
+    v, b = g["prox_in"], g["prox_b"]
+    assert np.array_equal(orc.prox_tv_conj(v, 0.7), g["prox_tv_conj"])
+    assert np.array_equal(orc.prox_huber_conj(v, 0.7), g["prox_huber_conj"])
+    assert np.array_equal(orc.prox_ell1_denoising(v, 0.3, b, 50.0),
+                          g["prox_ell1"])
+    assert np.array_equal(orc.prox_ell2_denoising(v, 0.3, b, 50.0),
+                          g["prox_ell2"])
+    for name in ("linear", "soft_l1", "huber", "cauchy", "arctan"):
+        for fs in (1.0, 1.7):
+            assert np.array_equal(orc.loss(name, g["loss_f2"], fs),
+                                  g["loss_%s_%g" % (name, fs)])
+            assert np.array_equal(orc.gradient_loss(name, g["loss_f2"], fs),
+                                  g["gradloss_%s_%g" % (name, fs)])
+    assert np.array_equal(orc.admm_prox_g(g["shrink_in"], 0.9, 3),
+                          g["shrink_out"])
+
+
+PD_CASES = [(k, alg, reg, data)
+            for k in ("1d", "2d", "3d")
+            for alg in ("ALG2", "ALG2_AHMOD", "ALG3")
+            for reg in ("TV", "Huber")
+            for data in ("L2", "L1")]
+
+
+@pytest.mark.parametrize("k,alg,reg,data", PD_CASES)
+def test_primal_dual_matches_reference(golden, k, alg, reg, data):
+    g = golden("pd")
+    obs = g["obs_" + k]
+    L2 = {"1d": 4.0, "2d": 8.0, "3d": 16.0}[k]
+    alpha = 0.05 if data == "L2" else 0.6
+    out = orc.primal_dual_denoise(obs.flatten(), obs.shape, reg, data, alpha,
+                                  25, L2, alg)
+    assert rel_l2(out, g["pd_%s_%s_%s%s" % (k, alg, reg, data)]) < TIGHT
+
+
+def test_primal_dual_cli_L2_and_spacing(golden):
+    g = golden("pd")
+    obs = g["obs_3d"]
+    out = orc.primal_dual_denoise(obs.flatten(), obs.shape, "TV", "L2", 0.03,
+                                  40, 8.0, "ALG2")
+    assert rel_l2(out, g["pd_3d_ALG2_TVL2_L2eq8"]) < 1e-11
+    out = orc.primal_dual_denoise(obs.flatten(), obs.shape, "TV", "L2", 0.05,
+                                  25, 64.0, "ALG2", spacing=g["pd_spacing"])
+    assert rel_l2(out, g["pd_3d_ALG2_TVL2_spacing"]) < TIGHT
+
+
+def test_refstyle_iteration_equals_restatement(golden):
+    obs = golden("pd")["obs_3d"]
+    a = orc.pd_tvl2_refstyle(obs.flatten(), obs.shape, 0.05, 25, 16.0,
+                             obs.max())
+    assert rel_l2(a, golden("pd")["pd_3d_ALG2_TVL2"]) < TIGHT
+
+
+DEC = {"1d": (50,), "2d": (18, 22), "3d": (12, 14, 16)}
+
+
+def _dec_ops(golden, k):
+    g = golden("admm")
+    shape = DEC[k]
+    cov = g["cov_" + k] if k != "1d" else float(g["cov_1d"].reshape(-1)[0])
+    D, Da, A, Aa = orc.flat_operators(shape, None, cov)
+    return g, shape, A, Aa, D, Da
+
+
+@pytest.mark.parametrize("k", ["1d", "2d", "3d"])
+def test_tikhonov_lsmr_matches_reference(golden, k):
+    g, shape, A, Aa, D, Da = _dec_ops(golden, k)
+    y = g["y_" + k]
+    xs = float(y.max())
+    I = lambda x: x.flatten()
+    out = orc.tikhonov(A, Aa, I, I, y, y, alpha=0.05, x_scale=xs, iter_max=10)
+    assert rel_l2(out, g["tk0_" + k]) < 1e-11
+    out = orc.tikhonov(A, Aa, D, Da, y, y, alpha=0.05, x_scale=xs, iter_max=10)
+    assert rel_l2(out, g["tk1_" + k]) < 1e-11
+    out = orc.tikhonov(A, Aa, D, Da, y, y, alpha=0.0, x_scale=xs, iter_max=6)
+    assert rel_l2(out, g["tk_noreg_" + k]) < 1e-11
+
+
+@pytest.mark.parametrize("k", ["1d", "2d", "3d"])
+def test_admm_lsmr_matches_reference(golden, k):
+    g, shape, A, Aa, D, Da = _dec_ops(golden, k)
+    y = g["y_" + k]
+    out = orc.admm(A, Aa, D, Da, y, y, len(shape), alpha=0.05, rho=0.5,
+                   iterations=6, iter_max=8, x_scale=float(y.max()))
+    assert rel_l2(out, g["admm_lsmr_" + k]) < 1e-10
+
+
+@pytest.mark.parametrize("k", ["1d", "2d"])
+def test_admm_lbfgsb_huber_matches_reference(golden, k):
+    g, shape, A, Aa, D, Da = _dec_ops(golden, k)
+    y = g["y_" + k]
+    out = orc.admm(A, Aa, D, Da, y, y, len(shape), alpha=0.05, rho=0.5,
+                   iterations=3, iter_max=8, minimizer="L-BFGS-B",
+                   data_loss="huber", x_scale=float(y.max()))
+    assert rel_l2(out, g["admm_lbfgsb_huber_" + k]) < 1e-9
+
+
+@pytest.mark.parametrize("lossname", ["huber", "soft_l1", "cauchy", "arctan",
+                                      "linear"])
+def test_tikhonov_minimize_losses_match_reference(golden, lossname):
+    g, shape, A, Aa, D, Da = _dec_ops(golden, "2d")
+    y = g["y_2d"]
+    out = orc.tikhonov(A, Aa, D, Da, y, y, alpha=0.05, x_scale=float(y.max()),
+                       iter_max=8, minimizer="L-BFGS-B", data_loss=lossname,
+                       data_loss_scale=0.1)
+    assert rel_l2(out, g["tk1_lbfgsb_%s_2d" % lossname]) < 1e-9
+
+
+def test_config1_and_config2_goldens(golden):
+    g = golden("configs")
+    lena = g["lena_noise_u8"].astype(np.float64)
+    out = orc.primal_dual_denoise(lena.flatten(), lena.shape, "TV", "L2", 0.03,
+                                  50, 8.0, "ALG2")
+    assert rel_l2(out, g["cfg1_lena_TVL2_50it_L2eq8"]) < 2e-7  # f32 storage
+    ph = g["phantom64"].astype(np.float64)
+    out = orc.primal_dual_denoise(ph.flatten(), ph.shape, "TV", "L2", 0.03,
+                                  200, 16.0, "ALG2")
+    assert rel_l2(out, g["cfg2_phantom_TVL2_200it_L2eq16"]) < 2e-7
+
+
+def test_synth_volume_is_deterministic():
+    a = orc.synth_volume(16, 0, "gauss")
+    b = orc.synth_volume(16, 0, "gauss")
+    assert np.array_equal(a, b) and a.shape == (16, 16, 16)
+    s = orc.synth_volume(16, 3, "sp")
+    assert set(np.unique(s)).issubset({0.0, 50.0, 100.0, 150.0})

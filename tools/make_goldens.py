@@ -1,0 +1,359 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the reference (gift-surg/NSoL) in the
+build container.  Run:  python tools/make_goldens.py [--ref /root/reference]
+
+Only DATA is written (inputs + the reference's outputs) into tests/golden/.
+The reference source never enters this repository.  The reference's solver
+modules import `pysitk.python_helper` purely for timing/printing
+(solver.py:152-161, primal_dual_solver.py:238, admm_linear_solver.py:177-180);
+pysitk is not installed here and cannot be fetched, so a no-arithmetic shim with
+those five functions is created in a temporary directory for the duration of
+this script.
+"""
+import argparse
+import gzip
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+def _install_print_timing_shim(tmp):
+    pk = os.path.join(tmp, "pysitk")
+    os.makedirs(pk)
+    open(os.path.join(pk, "__init__.py"), "w").close()
+    with open(os.path.join(pk, "definitions.py"), "w") as f:
+        f.write("DIR_TMP = %r\n" % tmp)
+    with open(os.path.join(pk, "python_helper.py"), "w") as f:
+        f.write(
+            "import time, datetime\n"
+            "def start_timing():\n    return time.time()\n"
+            "def stop_timing(t0):\n"
+            "    return datetime.timedelta(seconds=time.time() - t0)\n"
+            "def print_info(*a, **k):\n    pass\n"
+            "def print_title(*a, **k):\n    pass\n"
+            "def print_subtitle(*a, **k):\n    pass\n")
+    sys.path.insert(0, tmp)
+
+
+def read_nifti_f64(path):
+    """Minimal NIfTI-1 reader for the reference's 64^3 float64 phantom."""
+    raw = gzip.open(path, "rb").read()
+    hdr = np.frombuffer(raw[:348], dtype=np.uint8)
+    dim = np.frombuffer(raw[40:56], dtype="<i2")
+    datatype = np.frombuffer(raw[70:72], dtype="<i2")[0]
+    vox_offset = int(np.frombuffer(raw[108:112], dtype="<f4")[0])
+    assert datatype == 64 and dim[0] == 3, (datatype, dim)
+    nx, ny, nz = int(dim[1]), int(dim[2]), int(dim[3])
+    data = np.frombuffer(raw[vox_offset:vox_offset + 8 * nx * ny * nz],
+                         dtype="<f8")
+    del hdr
+    return data.reshape(nz, ny, nx).copy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    sys.dont_write_bytecode = True
+    tmp = tempfile.mkdtemp(prefix="nsol_goldens_")
+    _install_print_timing_shim(tmp)
+    sys.path.insert(0, args.ref)
+
+    import nsol.kernels as K
+    import nsol.linear_operators as LO
+    import nsol.loss_functions as LF
+    import nsol.primal_dual_solver as PD
+    import nsol.admm_linear_solver as ADMM
+    import nsol.tikhonov_linear_solver as TK
+    from nsol.proximal_operators import ProximalOperators as prox
+
+    rng = np.random.default_rng(20261003)
+
+    # ------------------------------------------------------------------ ops
+    g = {}
+    shapes = {"1d": (23,), "2d": (10, 13), "3d": (7, 10, 13)}
+    spac = {"1d": 1.5, "2d": np.array([2.0, 0.5]),
+            "3d": np.array([2.0, 4.0, 0.5])}
+    LOs = {"1d": LO.LinearOperators1D, "2d": LO.LinearOperators2D,
+           "3d": LO.LinearOperators3D}
+    for k, shp in shapes.items():
+        d = len(shp)
+        x = rng.standard_normal(shp)
+        zshape = (d * shp[0],) + shp[1:] if d > 1 else shp
+        p = rng.standard_normal(zshape)
+        g["x_" + k] = x
+        g["p_" + k] = p
+        for tag, sp in (("unit", None), ("sp", spac[k])):
+            lo = LOs[k]() if sp is None else LOs[k](spacing=sp)
+            gr, gra = lo.get_gradient_operators()
+            g["grad_%s_%s" % (k, tag)] = gr(x)
+            g["gradadj_%s_%s" % (k, tag)] = gra(p)
+            if sp is not None:
+                g["spacing_" + k] = np.atleast_1d(sp).astype(float)
+            Dx, Dxa = lo.get_dx_operators()
+            g["dx_%s_%s" % (k, tag)] = Dx(x)
+            g["dxadj_%s_%s" % (k, tag)] = Dxa(x)
+            if d >= 2:
+                Dy, Dya = lo.get_dy_operators()
+                g["dy_%s_%s" % (k, tag)] = Dy(x)
+                g["dyadj_%s_%s" % (k, tag)] = Dya(x)
+            if d == 3:
+                Dz, Dza = lo.get_dz_operators()
+                g["dz_%s_%s" % (k, tag)] = Dz(x)
+                g["dzadj_%s_%s" % (k, tag)] = Dza(x)
+
+    # Gaussian taps + blur: isotropic, anisotropic (axis quirk), spacing,
+    # and an axis shorter than the tap extent (tests/kernels_test.py:46 shape)
+    g["taps_1d"] = K.Kernels1D().get_gaussian(2.0)
+    g["taps_1d_sp"] = K.Kernels1D(spacing=1.5).get_gaussian(2.0, alpha_cut=4)
+    A, _ = LO.LinearOperators1D().get_gaussian_blurring_operators(2.0)
+    g["blur_1d"] = A(g["x_1d"])
+    cov2 = np.diag([2.0, 2.0])
+    g["taps_2d"] = K.Kernels2D().get_gaussian(cov2)
+    A, _ = LO.LinearOperators2D().get_gaussian_blurring_operators(cov2)
+    g["blur_2d"] = A(g["x_2d"])
+    cov2a = np.diag([1.0, 4.0])
+    g["cov_2d_aniso"] = cov2a
+    g["taps_2d_aniso"] = K.Kernels2D().get_gaussian(cov2a)
+    A, _ = LO.LinearOperators2D().get_gaussian_blurring_operators(cov2a)
+    g["blur_2d_aniso"] = A(g["x_2d"])
+    cov2f = np.array([[2.0, 0.6], [0.6, 1.0]])
+    g["cov_2d_full"] = cov2f
+    g["taps_2d_full"] = K.Kernels2D().get_gaussian(cov2f)
+    A, _ = LO.LinearOperators2D().get_gaussian_blurring_operators(cov2f)
+    g["blur_2d_full"] = A(g["x_2d"])
+    cov3 = np.diag([2.0, 2.0, 2.0])
+    g["taps_3d"] = K.Kernels3D().get_gaussian(cov3)
+    A, _ = LO.LinearOperators3D().get_gaussian_blurring_operators(cov3)
+    g["blur_3d"] = A(g["x_3d"])      # axis 0 has 7 < 11 taps -> multi-wrap
+    cov3a = np.diag([1.0, 4.0, 9.0])
+    g["cov_3d_aniso"] = cov3a
+    g["taps_3d_aniso"] = K.Kernels3D().get_gaussian(cov3a)
+    x3b = rng.standard_normal((20, 14, 9))
+    g["x_3d_b"] = x3b
+    A, _ = LO.LinearOperators3D().get_gaussian_blurring_operators(cov3a)
+    g["blur_3d_aniso"] = A(x3b)
+    g["taps_3d_sp"] = K.Kernels3D(spacing=spac["3d"]).get_gaussian(
+        cov3 * 2, alpha_cut=2)
+    A, _ = LO.LinearOperators3D(spacing=spac["3d"]).\
+        get_gaussian_blurring_operators(cov3 * 2, alpha_cut=2)
+    g["blur_3d_sp"] = A(x3b)
+    # generic convolution with an asymmetric, even-sized user kernel
+    ker = rng.standard_normal((2, 3, 4))
+    g["userker_3d"] = ker
+    for mode in ("wrap", "constant", "nearest", "reflect", "mirror"):
+        C, Ca = LO.LinearOperators3D().\
+            get_convolution_and_adjoint_convolution_operators(ker, mode=mode)
+        g["userconv_3d_" + mode] = C(x3b)
+    ker2 = rng.standard_normal((3, 2))
+    g["userker_2d"] = ker2
+    C, _ = LO.LinearOperators2D().\
+        get_convolution_and_adjoint_convolution_operators(ker2)
+    g["userconv_2d_wrap"] = C(g["x_2d"])
+
+    # proxes (element-wise)
+    v = 3.0 * rng.standard_normal(501)
+    v[:5] = [0.0, 1.0, -1.0, 1.0 + 1e-12, -0.5]
+    b0 = 100.0 * rng.random(501)
+    g["prox_in"] = v
+    g["prox_b"] = b0
+    g["prox_tv_conj"] = prox.prox_tv_conj(np.array(v), 0.7)
+    g["prox_huber_conj"] = prox.prox_huber_conj(np.array(v), 0.7)
+    g["prox_ell1"] = prox.prox_ell1_denoising(np.array(v), 0.3, b0, 50.0)
+    g["prox_ell2"] = prox.prox_ell2_denoising(np.array(v), 0.3, b0, 50.0)
+    # losses
+    f2 = np.concatenate(([0.0, 1.345 ** 2, 1.8], 9.0 * rng.random(60)))
+    g["loss_f2"] = f2
+    for name in ("linear", "soft_l1", "huber", "cauchy", "arctan"):
+        for fs in (1.0, 1.7):
+            g["loss_%s_%g" % (name, fs)] = LF.LossFunctions.get_loss[name](
+                f2=f2, f_scale=fs)
+            g["gradloss_%s_%g" % (name, fs)] = \
+                LF.LossFunctions.get_gradient_loss[name](f2=f2, f_scale=fs)
+    # ADMM isotropic shrink
+    t3 = rng.standard_normal((3 * 6, 5, 4))
+    g["shrink_in"] = t3
+    dummy = ADMM.ADMMLinearSolver(A=None, A_adj=None, b=np.zeros(1), B=None,
+                                  B_adj=None, x0=np.zeros(1), dimension=3)
+    g["shrink_out"] = dummy._prox_g(t3, tau=0.9, dimension=3)
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **g)
+
+    # ------------------------------------------------------------ PD solver
+    def run_pd(obs, reg, data, alpha, iters, L2, alg, spacing=None):
+        d = obs.ndim
+        b = obs.flatten()
+        x0 = obs.flatten()
+        x_scale = np.max(obs)
+        lo = LOs["%dd" % d]() if spacing is None else \
+            LOs["%dd" % d](spacing=spacing)
+        grad, grad_adj = lo.get_gradient_operators()
+        X_shape = obs.shape
+        Z_shape = grad(obs).shape
+        D = lambda x: grad(x.reshape(*X_shape)).flatten()
+        D_adj = lambda x: grad_adj(x.reshape(*Z_shape)).flatten()
+        if data == "L1":
+            pf = lambda x, tau: prox.prox_ell1_denoising(
+                x, tau, x0=b, x_scale=x_scale)
+        else:
+            pf = lambda x, tau: prox.prox_ell2_denoising(
+                x, tau, x0=b, x_scale=x_scale)
+        pg = prox.prox_huber_conj if reg == "Huber" else prox.prox_tv_conj
+        s = PD.PrimalDualSolver(prox_f=pf, prox_g_conj=pg, B=D, B_conj=D_adj,
+                                L2=L2, x0=x0, alpha=alpha, iterations=iters,
+                                x_scale=x_scale, alg_type=alg)
+        s.run()
+        return s.get_x()
+
+    g = {}
+    def noisy_blocks(shape):
+        idx = np.indices(shape)
+        v = 100.0 * ((sum(i // 4 for i in idx)) % 2) + 20.0
+        return v + 8.0 * rng.standard_normal(shape)
+    obs = {"1d": noisy_blocks((50,)), "2d": noisy_blocks((32, 40)),
+           "3d": noisy_blocks((16, 20, 24))}
+    for k, o in obs.items():
+        g["obs_" + k] = o
+    cases = []
+    for k in ("1d", "2d", "3d"):
+        L2 = {"1d": 4.0, "2d": 8.0, "3d": 16.0}[k]
+        for alg in ("ALG2", "ALG2_AHMOD", "ALG3"):
+            for reg in ("TV", "Huber"):
+                for data in ("L2", "L1"):
+                    alpha = 0.05 if data == "L2" else 0.6
+                    name = "pd_%s_%s_%s%s" % (k, alg, reg, data)
+                    g[name] = run_pd(obs[k], reg, data, alpha, 25, L2, alg)
+                    cases.append(name)
+    # CLI-faithful L2=8 on 3D (run_denoising.py:147) and non-unit spacing
+    g["pd_3d_ALG2_TVL2_L2eq8"] = run_pd(obs["3d"], "TV", "L2", 0.03, 40, 8.0,
+                                        "ALG2")
+    g["pd_3d_ALG2_TVL2_spacing"] = run_pd(
+        obs["3d"], "TV", "L2", 0.05, 25, 64.0, "ALG2",
+        spacing=np.array([2.0, 4.0, 0.5]))
+    g["pd_spacing"] = np.array([2.0, 4.0, 0.5])
+    np.savez_compressed(os.path.join(OUT, "pd.npz"), **g)
+
+    # ----------------------------------------------- Tikhonov / ADMM solvers
+    g = {}
+
+    def ops_for(shape, cov, spacing=None):
+        d = len(shape)
+        lo = LOs["%dd" % d]() if spacing is None else \
+            LOs["%dd" % d](spacing=spacing)
+        A, A_adj = lo.get_gaussian_blurring_operators(cov)
+        grad, grad_adj = lo.get_gradient_operators()
+        X = shape
+        Z = grad(np.zeros(shape)).shape
+        A_ = lambda x: A(x.reshape(*X)).flatten()
+        Aa_ = lambda x: A_adj(x.reshape(*X)).flatten()
+        D_ = lambda x: grad(x.reshape(*X)).flatten()
+        Da_ = lambda x: grad_adj(x.reshape(*Z)).flatten()
+        return A_, Aa_, D_, Da_
+
+    def blocks(shape):
+        idx = np.indices(shape)
+        return 100.0 * ((sum(i // 4 for i in idx)) % 2) + 20.0
+
+    dec = {"1d": ((50,), 1.5), "2d": ((18, 22), np.diag([1.5, 1.5])),
+           "3d": ((12, 14, 16), np.diag([1.0, 1.0, 1.0]))}
+    for k, (shape, cov) in dec.items():
+        A_, Aa_, D_, Da_ = ops_for(shape, cov)
+        gt = blocks(shape)
+        y = A_(gt.flatten()) + 2.0 * rng.standard_normal(gt.size)
+        g["gt_" + k] = gt
+        g["y_" + k] = y
+        g["cov_" + k] = np.atleast_2d(cov)
+        xs = float(y.max())
+        I_ = lambda x: x.flatten()
+        # stand-alone Tikhonov TK0 / TK1 (interface :217-253)
+        s = TK.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=I_, B_adj=I_, b=y,
+                                    x0=y, alpha=0.05, x_scale=xs, iter_max=10)
+        s.run()
+        g["tk0_" + k] = s.get_x()
+        s = TK.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=D_, B_adj=Da_, b=y,
+                                    x0=y, alpha=0.05, x_scale=xs, iter_max=10)
+        s.run()
+        g["tk1_" + k] = s.get_x()
+        # alpha below EPS -> un-augmented system (tikhonov :229, :244-248)
+        s = TK.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=D_, B_adj=Da_, b=y,
+                                    x0=y, alpha=0.0, x_scale=xs, iter_max=6)
+        s.run()
+        g["tk_noreg_" + k] = s.get_x()
+        # ADMM, lsmr path (interface :282-299 wiring)
+        s = ADMM.ADMMLinearSolver(A=A_, A_adj=Aa_, b=y, B=D_, B_adj=Da_,
+                                  x0=y, dimension=len(shape), alpha=0.05,
+                                  rho=0.5, iterations=6, iter_max=8,
+                                  x_scale=xs)
+        s.run()
+        g["admm_lsmr_" + k] = s.get_x()
+        # ADMM, robust loss via L-BFGS-B (b_reg ignored by the reference)
+        s = ADMM.ADMMLinearSolver(A=A_, A_adj=Aa_, b=y, B=D_, B_adj=Da_,
+                                  x0=y, dimension=len(shape), alpha=0.05,
+                                  rho=0.5, iterations=3, iter_max=8,
+                                  minimizer="L-BFGS-B", data_loss="huber",
+                                  x_scale=xs)
+        s.run()
+        g["admm_lbfgsb_huber_" + k] = s.get_x()
+        # Tikhonov robust losses through minimize
+        for lossname in ("huber", "soft_l1", "cauchy", "arctan", "linear"):
+            s = TK.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=D_, B_adj=Da_, b=y,
+                                        x0=y, alpha=0.05, x_scale=xs,
+                                        iter_max=8, minimizer="L-BFGS-B",
+                                        data_loss=lossname,
+                                        data_loss_scale=0.1)
+            s.run()
+            g["tk1_lbfgsb_%s_%s" % (lossname, k)] = s.get_x()
+    # PD deconvolution (prox_linear_least_squares; interface :257-280)
+    shape, cov = dec["2d"]
+    A_, Aa_, D_, Da_ = ops_for(shape, cov)
+    y = g["y_2d"]
+    xs = float(y.max())
+    pf = lambda x, tau: prox.prox_linear_least_squares(
+        x=x, tau=tau, A=A_, A_adj=Aa_, b=y, x0=y, iter_max=10, x_scale=xs)
+    s = PD.PrimalDualSolver(prox_f=pf, prox_g_conj=prox.prox_tv_conj, B=D_,
+                            B_conj=Da_, L2=8, alpha=0.05, x0=y, iterations=8,
+                            x_scale=xs)
+    s.run()
+    g["pd_deconv_2d"] = s.get_x()
+    np.savez_compressed(os.path.join(OUT, "admm.npz"), **g)
+
+    # ------------------------------------ BASELINE configs 1 and 2 (data/)
+    g = {}
+    from PIL import Image
+    lena = np.array(Image.open(os.path.join(
+        args.ref, "data", "2D_Lena_256_noise.png")))
+    assert lena.ndim == 2
+    g["lena_noise_u8"] = lena.astype(np.uint8)
+    g["cfg1_lena_TVL2_50it_L2eq8"] = run_pd(
+        lena.astype(np.float64), "TV", "L2", 0.03, 50, 8.0, "ALG2"
+    ).astype(np.float32)
+    ph3 = read_nifti_f64(os.path.join(
+        args.ref, "data", "3D_SheppLoganPhantom_64.nii.gz"))
+    g["phantom64"] = ph3.astype(np.float32)
+    assert np.array_equal(g["phantom64"].astype(np.float64), ph3)
+    noisy = ph3 + 0.05 * ph3.max() * np.random.default_rng(1).\
+        standard_normal(ph3.shape)
+    g["phantom64_noise_seed"] = np.array(1)
+    for L2 in (8.0, 16.0):
+        g["cfg2_phantom_TVL2_200it_L2eq%d" % L2] = run_pd(
+            ph3, "TV", "L2", 0.03, 200, L2, "ALG2").astype(np.float32)
+        g["cfg2_noisy_TVL2_200it_L2eq%d" % L2] = run_pd(
+            noisy, "TV", "L2", 0.03, 200, L2, "ALG2").astype(np.float32)
+    g["cfg2_noisy_TVL1_200it_L2eq16"] = run_pd(
+        noisy, "TV", "L1", 0.6, 200, 16.0, "ALG2").astype(np.float32)
+    g["cfg2_noisy_HuberL2_200it_L2eq16"] = run_pd(
+        noisy, "Huber", "L2", 0.03, 200, 16.0, "ALG2").astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "configs.npz"), **g)
+    print("goldens written to", os.path.abspath(OUT))
+    for f in sorted(os.listdir(OUT)):
+        print("  %-16s %8.1f KiB" % (f, os.path.getsize(
+            os.path.join(OUT, f)) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()
