@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Chambolle-Pock primal-dual iterations/sec on a synthetic
+512^3 float32 TV-L2 denoising problem (BASELINE.json configs[2]), one volume
+per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is ONE primal-dual iteration = one launch of the single-pass fused
+kernel over the whole volume (inputs already resident in HBM).  N > 1: launched
+by torch.distributed.run, one rank per GPU, each rank owns its own volume (weak
+scaling, no per-iteration collective); after the timed region the results are
+gathered once on rank 0 over RCCL (reported as gather_ms, not part of `value`).
+Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_VOXEL = 44        # 11 float32 words: read xbar,x,b,p[3]; write p[3],x,xbar
+
+
+class HipEvents(object):
+    """hipEvent timing on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [
+            ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+
+    def create(self):
+        ev = ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(ev)) == 0
+        return ev
+
+    def record(self, ev, stream):
+        assert self.hip.hipEventRecord(ev, ctypes.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        assert self.hip.hipEventSynchronize(b) == 0
+        ms = ctypes.c_float()
+        assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+        return float(ms.value)
+
+
+def cpu_baseline(sample_n, iters):
+    """Reference-style NumPy/SciPy iteration (oracle port) on the host."""
+    from oracle import nsol_oracle as orc
+    vol = orc.synth_volume(sample_n, 0, "gauss")
+    b = vol.reshape(-1)
+    xs = float(vol.max())
+    shape = vol.shape
+    orc.pd_tvl2_refstyle(b, shape, 0.03, 1, 16.0, xs)          # warm-up
+    t0 = time.time()
+    orc.pd_tvl2_refstyle(b, shape, 0.03, iters, 16.0, xs)
+    dt = time.time() - t0
+    return iters / dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--data", default="L2", choices=["L2", "L1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(
+            "cuda", local_rank))
+
+    from nsol_amd import ops, _lib
+    from nsol_amd.primal_dual_solver import step_schedule
+    from nsol_amd.synthetic import synth_volume
+    _lib.load()
+
+    n = args.size
+    shape = (n, n, n)
+    nvox = n ** 3
+    alpha = 0.03 if args.data == "L2" else 0.6
+    kind = "gauss" if args.data == "L2" else "sp"
+    vol = synth_volume(n, seed=rank, kind=kind, dtype=np.float32)
+    x_scale = float(vol.max())
+    dev = torch.device("cuda", local_rank)
+    bt = torch.from_numpy(vol.reshape(-1)).to(dev)
+    del vol
+    bt = ops.scale(bt, x_scale, divide=True)          # b~ = b / x_scale
+    x = bt.clone()
+    xbar = [bt.clone(), torch.empty_like(bt)]
+    p = [torch.zeros(3 * nvox, dtype=torch.float32, device=dev)
+         for _ in range(2)]
+    w = (1.0, 1.0, 1.0)
+    lmbda = 1.0 / alpha
+    total = args.warmup + args.steps
+    sig, ta, th = step_schedule("ALG2", 16.0, lmbda, total)
+    flags = ops.PD_REG_TV | (ops.PD_DATA_L1 if args.data == "L1"
+                             else ops.PD_DATA_L2)
+
+    def run(first, count, p_is_zero):
+        # ping-pong parity follows the global iteration index
+        a, b_ = (0, 1) if first % 2 == 0 else (1, 0)
+        ops.pd_run(xbar[a], xbar[b_], x, bt, p[a], p[b_], shape, w, lmbda,
+                   sig[first:first + count], ta[first:first + count],
+                   th[first:first + count], p_is_zero, 0.05, flags)
+
+    if args.warmup > 0:
+        run(0, args.warmup, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = HipEvents()
+    e0, e1 = ev.create(), ev.create()
+    stream = torch.cuda.current_stream().cuda_stream
+    t0 = time.perf_counter()
+    ev.record(e0, stream)
+    run(args.warmup, args.steps, args.warmup == 0)
+    ev.record(e1, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev.elapsed_ms(e0, e1) / args.steps     # avg launch duration
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+
+    gather_ms = None
+    if world > 1:                                     # the one collective
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        res = ops.scale(x, x_scale)
+        bucket = [torch.empty_like(res) for _ in range(world)] \
+            if rank == 0 else None
+        dist.gather(res, gather_list=bucket, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        del bucket
+
+    finite = bool(torch.isfinite(x).all().item())
+
+    if rank == 0:
+        value = world * args.steps / tmax
+        achieved = BYTES_PER_VOXEL * nvox / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "primal-dual iters/sec on %d^3 fp32 TV-%s" %
+                      (n, args.data),
+            "value": value, "unit": "iterations/s (summed over volumes)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": tmax / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "synth_volume(%d, seed=rank, '%s'), TV-%s "
+                            "denoising, Chambolle-Pock ALG2, L2=16, "
+                            "alpha=%g, one volume per GPU" %
+                            (n, kind, args.data, alpha),
+                "volumes": world, "voxels_per_volume": nvox,
+                "kernel": "k_pd_fused (single pass)",
+                "gather_ms": gather_ms, "result_finite": finite},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "bytes_per_launch": BYTES_PER_VOXEL * nvox,
+                "avg_launch_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sn = args.cpu_sample
+            its = cpu_baseline(sn, 2)
+            out["cpu_baseline"] = {
+                "value": its * (sn ** 3) / float(nvox),
+                "unit": "iterations/s", "cores": 1, "kind": "port",
+                "host_cores_available": os.cpu_count(),
+                "sample": "oracle pd_tvl2_refstyle (NumPy float64 + "
+                          "scipy.ndimage, reference op sequence), %d^3 "
+                          "volume, 2 iterations after 1 warm-up, scaled by "
+                          "voxel count to %d^3" % (sn, n)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

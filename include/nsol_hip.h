@@ -1,0 +1,290 @@
+/*
+ * nsol_hip.h -- C ABI of libnsol_hip.so: MI355X (gfx950) kernels for the
+ * per-iteration hot path of NSoL's PrimalDualSolver.run() and
+ * ADMMLinearSolver.run().
+ *
+ * The reference (gift-surg/NSoL v0.1.14) is pure Python and has no FFI; its
+ * operator interface is a set of Python callables on flat arrays.  Each entry
+ * point below replaces the NumPy/SciPy call sites named in its comment
+ * (paths relative to the reference root).  The Python host package
+ * `nsol_amd` binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller, except where the
+ *    name ends in `_host`;
+ *  - volumes are C-contiguous [nz][ny][nx] (x fastest); 2-D: nz = 1;
+ *    1-D: nz = ny = 1.  `ndim` (1..3) says how many gradient components exist;
+ *  - a gradient field is `ndim` stacked volumes [x-comp; y-comp; z-comp]
+ *    (reference linear_operators.py:140 np.concatenate on axis 0);
+ *  - wx, wy, wz are the INVERSE spacings 1/h of the x, y, z axes
+ *    (reference kernels.py:102-112,160-190,240-286 scale taps by 1/spacing);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - functions are stateless, never allocate, never synchronise, never throw;
+ *    they return 0 on success, a positive hipError_t on a HIP failure and
+ *    NSOL_EINVAL (-1) on bad arguments;
+ *  - suffix _f32 / _f64 = element type of all volume arguments.  Scalars are
+ *    always passed as double and rounded to the element type inside.
+ */
+#ifndef NSOL_HIP_H
+#define NSOL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSOL_HIP_ABI_VERSION 1
+#define NSOL_EINVAL (-1)
+
+/* boundary modes of scipy.ndimage.convolve as used by
+ * linear_operators.py:60-68 (mode="wrap") and :98-106 (mode="constant") */
+#define NSOL_MODE_CONSTANT 0
+#define NSOL_MODE_WRAP 1
+#define NSOL_MODE_NEAREST 2
+#define NSOL_MODE_REFLECT 3 /* d c b a | a b c d | d c b a */
+#define NSOL_MODE_MIRROR 4  /* d c b | a b c d | c b a   */
+
+/* flags of the primal-dual kernels */
+#define NSOL_PD_REG_TV 0    /* proximal_operators.py:138-140 prox_tv_conj   */
+#define NSOL_PD_REG_HUBER 1 /* proximal_operators.py:156-159 prox_huber_conj */
+#define NSOL_PD_DATA_L2 0   /* proximal_operators.py:117-120 prox_ell2_denoising */
+#define NSOL_PD_DATA_L1 2   /* proximal_operators.py:95-98  prox_ell1_denoising */
+
+/* loss ids, loss_functions.py:251-266 */
+#define NSOL_LOSS_LINEAR 0
+#define NSOL_LOSS_SOFT_L1 1
+#define NSOL_LOSS_HUBER 2
+#define NSOL_LOSS_CAUCHY 3
+#define NSOL_LOSS_ARCTAN 4
+
+int nsol_hip_abi_version(void);
+/* number of doubles a reduction workspace must hold (see *_ws arguments) */
+int nsol_hip_reduce_ws_doubles(void);
+
+/* ---------------------------------------------------------------------- *
+ * Finite differences
+ * ---------------------------------------------------------------------- */
+/* K = grad: g[a] = D_a x, (D_a x)[i] = x[i+e_a]*w_a + x[i]*(-w_a), x := 0 past
+ * the last index.  Replaces linear_operators.py:121-144 (`grad`, three
+ * ndimage.convolve calls + np.concatenate). */
+int nsol_grad_f32(const float *x, float *g, int ndim, int64_t nz, int64_t ny,
+                  int64_t nx, double wx, double wy, double wz, void *stream);
+int nsol_grad_f64(const double *x, double *g, int ndim, int64_t nz, int64_t ny,
+                  int64_t nx, double wx, double wy, double wz, void *stream);
+/* K^T: out[i] = sum_a p_a[i]*(-w_a) + p_a[i-e_a]*w_a, p := 0 before the first
+ * index.  Replaces linear_operators.py:158-169 (_get_adjoint_gradient_operator). */
+int nsol_grad_adj_f32(const float *p, float *out, int ndim, int64_t nz,
+                      int64_t ny, int64_t nx, double wx, double wy, double wz,
+                      void *stream);
+int nsol_grad_adj_f64(const double *p, double *out, int ndim, int64_t nz,
+                      int64_t ny, int64_t nx, double wx, double wy, double wz,
+                      void *stream);
+/* single-axis D_a (adjoint = 0) or D_a^T (adjoint = 1); dir 0 = x, 1 = y, 2 = z.
+ * Replaces linear_operators.py:98-106, 193-247 (get_d{x,y,z}_operators). */
+int nsol_diff_axis_f32(const float *x, float *out, int dir, int adjoint,
+                       int64_t nz, int64_t ny, int64_t nx, double w,
+                       void *stream);
+int nsol_diff_axis_f64(const double *x, double *out, int dir, int adjoint,
+                       int64_t nz, int64_t ny, int64_t nx, double w,
+                       void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Convolution (Gaussian blur A = A^T and user kernels)
+ * ---------------------------------------------------------------------- */
+/* 1-D correlation along one ARRAY axis (0 = z, 1 = y, 2 = x):
+ *   out[i] = sum_{t<ntaps} taps_host[t] * x[i + t - centre]   (index mapped by `mode`).
+ * Three calls implement the separable Gaussian of linear_operators.py:82-86 /
+ * kernels.py:198-238 (diagonal covariance).  taps_host: HOST pointer, ntaps <= 129;
+ * the taps are copied into kernel arguments.  x and out must not alias. */
+int nsol_corr_axis_f32(const float *x, float *out, int axis, int64_t nz,
+                       int64_t ny, int64_t nx, const double *taps_host,
+                       int ntaps, int centre, int mode, void *stream);
+int nsol_corr_axis_f64(const double *x, double *out, int axis, int64_t nz,
+                       int64_t ny, int64_t nx, const double *taps_host,
+                       int ntaps, int centre, int mode, void *stream);
+/* dense N-D correlation with DEVICE taps [kz][ky][kx] and centre (cz,cy,cx):
+ *   out[i] = sum_t taps[t] * x[i + t - c].  Replaces linear_operators.py:60-68
+ * (scipy.ndimage.convolve with an arbitrary kernel; the host flips the kernel
+ * and derives the centre as ndimage does). */
+int nsol_corr_dense_f32(const float *x, float *out, int64_t nz, int64_t ny,
+                        int64_t nx, const float *taps, int kz, int ky, int kx,
+                        int cz, int cy, int cx, int mode, void *stream);
+int nsol_corr_dense_f64(const double *x, double *out, int64_t nz, int64_t ny,
+                        int64_t nx, const double *taps, int kz, int ky, int kx,
+                        int cz, int cy, int cx, int mode, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Element-wise building blocks (n = number of elements; out may alias inputs)
+ * ---------------------------------------------------------------------- */
+/* out = a*x + b*y            (primal_dual_solver.py:243,246,253 axpys) */
+int nsol_lincomb2_f32(float *out, double a, const float *x, double b,
+                      const float *y, int64_t n, void *stream);
+int nsol_lincomb2_f64(double *out, double a, const double *x, double b,
+                      const double *y, int64_t n, void *stream);
+/* out = a*x + b*y + c*z      (admm_linear_solver.py:208,222) */
+int nsol_lincomb3_f32(float *out, double a, const float *x, double b,
+                      const float *y, double c, const float *z, int64_t n,
+                      void *stream);
+int nsol_lincomb3_f64(double *out, double a, const double *x, double b,
+                      const double *y, double c, const double *z, int64_t n,
+                      void *stream);
+/* out = x * a (divide = 0) or x / a (divide = 1)   (solver.py:37,117-118) */
+int nsol_scale_f32(float *out, const float *x, double a, int divide, int64_t n,
+                   void *stream);
+int nsol_scale_f64(double *out, const double *x, double a, int divide,
+                   int64_t n, void *stream);
+/* out = min(max(x, lo), hi)  (tikhonov_linear_solver.py:142-143,156-158) */
+int nsol_clip_f32(float *out, const float *x, double lo, double hi, int64_t n,
+                  void *stream);
+int nsol_clip_f64(double *out, const double *x, double lo, double hi,
+                  int64_t n, void *stream);
+/* out = (x / den) / max(1, |x / den|): prox_tv_conj (den = 1) and
+ * prox_huber_conj (den = 1 + sigma*gamma), proximal_operators.py:138-159 */
+int nsol_prox_dual_clamp_f32(float *out, const float *x, double den, int64_t n,
+                             void *stream);
+int nsol_prox_dual_clamp_f64(double *out, const double *x, double den,
+                             int64_t n, void *stream);
+/* out = (x + tau*bt) / (1 + tau), bt = b / x_scale precomputed;
+ * proximal_operators.py:117-120 */
+int nsol_prox_ell2_f32(float *out, const float *x, const float *bt, double tau,
+                       int64_t n, void *stream);
+int nsol_prox_ell2_f64(double *out, const double *x, const double *bt,
+                       double tau, int64_t n, void *stream);
+/* out = bt + max(|x - bt| - tau, 0) * sign(x - bt); proximal_operators.py:95-98 */
+int nsol_prox_ell1_f32(float *out, const float *x, const float *bt, double tau,
+                       int64_t n, void *stream);
+int nsol_prox_ell1_f64(double *out, const double *x, const double *bt,
+                       double tau, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Reductions (deterministic two-stage; accumulate in double)
+ * ws: device workspace of nsol_hip_reduce_ws_doubles() doubles;
+ * result: device double[1] (dot, sumsq) -- read it back after the stream syncs.
+ * ---------------------------------------------------------------------- */
+/* result[0] = sum x[i]*y[i]   (np.linalg.norm in scipy lsmr.py:320-413) */
+int nsol_dot_f32(const float *x, const float *y, int64_t n, double *result,
+                 double *ws, void *stream);
+int nsol_dot_f64(const double *x, const double *y, int64_t n, double *result,
+                 double *ws, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Primal-dual (Chambolle-Pock) iteration, primal_dual_solver.py:232-261
+ * ---------------------------------------------------------------------- */
+/* dual step: p_out = clamp((p_in + sigma * grad(xbar)) / hden)
+ * (primal_dual_solver.py:242-243 with prox_tv_conj / prox_huber_conj);
+ * p_in may be NULL (= 0, first iteration); p_out may alias p_in. */
+int nsol_pd_dual_step_f32(const float *xbar, const float *p_in, float *p_out,
+                          int ndim, int64_t nz, int64_t ny, int64_t nx,
+                          double wx, double wy, double wz, double sigma,
+                          double hden, void *stream);
+int nsol_pd_dual_step_f64(const double *xbar, const double *p_in,
+                          double *p_out, int ndim, int64_t nz, int64_t ny,
+                          int64_t nx, double wx, double wy, double wz,
+                          double sigma, double hden, void *stream);
+/* primal step: u = x - tau*grad_adj(p); x_new = prox_f(u, tl); xbar = x_new +
+ * theta*(x_new - x); x is updated in place (primal_dual_solver.py:246-256).
+ * flags: NSOL_PD_DATA_L2 | NSOL_PD_DATA_L1; tl = tau*lambda. */
+int nsol_pd_primal_step_f32(const float *p, float *x, float *xbar,
+                            const float *bt, int ndim, int64_t nz, int64_t ny,
+                            int64_t nx, double wx, double wy, double wz,
+                            double tau, double tl, double theta, int flags,
+                            void *stream);
+int nsol_pd_primal_step_f64(const double *p, double *x, double *xbar,
+                            const double *bt, int ndim, int64_t nz, int64_t ny,
+                            int64_t nx, double wx, double wy, double wz,
+                            double tau, double tl, double theta, int flags,
+                            void *stream);
+/* one whole iteration in a single pass over memory (11 words per voxel in 3-D):
+ * reads xbar_in, x, bt, p_in; writes p_out, x (in place), xbar_out.
+ * xbar_out must not alias xbar_in and p_out must not alias p_in (neighbouring
+ * workgroups read the old values).  p_in may be NULL on the first iteration.
+ * flags: NSOL_PD_REG_* | NSOL_PD_DATA_*. */
+int nsol_pd_fused_iter_f32(const float *xbar_in, float *xbar_out, float *x,
+                           const float *bt, const float *p_in, float *p_out,
+                           int ndim, int64_t nz, int64_t ny, int64_t nx,
+                           double wx, double wy, double wz, double sigma,
+                           double hden, double tau, double tl, double theta,
+                           int flags, void *stream);
+int nsol_pd_fused_iter_f64(const double *xbar_in, double *xbar_out, double *x,
+                           const double *bt, const double *p_in, double *p_out,
+                           int ndim, int64_t nz, int64_t ny, int64_t nx,
+                           double wx, double wy, double wz, double sigma,
+                           double hden, double tau, double tl, double theta,
+                           int flags, void *stream);
+/* `iterations` fused iterations enqueued back to back with the host-side step
+ * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
+ * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;
+ * iteration n reads buffer (n & 1) and writes buffer ((n+1) & 1).  p0 is
+ * treated as zero in iteration 0 when p_is_zero != 0.  gamma_huber is the
+ * Huber parameter (0.05). */
+int nsol_pd_run_f32(float *xbar0, float *xbar1, float *x, const float *bt,
+                    float *p0, float *p1, int ndim, int64_t nz, int64_t ny,
+                    int64_t nx, double wx, double wy, double wz, double lambda,
+                    const double *sigma_host, const double *tau_host,
+                    const double *theta_host, int iterations, int p_is_zero,
+                    double gamma_huber, int flags, void *stream);
+int nsol_pd_run_f64(double *xbar0, double *xbar1, double *x, const double *bt,
+                    double *p0, double *p1, int ndim, int64_t nz, int64_t ny,
+                    int64_t nx, double wx, double wy, double wz, double lambda,
+                    const double *sigma_host, const double *tau_host,
+                    const double *theta_host, int iterations, int p_is_zero,
+                    double gamma_huber, int flags, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * ADMM outer update, admm_linear_solver.py:202-218, 239-253
+ * ---------------------------------------------------------------------- */
+/* t = grad(x) + w - c;  n = sqrt(sum_a t_a^2);  v_a = n > thr ?
+ * max(n - thr, 0) * t_a / n : 0;  w = t - v;  rhs = rhs_scale * (v - w + c).
+ * c (b_reg / x_scale) may be NULL (= 0).  w is updated in place; rhs may be
+ * NULL.  grad is fused in (x is the primal volume). */
+int nsol_admm_vw_update_f32(const float *x, float *v, float *w, const float *c,
+                            float *rhs, int ndim, int64_t nz, int64_t ny,
+                            int64_t nx, double wx, double wy, double wz,
+                            double thr, double rhs_scale, void *stream);
+int nsol_admm_vw_update_f64(const double *x, double *v, double *w,
+                            const double *c, double *rhs, int ndim, int64_t nz,
+                            int64_t ny, int64_t nx, double wx, double wy,
+                            double wz, double thr, double rhs_scale,
+                            void *stream);
+/* isotropic vector soft-threshold alone (admm_linear_solver.py:239-253):
+ * t, v are ndim stacked blocks of m elements. */
+int nsol_vector_shrink_f32(const float *t, float *v, int ndim, int64_t m,
+                           double thr, void *stream);
+int nsol_vector_shrink_f64(const double *t, double *v, int ndim, int64_t m,
+                           double thr, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Robust data term, linear_solver.py:315-340 + loss_functions.py:82-248
+ * ---------------------------------------------------------------------- */
+/* r = residual (A x - b).  g = rho'(r^2) * r (may alias r; may be NULL);
+ * result[0] = 0.5 * sum rho(r^2).  loss = NSOL_LOSS_*; f_scale = data_loss_scale. */
+int nsol_loss_cost_grad_f32(const float *r, float *g, int64_t n, int loss,
+                            double f_scale, double *result, double *ws,
+                            void *stream);
+int nsol_loss_cost_grad_f64(const double *r, double *g, int64_t n, int loss,
+                            double f_scale, double *result, double *ws,
+                            void *stream);
+
+/* element-wise rho(f2) and rho'(f2) (either output may be NULL); the API of
+ * loss_functions.py:82-248 (huber's gamma is a parameter there, default 1.345). */
+int nsol_loss_eval_f32(const float *f2, float *rho, float *drho, int64_t n,
+                       int loss, double f_scale, double huber_gamma,
+                       void *stream);
+int nsol_loss_eval_f64(const double *f2, double *rho, double *drho, int64_t n,
+                       int loss, double f_scale, double huber_gamma,
+                       void *stream);
+/* prior values of prior_measures.py:27-52 on a stacked field t (ndim blocks of
+ * m): mode 0: result = sum_i sqrt(sum_a t_a[i]^2)          (total variation)
+ *    mode 1: result = sum_i huber(sum_a t_a[i]^2; gamma) / (2 gamma)  (Huber) */
+int nsol_vector_norm_sum_f32(const float *t, int ndim, int64_t m, int mode,
+                             double gamma, double *result, double *ws,
+                             void *stream);
+int nsol_vector_norm_sum_f64(const double *t, int ndim, int64_t m, int mode,
+                             double gamma, double *result, double *ws,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSOL_HIP_H */

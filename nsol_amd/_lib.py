@@ -1,0 +1,81 @@
+"""ctypes binding of libnsol_hip.so (the C ABI declared in include/nsol_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or does not export a
+symbol, every compute entry point raises.
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libnsol_hip.so")
+HEADER = os.path.join(HERE, "..", "include", "nsol_hip.h")
+
+_lib = None
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_ptr = ctypes.c_void_p
+
+_CTYPE = {"int": c_int, "int64_t": c_i64, "double": c_dbl}
+
+
+class NsolHipError(RuntimeError):
+    pass
+
+
+def declared_symbols(header=HEADER):
+    """Parse include/nsol_hip.h: {name: (restype, [argtypes])}."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bint\s+(nsol_\w+)\s*\(([^)]*)\)\s*;", text):
+        name, args = m.group(1), m.group(2).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(c_ptr)
+                else:
+                    argtypes.append(_CTYPE[a.split()[-2]])
+        out[name] = (c_int, argtypes)
+    return out
+
+
+def load():
+    """Load the library once and set argtypes from the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NsolHipError(
+            "libnsol_hip.so not found at %s -- build it with "
+            "`python -m nsol_amd.build` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, argtypes) in declared_symbols().items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise NsolHipError("libnsol_hip.so does not export %s" % name)
+        fn.restype = res
+        fn.argtypes = argtypes
+    # experiment knob, not part of the reference-facing ABI
+    lib.nsol_hip_set_param.restype = c_int
+    lib.nsol_hip_set_param.argtypes = [ctypes.c_char_p, c_int]
+    if lib.nsol_hip_abi_version() != 1:
+        raise NsolHipError("libnsol_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc == -1:
+            raise ValueError("%s: invalid argument" % what)
+        raise NsolHipError("%s failed with hipError_t %d" % (what, rc))
+
+
+def set_param(name, value):
+    check(load().nsol_hip_set_param(name.encode(), int(value)), "set_param")

@@ -1,0 +1,143 @@
+"""ADMM for TV-regularised linear least squares on MI355X (drop-in for
+nsol/admm_linear_solver.py:28-312):
+
+    min_x 1/2 sum rho((A x - b)^2) + alpha ||B x - b_reg||_{2,1}
+
+Each iteration (admm :202-218):
+  1) x = TikhonovLinearSolver(alpha = rho, b_reg = v - w + b_reg, x0 = x)
+  2) t = B x + w - b_reg;  v = isotropic shrink(t, alpha/rho);  w = t - v
+Step 2 is ONE fused HIP kernel (grad + shrink + both updates + the next
+right-hand side) when B is nsol_amd's gradient operator; otherwise it is
+assembled from the generic kernels.
+"""
+import numpy as np
+
+from . import ops
+from .bridge import BridgedCallable
+from .device import is_device_tensor
+from .linear_solver import LinearSolver
+from .symbolic import trace_operator
+from . import tikhonov_linear_solver as tk
+
+
+class ADMMLinearSolver(LinearSolver):
+
+    def __init__(self, A, A_adj, b, B, B_adj, x0, dimension, b_reg=0,
+                 alpha=0.01, iter_max=10, minimizer="lsmr",
+                 data_loss="linear", data_loss_scale=1, rho=0.5,
+                 iterations=10, x_scale=1, verbose=0, dtype=None):
+        LinearSolver.__init__(
+            self, A=A, A_adj=A_adj, b=b, x0=x0, alpha=alpha, iter_max=iter_max,
+            minimizer=minimizer, data_loss=data_loss,
+            data_loss_scale=data_loss_scale, x_scale=x_scale, verbose=verbose,
+            dtype=dtype)
+        self._B = B
+        self._B_adj = B_adj
+        self._b_reg = self._scaled(b_reg)
+        self._dimension = dimension
+        self._rho = float(rho)
+        self._iterations = iterations
+        self._execution = None
+
+    def set_rho(self, rho):
+        self._rho = rho
+
+    def get_rho(self):
+        return self._rho
+
+    def get_dimension(self):
+        return self._dimension
+
+    def set_iterations(self, iterations):
+        self._iterations = iterations
+
+    def get_iterations(self):
+        return self._iterations
+
+    def get_execution(self):
+        return self._execution
+
+    # ------------------------------------------------------------------
+    def _run(self):
+        if self._observer is not None:
+            self._observer.add_x(self.get_x())
+
+        x = self._x0_device().clone()
+        n = x.numel()
+        B = BridgedCallable(self._B, self._dtype)
+        desc = trace_operator(self._B, n)
+        fused = desc is not None and desc[0] == "grad" and \
+            desc[1].dimension == self._dimension
+        self._execution = "fused-outer" if fused else "generic-outer"
+
+        scalar_c = not is_device_tensor(self._b_reg) and \
+            np.ndim(self._b_reg) == 0
+        c = None
+        if not (scalar_c and float(self._b_reg) == 0.0):
+            if scalar_c:
+                import torch
+                c = torch.full((B(x).numel(),), float(self._b_reg),
+                               dtype=x.dtype, device=x.device)
+            else:
+                c = self._dev(self._b_reg)
+
+        # v = B(x0) - b_reg ; w = 0                         (admm :171-172)
+        v = B(x)
+        if c is not None:
+            v = ops.lincomb2(1.0, v, -1.0, c)
+        import torch
+        w = torch.zeros_like(v)
+        # b_reg of the first x-update: v - w + b_reg        (admm :222)
+        breg = ops.lincomb2(1.0, v, -1.0, w)
+        if c is not None:
+            breg = ops.lincomb2(1.0, breg, 1.0, c, out=breg)
+        thr = self._alpha / self._rho
+
+        for i in range(self._iterations):
+            if self._verbose:
+                print("ADMM iteration %d/%d" % (i + 1, self._iterations))
+            x = self._solve_tikhonov_least_squares(x, breg)
+            if fused:
+                ops.admm_vw_update(x, v, w, c, breg, desc[2], desc[1].w, thr,
+                                   1.0)
+            else:
+                Bx = B(x)
+                t = ops.lincomb2(1.0, Bx, 1.0, w)
+                if c is not None:
+                    t = ops.lincomb2(1.0, t, -1.0, c, out=t)
+                v = ops.vector_shrink(t, self._dimension, thr)
+                w = ops.lincomb2(1.0, t, -1.0, v)
+                breg = ops.lincomb2(1.0, v, -1.0, w)
+                if c is not None:
+                    breg = ops.lincomb2(1.0, breg, 1.0, c, out=breg)
+            self._x = x
+            if self._observer is not None:
+                self._observer.add_x(self.get_x())
+        self._x = x
+
+    def _solve_tikhonov_least_squares(self, x, b_reg):
+        # admm :220-237: data_loss_scale and bounds are NOT forwarded
+        tikhonov = tk.TikhonovLinearSolver(
+            A=self._A, A_adj=self._A_adj, B=self._B, B_adj=self._B_adj,
+            b=self._dev(self._b), b_reg=b_reg, alpha=self._rho, x0=x,
+            x_scale=1, iter_max=self._iter_max, data_loss=self._data_loss,
+            minimizer=self._minimizer, verbose=self._verbose,
+            dtype=self._dtype)
+        tikhonov.run()
+        return tikhonov._x
+
+    def _prox_g(self, t, tau, dimension):
+        """Isotropic vector soft-threshold (admm :239-253); t: device tensor
+        or NumPy array of `dimension` stacked blocks."""
+        if is_device_tensor(t):
+            return ops.vector_shrink(t.contiguous().view(-1), dimension,
+                                     tau).view(t.shape)
+        from .device import to_device, to_numpy
+        arr = np.asarray(t, dtype=np.float64)
+        out = ops.vector_shrink(to_device(arr.reshape(-1), np.float64),
+                                dimension, tau)
+        return to_numpy(out).reshape(arr.shape)
+
+    def _get_cost_regularization_term(self, x):
+        from .prior_measures import PriorMeasures
+        return PriorMeasures.total_variation(x, self._B, self._dimension)

@@ -1,0 +1,92 @@
+// Shared helpers for the gfx950 kernels of libnsol_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nsol_hip.h"
+
+namespace nsol {
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kBlock = 256;          // 4 waves, one per SIMD
+constexpr int kMaxGridBlocks = 4096; // grid-stride cap: 256 CUs x 16
+constexpr int kReducePartials = 1024;
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : static_cast<int>(e);
+}
+
+inline int grid_for(int64_t n, int per_block = kBlock) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > kMaxGridBlocks) b = kMaxGridBlocks;
+  return static_cast<int>(b);
+}
+
+// Volume extents + inverse spacings handed to kernels by value.
+template <typename T>
+struct Geom {
+  int64_t nz, ny, nx;
+  int64_t sy;   // = nx        (row stride)
+  int64_t sz;   // = ny*nx     (plane stride)
+  int64_t n;    // = nz*ny*nx  (component stride of a gradient field)
+  T wx, wy, wz; // 1/h
+  int ndim;
+};
+
+template <typename T>
+inline Geom<T> make_geom(int ndim, int64_t nz, int64_t ny, int64_t nx,
+                         double wx, double wy, double wz) {
+  Geom<T> g;
+  g.nz = nz; g.ny = ny; g.nx = nx;
+  g.sy = nx; g.sz = ny * nx; g.n = nz * ny * nx;
+  g.wx = static_cast<T>(wx); g.wy = static_cast<T>(wy); g.wz = static_cast<T>(wz);
+  g.ndim = ndim;
+  return g;
+}
+
+inline bool geom_ok(int ndim, int64_t nz, int64_t ny, int64_t nx) {
+  if (ndim < 1 || ndim > 3 || nz < 1 || ny < 1 || nx < 1) return false;
+  if (ndim < 3 && nz != 1) return false;
+  if (ndim < 2 && ny != 1) return false;
+  return true;
+}
+
+// ---- scalar maths with the reference's operation order (no FMA: the library
+// is built with -ffp-contract=off so fp64 results are bit-comparable to NumPy)
+template <typename T> __device__ __forceinline__ T t_abs(T v) { return v < T(0) ? -v : v; }
+template <> __device__ __forceinline__ float t_abs<float>(float v) { return fabsf(v); }
+template <> __device__ __forceinline__ double t_abs<double>(double v) { return fabs(v); }
+template <typename T> __device__ __forceinline__ T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T t_sqrt(T v);
+template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
+
+// x / max(1, |x|)   (proximal_operators.py:139-140)
+template <typename T> __device__ __forceinline__ T dual_clamp(T q) {
+  return q / t_max(T(1), t_abs(q));
+}
+
+// np.sign
+template <typename T> __device__ __forceinline__ T t_sign(T v) {
+  return v > T(0) ? T(1) : (v < T(0) ? T(-1) : T(0));
+}
+
+// prox of the data term (proximal_operators.py:95-98, 117-120)
+template <typename T>
+__device__ __forceinline__ T prox_data(T u, T bt, T tl, T one_plus_tl, bool l1) {
+  if (l1) {
+    T d = u - bt;
+    return bt + t_max(t_abs(d) - tl, T(0)) * t_sign(d);
+  }
+  return (u + tl * bt) / one_plus_tl;
+}
+
+}  // namespace nsol
+
+#define NSOL_CHECK_GEOM(ndim, nz, ny, nx) \
+  if (!nsol::geom_ok(ndim, nz, ny, nx)) return NSOL_EINVAL

@@ -1,0 +1,549 @@
+// Stand-alone operators of the NSoL hot path for gfx950: finite differences,
+// element-wise proxes / axpys, deterministic reductions, the ADMM outer update
+// and the robust data term.  All are HBM-bound maps: one coalesced pass, x is
+// the fastest-varying thread index, neighbours along y/z come from other rows
+// that the same or an adjacent wave touches (L1/L2 hits).
+#include "nsol_common.hpp"
+
+using namespace nsol;
+
+namespace {
+
+// ---------------------------------------------------------------- grad ----
+// reference: linear_operators.py:98-106 (D_a = convolve(x, [1,-1]/h, "constant"))
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_grad(const T *__restrict__ x,
+                                                  T *__restrict__ g, Geom<T> G) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
+       i += stride) {
+    const int64_t ix = i % G.nx;
+    const int64_t r = i / G.nx;
+    const int64_t iy = r % G.ny;
+    const int64_t iz = r / G.ny;
+    const T c = x[i];
+    const T xr = (ix + 1 < G.nx) ? x[i + 1] : T(0);
+    g[i] = xr * G.wx + c * (-G.wx);
+    if (G.ndim >= 2) {
+      const T xd = (iy + 1 < G.ny) ? x[i + G.sy] : T(0);
+      g[G.n + i] = xd * G.wy + c * (-G.wy);
+    }
+    if (G.ndim >= 3) {
+      const T xb = (iz + 1 < G.nz) ? x[i + G.sz] : T(0);
+      g[2 * G.n + i] = xb * G.wz + c * (-G.wz);
+    }
+  }
+}
+
+// reference: linear_operators.py:158-169 (sum of D_a^T, accumulated in the
+// order x, y, z as `D_adj_x += ...` does)
+template <typename T>
+__device__ __forceinline__ T grad_adj_at(const T *__restrict__ p, const Geom<T> &G,
+                                         int64_t i, int64_t ix, int64_t iy,
+                                         int64_t iz) {
+  T acc = p[i] * (-G.wx) + ((ix > 0) ? p[i - 1] : T(0)) * G.wx;
+  if (G.ndim >= 2) {
+    const T *py = p + G.n;
+    acc += py[i] * (-G.wy) + ((iy > 0) ? py[i - G.sy] : T(0)) * G.wy;
+  }
+  if (G.ndim >= 3) {
+    const T *pz = p + 2 * G.n;
+    acc += pz[i] * (-G.wz) + ((iz > 0) ? pz[i - G.sz] : T(0)) * G.wz;
+  }
+  return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
+                                                      T *__restrict__ out,
+                                                      Geom<T> G) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
+       i += stride) {
+    const int64_t ix = i % G.nx;
+    const int64_t r = i / G.nx;
+    out[i] = grad_adj_at(p, G, i, ix, r % G.ny, r / G.ny);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_diff_axis(const T *__restrict__ x,
+                                                       T *__restrict__ out,
+                                                       Geom<T> G, int dir,
+                                                       int adjoint, T w) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t step = dir == 0 ? 1 : (dir == 1 ? G.sy : G.sz);
+  const int64_t len = dir == 0 ? G.nx : (dir == 1 ? G.ny : G.nz);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
+       i += stride) {
+    const int64_t ix = i % G.nx;
+    const int64_t r = i / G.nx;
+    const int64_t pos = dir == 0 ? ix : (dir == 1 ? r % G.ny : r / G.ny);
+    const T c = x[i];
+    if (!adjoint) {
+      const T nb = (pos + 1 < len) ? x[i + step] : T(0);
+      out[i] = nb * w + c * (-w);
+    } else {
+      const T nb = (pos > 0) ? x[i - step] : T(0);
+      out[i] = c * (-w) + nb * w;
+    }
+  }
+}
+
+// --------------------------------------------------------- element-wise ----
+template <typename T, typename F>
+__global__ __launch_bounds__(kBlock) void k_map(int64_t n, F f) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    f(i);
+}
+
+template <typename T, typename F>
+inline int launch_map(int64_t n, void *stream, F f) {
+  if (n < 0) return NSOL_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((k_map<T, F>), dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), n, f);
+  return launch_status();
+}
+
+// ------------------------------------------------------------ reductions ----
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// block partial -> ws[blockIdx]; deterministic (fixed tree, fixed order)
+__device__ __forceinline__ void block_store_partial(double v, double *ws) {
+  __shared__ double s[kBlock / kWave];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s[k];
+    ws[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_final(const double *ws,
+                                                          int nparts,
+                                                          double *result,
+                                                          double scale) {
+  double v = 0.0;
+  for (int k = threadIdx.x; k < nparts; k += kBlock) v += ws[k];
+  __shared__ double s[kBlock / kWave];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s[k];
+    result[0] = t * scale;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dot(const T *__restrict__ x,
+                                                 const T *__restrict__ y,
+                                                 int64_t n, double *ws) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride)
+    acc += (double)x[i] * (double)y[i];
+  block_store_partial(acc, ws);
+}
+
+inline int reduce_grid(int64_t n) {
+  int g = grid_for(n);
+  return g > kReducePartials ? kReducePartials : g;
+}
+
+// ------------------------------------------------------------------ ADMM ----
+// admm_linear_solver.py:208-216 with grad fused in
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
+                                                     T *__restrict__ v,
+                                                     T *__restrict__ w,
+                                                     const T *__restrict__ c,
+                                                     T *__restrict__ rhs,
+                                                     Geom<T> G, T thr,
+                                                     T rhs_scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
+       i += stride) {
+    const int64_t ix = i % G.nx;
+    const int64_t r = i / G.nx;
+    const int64_t iy = r % G.ny;
+    const int64_t iz = r / G.ny;
+    const T xc = x[i];
+    T t[3] = {T(0), T(0), T(0)};
+    T cc[3] = {T(0), T(0), T(0)};
+    {
+      const T nb = (ix + 1 < G.nx) ? x[i + 1] : T(0);
+      t[0] = nb * G.wx + xc * (-G.wx);
+    }
+    if (G.ndim >= 2) {
+      const T nb = (iy + 1 < G.ny) ? x[i + G.sy] : T(0);
+      t[1] = nb * G.wy + xc * (-G.wy);
+    }
+    if (G.ndim >= 3) {
+      const T nb = (iz + 1 < G.nz) ? x[i + G.sz] : T(0);
+      t[2] = nb * G.wz + xc * (-G.wz);
+    }
+    T n2 = T(0);
+    for (int a = 0; a < G.ndim; ++a) {
+      if (c) cc[a] = c[a * G.n + i];
+      t[a] = t[a] + w[a * G.n + i] - cc[a];
+      n2 = (a == 0) ? t[a] * t[a] : n2 + t[a] * t[a];
+    }
+    const T nrm = t_sqrt(n2);
+    const bool on = nrm > thr;
+    const T mag = t_max(t_abs(nrm) - thr, T(0)) * t_sign(nrm);
+    for (int a = 0; a < G.ndim; ++a) {
+      const T va = on ? mag * t[a] / nrm : T(0);
+      const T wa = t[a] - va;
+      v[a * G.n + i] = va;
+      w[a * G.n + i] = wa;
+      if (rhs) rhs[a * G.n + i] = rhs_scale * (va - wa + cc[a]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_vector_shrink(const T *__restrict__ t,
+                                                           T *__restrict__ v,
+                                                           int ndim, int64_t m,
+                                                           T thr) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+       i += stride) {
+    T tt[3];
+    T n2 = T(0);
+    for (int a = 0; a < ndim; ++a) {
+      tt[a] = t[a * m + i];
+      n2 = (a == 0) ? tt[a] * tt[a] : n2 + tt[a] * tt[a];
+    }
+    const T nrm = t_sqrt(n2);
+    const bool on = nrm > thr;
+    const T mag = t_max(t_abs(nrm) - thr, T(0)) * t_sign(nrm);
+    for (int a = 0; a < ndim; ++a) v[a * m + i] = on ? mag * tt[a] / nrm : T(0);
+  }
+}
+
+// ---------------------------------------------------------- robust loss ----
+// loss_functions.py:82-248: rho(z*s2)... evaluated on f2 = r^2, z = f2 / f_scale^2
+template <typename T>
+__device__ __forceinline__ void loss_eval(int loss, T f2, T s2, T &rho, T &drho,
+                                          T gm = T(1.345)) {
+  const T z = f2 / s2;
+  switch (loss) {
+    case NSOL_LOSS_SOFT_L1: {
+      const T q = t_sqrt(T(1) + z);
+      rho = T(2) * (q - T(1)) * s2;
+      drho = T(1) / q;
+    } break;
+    case NSOL_LOSS_HUBER: {
+      const T g2 = gm * gm;
+      if (z < g2) { rho = z * s2; drho = T(1); }
+      else {
+        const T q = t_sqrt(z);
+        rho = (T(2) * gm * q - g2) * s2;
+        drho = gm / q;
+      }
+    } break;
+    case NSOL_LOSS_CAUCHY:
+      rho = (T)log1p((double)z) * s2;
+      drho = T(1) / (T(1) + z);
+      break;
+    case NSOL_LOSS_ARCTAN:
+      rho = (T)atan((double)z) * s2;
+      drho = T(1) / (T(1) + z * z);
+      break;
+    default:
+      rho = f2;
+      drho = T(1);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_loss(const T *__restrict__ r,
+                                                  T *__restrict__ g, int64_t n,
+                                                  int loss, T s2, double *ws) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    const T rv = r[i];
+    T rho, drho;
+    loss_eval(loss, rv * rv, s2, rho, drho);
+    acc += (double)rho;
+    if (g) g[i] = drho * rv;
+  }
+  block_store_partial(acc, ws);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_loss_eval(const T *__restrict__ f2,
+                                                       T *rho, T *drho,
+                                                       int64_t n, int loss,
+                                                       T s2, T gm) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    T r, d;
+    loss_eval(loss, f2[i], s2, r, d, gm);
+    if (rho) rho[i] = r;
+    if (drho) drho[i] = d;
+  }
+}
+
+// prior_measures.py:27-52
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_vector_norm_sum(
+    const T *__restrict__ t, int ndim, int64_t m, int mode, T gm, double *ws) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+       i += stride) {
+    T n2 = T(0);
+    for (int a = 0; a < ndim; ++a) {
+      const T v = t[a * m + i];
+      n2 = (a == 0) ? v * v : n2 + v * v;
+    }
+    if (mode == 0) {
+      acc += (double)t_sqrt(n2);
+    } else {
+      T r, d;
+      loss_eval(NSOL_LOSS_HUBER, n2, T(1), r, d, gm);
+      acc += (double)(r / (T(2) * gm));
+    }
+  }
+  block_store_partial(acc, ws);
+}
+
+// ------------------------------------------------------- typed front ends ----
+template <typename T>
+int loss_eval_impl(const T *f2, T *rho, T *drho, int64_t n, int loss,
+                   double f_scale, double gm, void *stream) {
+  if (n < 0 || !f2 || loss < 0 || loss > 4) return NSOL_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_loss_eval<T>, dim3(grid_for(n)), dim3(kBlock), 0,
+                     as_stream(stream), f2, rho, drho, n, loss,
+                     (T)(f_scale * f_scale), (T)gm);
+  return launch_status();
+}
+
+template <typename T>
+int vector_norm_sum_impl(const T *t, int ndim, int64_t m, int mode, double gm,
+                         double *result, double *ws, void *stream) {
+  if (ndim < 1 || ndim > 3 || m < 0 || !t || !result || !ws || mode < 0 ||
+      mode > 1)
+    return NSOL_EINVAL;
+  const int gr = reduce_grid(m);
+  hipLaunchKernelGGL(k_vector_norm_sum<T>, dim3(gr), dim3(kBlock), 0,
+                     as_stream(stream), t, ndim, m, mode, (T)gm, ws);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kBlock), 0, as_stream(stream),
+                     ws, gr, result, 1.0);
+  return launch_status();
+}
+
+template <typename T>
+int grad_impl(const T *x, T *g, int ndim, int64_t nz, int64_t ny, int64_t nx,
+              double wx, double wy, double wz, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !g) return NSOL_EINVAL;
+  Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  hipLaunchKernelGGL(k_grad<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
+                     as_stream(stream), x, g, G);
+  return launch_status();
+}
+
+template <typename T>
+int grad_adj_impl(const T *p, T *out, int ndim, int64_t nz, int64_t ny,
+                  int64_t nx, double wx, double wy, double wz, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!p || !out) return NSOL_EINVAL;
+  Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  hipLaunchKernelGGL(k_grad_adj<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
+                     as_stream(stream), p, out, G);
+  return launch_status();
+}
+
+template <typename T>
+int diff_axis_impl(const T *x, T *out, int dir, int adjoint, int64_t nz,
+                   int64_t ny, int64_t nx, double w, void *stream) {
+  if (dir < 0 || dir > 2 || nz < 1 || ny < 1 || nx < 1 || !x || !out || x == out)
+    return NSOL_EINVAL;
+  Geom<T> G = make_geom<T>(3, nz, ny, nx, 1, 1, 1);
+  hipLaunchKernelGGL(k_diff_axis<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
+                     as_stream(stream), x, out, G, dir, adjoint, (T)w);
+  return launch_status();
+}
+
+template <typename T>
+int dot_impl(const T *x, const T *y, int64_t n, double *result, double *ws,
+             void *stream) {
+  if (n < 0 || !result || !ws || (n > 0 && (!x || !y))) return NSOL_EINVAL;
+  const int g = reduce_grid(n);
+  hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(kBlock), 0, as_stream(stream), x, y,
+                     n, ws);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kBlock), 0, as_stream(stream),
+                     ws, g, result, 1.0);
+  return launch_status();
+}
+
+template <typename T>
+int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
+                 int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                 double wz, double thr, double rhs_scale, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !v || !w) return NSOL_EINVAL;
+  Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  hipLaunchKernelGGL(k_admm_vw<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
+                     as_stream(stream), x, v, w, c, rhs, G, (T)thr,
+                     (T)rhs_scale);
+  return launch_status();
+}
+
+template <typename T>
+int shrink_impl(const T *t, T *v, int ndim, int64_t m, double thr, void *stream) {
+  if (ndim < 1 || ndim > 3 || m < 0 || !t || !v) return NSOL_EINVAL;
+  if (m == 0) return 0;
+  hipLaunchKernelGGL(k_vector_shrink<T>, dim3(grid_for(m)), dim3(kBlock), 0,
+                     as_stream(stream), t, v, ndim, m, (T)thr);
+  return launch_status();
+}
+
+template <typename T>
+int loss_impl(const T *r, T *g, int64_t n, int loss, double f_scale,
+              double *result, double *ws, void *stream) {
+  if (n < 0 || !r || !result || !ws || loss < 0 || loss > 4) return NSOL_EINVAL;
+  const int gr = reduce_grid(n);
+  const T s2 = (T)(f_scale * f_scale);
+  hipLaunchKernelGGL(k_loss<T>, dim3(gr), dim3(kBlock), 0, as_stream(stream), r,
+                     g, n, loss, s2, ws);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kBlock), 0, as_stream(stream),
+                     ws, gr, result, 0.5);
+  return launch_status();
+}
+
+}  // namespace
+
+// ================================ C ABI ====================================
+extern "C" {
+
+int nsol_hip_abi_version(void) { return NSOL_HIP_ABI_VERSION; }
+int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
+
+#define NSOL_DEF2(NAME, T, SUF)                                                  \
+  int nsol_grad_##SUF(const T *x, T *g, int ndim, int64_t nz, int64_t ny,        \
+                      int64_t nx, double wx, double wy, double wz, void *s) {    \
+    return grad_impl<T>(x, g, ndim, nz, ny, nx, wx, wy, wz, s);                  \
+  }                                                                              \
+  int nsol_grad_adj_##SUF(const T *p, T *o, int ndim, int64_t nz, int64_t ny,    \
+                          int64_t nx, double wx, double wy, double wz,           \
+                          void *s) {                                             \
+    return grad_adj_impl<T>(p, o, ndim, nz, ny, nx, wx, wy, wz, s);              \
+  }                                                                              \
+  int nsol_diff_axis_##SUF(const T *x, T *o, int dir, int adj, int64_t nz,       \
+                           int64_t ny, int64_t nx, double w, void *s) {          \
+    return diff_axis_impl<T>(x, o, dir, adj, nz, ny, nx, w, s);                  \
+  }                                                                              \
+  int nsol_lincomb2_##SUF(T *out, double a, const T *x, double b, const T *y,    \
+                          int64_t n, void *s) {                                  \
+    if (n > 0 && (!out || !x || !y)) return NSOL_EINVAL;                         \
+    const T ta = (T)a, tb = (T)b;                                                \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      out[i] = ta * x[i] + tb * y[i];                                            \
+    });                                                                          \
+  }                                                                              \
+  int nsol_lincomb3_##SUF(T *out, double a, const T *x, double b, const T *y,    \
+                          double c, const T *z, int64_t n, void *s) {            \
+    if (n > 0 && (!out || !x || !y || !z)) return NSOL_EINVAL;                   \
+    const T ta = (T)a, tb = (T)b, tc = (T)c;                                     \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      out[i] = ta * x[i] + tb * y[i] + tc * z[i];                                \
+    });                                                                          \
+  }                                                                              \
+  int nsol_scale_##SUF(T *out, const T *x, double a, int divide, int64_t n,      \
+                       void *s) {                                                \
+    if (n > 0 && (!out || !x)) return NSOL_EINVAL;                               \
+    const T ta = (T)a;                                                           \
+    if (divide)                                                                  \
+      return launch_map<T>(n, s,                                                 \
+                           [=] __device__(int64_t i) { out[i] = x[i] / ta; });   \
+    return launch_map<T>(n, s,                                                   \
+                         [=] __device__(int64_t i) { out[i] = x[i] * ta; });     \
+  }                                                                              \
+  int nsol_clip_##SUF(T *out, const T *x, double lo, double hi, int64_t n,       \
+                      void *s) {                                                 \
+    if (n > 0 && (!out || !x)) return NSOL_EINVAL;                               \
+    const T tlo = (T)lo, thi = (T)hi;                                            \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      T v = x[i];                                                                \
+      v = v < tlo ? tlo : v;                                                     \
+      out[i] = v > thi ? thi : v;                                                \
+    });                                                                          \
+  }                                                                              \
+  int nsol_prox_dual_clamp_##SUF(T *out, const T *x, double den, int64_t n,      \
+                                 void *s) {                                      \
+    if (n > 0 && (!out || !x)) return NSOL_EINVAL;                               \
+    const T td = (T)den;                                                         \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      out[i] = dual_clamp<T>(x[i] / td);                                         \
+    });                                                                          \
+  }                                                                              \
+  int nsol_prox_ell2_##SUF(T *out, const T *x, const T *bt, double tau,          \
+                           int64_t n, void *s) {                                 \
+    if (n > 0 && (!out || !x || !bt)) return NSOL_EINVAL;                        \
+    const T tl = (T)tau, opt = (T)(1.0 + tau);                                   \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      out[i] = prox_data<T>(x[i], bt[i], tl, opt, false);                        \
+    });                                                                          \
+  }                                                                              \
+  int nsol_prox_ell1_##SUF(T *out, const T *x, const T *bt, double tau,          \
+                           int64_t n, void *s) {                                 \
+    if (n > 0 && (!out || !x || !bt)) return NSOL_EINVAL;                        \
+    const T tl = (T)tau;                                                         \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      out[i] = prox_data<T>(x[i], bt[i], tl, T(1), true);                        \
+    });                                                                          \
+  }                                                                              \
+  int nsol_dot_##SUF(const T *x, const T *y, int64_t n, double *r, double *ws,   \
+                     void *s) {                                                  \
+    return dot_impl<T>(x, y, n, r, ws, s);                                       \
+  }                                                                              \
+  int nsol_admm_vw_update_##SUF(const T *x, T *v, T *w, const T *c, T *rhs,      \
+                                int ndim, int64_t nz, int64_t ny, int64_t nx,    \
+                                double wx, double wy, double wz, double thr,     \
+                                double rs, void *s) {                            \
+    return admm_vw_impl<T>(x, v, w, c, rhs, ndim, nz, ny, nx, wx, wy, wz, thr,   \
+                           rs, s);                                               \
+  }                                                                              \
+  int nsol_vector_shrink_##SUF(const T *t, T *v, int ndim, int64_t m,            \
+                               double thr, void *s) {                            \
+    return shrink_impl<T>(t, v, ndim, m, thr, s);                                \
+  }                                                                              \
+  int nsol_loss_cost_grad_##SUF(const T *r, T *g, int64_t n, int loss,           \
+                                double fs, double *res, double *ws, void *s) {   \
+    return loss_impl<T>(r, g, n, loss, fs, res, ws, s);                          \
+  }                                                                              \
+  int nsol_loss_eval_##SUF(const T *f2, T *rho, T *drho, int64_t n, int loss,    \
+                           double fs, double gm, void *s) {                      \
+    return loss_eval_impl<T>(f2, rho, drho, n, loss, fs, gm, s);                 \
+  }                                                                              \
+  int nsol_vector_norm_sum_##SUF(const T *t, int ndim, int64_t m, int mode,      \
+                                 double gm, double *res, double *ws, void *s) {  \
+    return vector_norm_sum_impl<T>(t, ndim, m, mode, gm, res, ws, s);            \
+  }
+
+NSOL_DEF2(_, float, f32)
+NSOL_DEF2(_, double, f64)
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+"""LSMR (Fong & Saunders, SIAM J. Sci. Comput. 2011) with all vectors resident
+in HBM.  Replaces the call
+    scipy.sparse.linalg.lsmr(A, b, maxiter=iter_max, atol=0, btol=0)
+of tikhonov_linear_solver.py:149-154 (SciPy 1.15 semantics: damp = 0,
+conlim = 1e8, start from x = 0).
+
+The operator is given in block form so that the augmented system
+[A; sqrt(alpha) B] never needs a concatenated copy:
+    matvec(v)      -> list of device vectors  (one per row block)
+    rmatvec(parts) -> device vector
+Golub-Kahan vectors are updated by HIP axpy kernels, norms are deterministic
+float64 reductions on the GPU; the plane rotations are host scalars.
+"""
+import math
+
+import numpy as np
+
+from . import ops
+
+
+def _sym_ortho(a, b):
+    """Stable Givens rotation: returns (c, s, r) with c*a + s*b = r."""
+    if b == 0:
+        return float(np.sign(a)), 0.0, abs(a)
+    if a == 0:
+        return 0.0, float(np.sign(b)), abs(b)
+    if abs(b) > abs(a):
+        t = a / b
+        s = float(np.sign(b)) / math.sqrt(1 + t * t)
+        return s * t, s, b / s
+    t = b / a
+    c = float(np.sign(a)) / math.sqrt(1 + t * t)
+    return c, c * t, a / c
+
+
+def _norm(parts):
+    return math.sqrt(sum(ops.dot(p, p) for p in parts))
+
+
+def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
+         conlim=1e8):
+    """Minimise ||A x - b||_2.  b_parts: list of device vectors (consumed:
+    they become the u blocks).  x_like: device vector shaped like x.
+    Returns (x, istop, itn)."""
+    import torch
+    u = list(b_parts)
+    normb = _norm(u)
+    x = torch.zeros_like(x_like)
+    beta = normb
+    if beta > 0:
+        for k in range(len(u)):
+            ops.scale(u[k], 1.0 / beta, out=u[k])
+        v = rmatvec(u)
+        alpha = _norm([v])
+    else:
+        v = torch.zeros_like(x_like)
+        alpha = 0.0
+    if alpha > 0:
+        ops.scale(v, 1.0 / alpha, out=v)
+
+    itn = 0
+    zetabar = alpha * beta
+    alphabar = alpha
+    rho = rhobar = cbar = 1.0
+    sbar = 0.0
+    h = v.clone()
+    hbar = torch.zeros_like(x_like)
+    betadd, betad = beta, 0.0
+    rhodold = 1.0
+    tautildeold = thetatilde = zeta = d = 0.0
+    normA2 = alpha * alpha
+    maxrbar, minrbar = 0.0, 1e100
+    istop = 0
+    ctol = 1.0 / conlim if conlim > 0 else 0.0
+    if alpha * beta == 0 or normb == 0:
+        return x, istop, itn
+
+    while itn < maxiter:
+        itn += 1
+        # bidiagonalisation:  beta u = A v - alpha u ;  alpha v = A^T u - beta v
+        Av = matvec(v)
+        for k in range(len(u)):
+            ops.lincomb2(-alpha, u[k], 1.0, Av[k], out=u[k])
+        del Av
+        beta = _norm(u)
+        if beta > 0:
+            for k in range(len(u)):
+                ops.scale(u[k], 1.0 / beta, out=u[k])
+            ops.lincomb2(-beta, v, 1.0, rmatvec(u), out=v)
+            alpha = _norm([v])
+            if alpha > 0:
+                ops.scale(v, 1.0 / alpha, out=v)
+
+        chat, shat, alphahat = _sym_ortho(alphabar, 0.0)
+        rhoold = rho
+        c, s, rho = _sym_ortho(alphahat, beta)
+        thetanew = s * alpha
+        alphabar = c * alpha
+        rhobarold, zetaold = rhobar, zeta
+        thetabar = sbar * rho
+        rhotemp = cbar * rho
+        cbar, sbar, rhobar = _sym_ortho(cbar * rho, thetanew)
+        zeta = cbar * zetabar
+        zetabar = -sbar * zetabar
+
+        ops.lincomb2(-(thetabar * rho / (rhoold * rhobarold)), hbar, 1.0, h,
+                     out=hbar)
+        ops.lincomb2(1.0, x, zeta / (rho * rhobar), hbar, out=x)
+        ops.lincomb2(-(thetanew / rho), h, 1.0, v, out=h)
+
+        betaacute = chat * betadd
+        betacheck = -shat * betadd
+        betahat = c * betaacute
+        betadd = -s * betaacute
+        thetatildeold = thetatilde
+        ctildeold, stildeold, rhotildeold = _sym_ortho(rhodold, thetabar)
+        thetatilde = stildeold * rhobar
+        rhodold = ctildeold * rhobar
+        betad = -stildeold * betad + ctildeold * betahat
+        tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold
+        taud = (zeta - thetatilde * tautildeold) / rhodold
+        d = d + betacheck * betacheck
+        normr = math.sqrt(d + (betad - taud) ** 2 + betadd * betadd)
+        normA2 = normA2 + beta * beta
+        normA = math.sqrt(normA2)
+        normA2 = normA2 + alpha * alpha
+        maxrbar = max(maxrbar, rhobarold)
+        if itn > 1:
+            minrbar = min(minrbar, rhobarold)
+        condA = max(maxrbar, rhotemp) / min(minrbar, rhotemp)
+
+        normar = abs(zetabar)
+        normx = _norm([x])
+        test1 = normr / normb
+        test2 = normar / (normA * normr) if (normA * normr) != 0 else np.inf
+        test3 = 1.0 / condA
+        t1 = test1 / (1 + normA * normx / normb)
+        rtol = btol + atol * normA * normx / normb
+        if itn >= maxiter:
+            istop = 7
+        if 1 + test3 <= 1:
+            istop = 6
+        if 1 + test2 <= 1:
+            istop = 5
+        if 1 + t1 <= 1:
+            istop = 4
+        if test3 <= ctol:
+            istop = 3
+        if test2 <= atol:
+            istop = 2
+        if test1 <= rtol:
+            istop = 1
+        if istop > 0:
+            break
+    return x, istop, itn

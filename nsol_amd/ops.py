@@ -1,0 +1,297 @@
+"""Device-tensor front end of the C ABI (include/nsol_hip.h).
+
+Every function takes/returns contiguous torch HIP tensors of float32 or
+float64 and launches hand-written kernels from libnsol_hip.so on the current
+torch stream.  No arithmetic is done by torch itself.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .device import suffix, stream_ptr, empty_like
+
+MODES = {"constant": 0, "wrap": 1, "nearest": 2, "reflect": 3, "mirror": 4}
+LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
+PD_REG_TV, PD_REG_HUBER, PD_DATA_L2, PD_DATA_L1 = 0, 1, 0, 2
+
+
+def _fn(name, t):
+    return getattr(_lib.load(), "nsol_%s_%s" % (name, suffix(t)))
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+        raise TypeError("expected a contiguous HIP device tensor")
+    return t
+
+
+def dims3(shape):
+    """(ndim, nz, ny, nx) of an N-D volume shape (N = 1, 2, 3)."""
+    shape = tuple(int(s) for s in shape)
+    nd = len(shape)
+    if nd == 1:
+        return 1, 1, 1, shape[0]
+    if nd == 2:
+        return 2, 1, shape[0], shape[1]
+    if nd == 3:
+        return 3, shape[0], shape[1], shape[2]
+    raise ValueError("only 1-D, 2-D and 3-D volumes are supported")
+
+
+def inv_spacing(spacing, ndim):
+    """(wx, wy, wz) = 1/spacing; spacing[0] belongs to the LAST array axis
+    (reference kernels.py:240-286)."""
+    sp = np.atleast_1d(spacing).astype(float)
+    w = [1.0, 1.0, 1.0]
+    for a in range(ndim):
+        w[a] = 1.0 / sp[a]
+    return tuple(w)
+
+
+# ------------------------------------------------------------ operators ----
+def grad(x, shape, w, out=None):
+    _chk(x)
+    ndim, nz, ny, nx = dims3(shape)
+    if out is None:
+        out = empty_like(x, ndim * x.numel())
+    _lib.check(_fn("grad", x)(_p(x), _p(out), ndim, nz, ny, nx, w[0], w[1],
+                              w[2], stream_ptr()), "nsol_grad")
+    return out
+
+
+def grad_adj(p, shape, w, out=None):
+    _chk(p)
+    ndim, nz, ny, nx = dims3(shape)
+    if out is None:
+        out = empty_like(p, nz * ny * nx)
+    _lib.check(_fn("grad_adj", p)(_p(p), _p(out), ndim, nz, ny, nx, w[0], w[1],
+                                  w[2], stream_ptr()), "nsol_grad_adj")
+    return out
+
+
+def diff_axis(x, shape, direction, adjoint, w):
+    _chk(x)
+    _, nz, ny, nx = dims3(shape)
+    out = empty_like(x)
+    _lib.check(_fn("diff_axis", x)(_p(x), _p(out), int(direction),
+                                   int(bool(adjoint)), nz, ny, nx, float(w),
+                                   stream_ptr()), "nsol_diff_axis")
+    return out
+
+
+def corr_axis(x, shape, axis3, taps, centre, mode, out=None):
+    """1-D correlation along axis3 (0=z,1=y,2=x of the padded 3-D shape)."""
+    _chk(x)
+    _, nz, ny, nx = dims3(shape)
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("corr_axis", x)(
+        _p(x), _p(out), int(axis3), nz, ny, nx, taps.ctypes.data,
+        int(taps.size), int(centre), MODES[mode], stream_ptr()),
+        "nsol_corr_axis")
+    return out
+
+
+def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
+    _chk(x)
+    _chk(taps_dev)
+    _, nz, ny, nx = dims3(shape)
+    out = empty_like(x)
+    _lib.check(_fn("corr_dense", x)(
+        _p(x), _p(out), nz, ny, nx, _p(taps_dev), kshape3[0], kshape3[1],
+        kshape3[2], centre3[0], centre3[1], centre3[2], MODES[mode],
+        stream_ptr()), "nsol_corr_dense")
+    return out
+
+
+# --------------------------------------------------------- element-wise ----
+def lincomb2(a, x, b, y, out=None):
+    _chk(x), _chk(y)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("lincomb2", x)(_p(out), float(a), _p(x), float(b), _p(y),
+                                  x.numel(), stream_ptr()), "nsol_lincomb2")
+    return out
+
+
+def lincomb3(a, x, b, y, c, z, out=None):
+    _chk(x), _chk(y), _chk(z)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("lincomb3", x)(_p(out), float(a), _p(x), float(b), _p(y),
+                                  float(c), _p(z), x.numel(), stream_ptr()),
+               "nsol_lincomb3")
+    return out
+
+
+def scale(x, a, divide=False, out=None):
+    _chk(x)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("scale", x)(_p(out), _p(x), float(a), int(bool(divide)),
+                               x.numel(), stream_ptr()), "nsol_scale")
+    return out
+
+
+def clip(x, lo, hi, out=None):
+    _chk(x)
+    if out is None:
+        out = empty_like(x)
+    lo = -1.7976931348623157e308 if lo == -np.inf else float(lo)
+    hi = 1.7976931348623157e308 if hi == np.inf else float(hi)
+    if x.dtype == torch.float32:
+        lo = max(lo, -3.4028234663852886e38)
+        hi = min(hi, 3.4028234663852886e38)
+    _lib.check(_fn("clip", x)(_p(out), _p(x), lo, hi, x.numel(),
+                              stream_ptr()), "nsol_clip")
+    return out
+
+
+def prox_dual_clamp(x, den=1.0, out=None):
+    _chk(x)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("prox_dual_clamp", x)(_p(out), _p(x), float(den),
+                                         x.numel(), stream_ptr()),
+               "nsol_prox_dual_clamp")
+    return out
+
+
+def prox_ell2(x, bt, tau, out=None):
+    _chk(x), _chk(bt)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("prox_ell2", x)(_p(out), _p(x), _p(bt), float(tau),
+                                   x.numel(), stream_ptr()), "nsol_prox_ell2")
+    return out
+
+
+def prox_ell1(x, bt, tau, out=None):
+    _chk(x), _chk(bt)
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("prox_ell1", x)(_p(out), _p(x), _p(bt), float(tau),
+                                   x.numel(), stream_ptr()), "nsol_prox_ell1")
+    return out
+
+
+# ------------------------------------------------------------ reductions ----
+_ws = {}
+
+
+def _workspace(dev):
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _ws:
+        n = _lib.load().nsol_hip_reduce_ws_doubles()
+        _ws[key] = (torch.empty(n, dtype=torch.float64, device=dev),
+                    torch.empty(1, dtype=torch.float64, device=dev))
+    return _ws[key]
+
+
+def dot(x, y):
+    """sum(x*y) accumulated in float64; returns a Python float (syncs)."""
+    _chk(x), _chk(y)
+    ws, res = _workspace(x.device)
+    _lib.check(_fn("dot", x)(_p(x), _p(y), x.numel(), _p(res), _p(ws),
+                             stream_ptr()), "nsol_dot")
+    return float(res.item())
+
+
+def norm2(x):
+    return float(np.sqrt(dot(x, x)))
+
+
+def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None):
+    """(0.5*sum rho(r^2), rho'(r^2)*r)."""
+    _chk(r)
+    ws, res = _workspace(r.device)
+    g = None
+    if want_grad:
+        g = empty_like(r) if out is None else out
+    _lib.check(_fn("loss_cost_grad", r)(_p(r), _p(g), r.numel(), LOSSES[loss],
+                                        float(f_scale), _p(res), _p(ws),
+                                        stream_ptr()), "nsol_loss_cost_grad")
+    return float(res.item()), g
+
+
+def loss_eval(f2, loss, f_scale=1.0, huber_gamma=1.345):
+    """Element-wise (rho(f2), rho'(f2))."""
+    _chk(f2)
+    rho, drho = empty_like(f2), empty_like(f2)
+    _lib.check(_fn("loss_eval", f2)(_p(f2), _p(rho), _p(drho), f2.numel(),
+                                    LOSSES[loss], float(f_scale),
+                                    float(huber_gamma), stream_ptr()),
+               "nsol_loss_eval")
+    return rho, drho
+
+
+def vector_norm_sum(t, ndim, mode=0, gamma=0.05):
+    _chk(t)
+    ws, res = _workspace(t.device)
+    _lib.check(_fn("vector_norm_sum", t)(
+        _p(t), int(ndim), t.numel() // int(ndim), int(mode), float(gamma),
+        _p(res), _p(ws), stream_ptr()), "nsol_vector_norm_sum")
+    return float(res.item())
+
+
+# ------------------------------------------------------------------- PD ----
+def pd_dual_step(xbar, p_in, p_out, shape, w, sigma, hden):
+    ndim, nz, ny, nx = dims3(shape)
+    _lib.check(_fn("pd_dual_step", xbar)(
+        _p(xbar), _p(p_in), _p(p_out), ndim, nz, ny, nx, w[0], w[1], w[2],
+        float(sigma), float(hden), stream_ptr()), "nsol_pd_dual_step")
+
+
+def pd_primal_step(p, x, xbar, bt, shape, w, tau, tl, theta, flags):
+    ndim, nz, ny, nx = dims3(shape)
+    _lib.check(_fn("pd_primal_step", x)(
+        _p(p), _p(x), _p(xbar), _p(bt), ndim, nz, ny, nx, w[0], w[1], w[2],
+        float(tau), float(tl), float(theta), int(flags), stream_ptr()),
+        "nsol_pd_primal_step")
+
+
+def pd_fused_iter(xbar_in, xbar_out, x, bt, p_in, p_out, shape, w, sigma,
+                  hden, tau, tl, theta, flags):
+    ndim, nz, ny, nx = dims3(shape)
+    _lib.check(_fn("pd_fused_iter", x)(
+        _p(xbar_in), _p(xbar_out), _p(x), _p(bt), _p(p_in), _p(p_out), ndim,
+        nz, ny, nx, w[0], w[1], w[2], float(sigma), float(hden), float(tau),
+        float(tl), float(theta), int(flags), stream_ptr()),
+        "nsol_pd_fused_iter")
+
+
+def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
+           p_is_zero, gamma_huber, flags):
+    ndim, nz, ny, nx = dims3(shape)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    _lib.check(_fn("pd_run", x)(
+        _p(xbar0), _p(xbar1), _p(x), _p(bt), _p(p0), _p(p1), ndim, nz, ny, nx,
+        w[0], w[1], w[2], float(lmbda), sigma.ctypes.data, tau.ctypes.data,
+        theta.ctypes.data, int(sigma.size), int(bool(p_is_zero)),
+        float(gamma_huber), int(flags), stream_ptr()), "nsol_pd_run")
+
+
+# ----------------------------------------------------------------- ADMM ----
+def admm_vw_update(x, v, w_, c, rhs, shape, w, thr, rhs_scale):
+    ndim, nz, ny, nx = dims3(shape)
+    _lib.check(_fn("admm_vw_update", x)(
+        _p(x), _p(v), _p(w_), _p(c), _p(rhs), ndim, nz, ny, nx, w[0], w[1],
+        w[2], float(thr), float(rhs_scale), stream_ptr()),
+        "nsol_admm_vw_update")
+
+
+def vector_shrink(t, ndim, thr, out=None):
+    _chk(t)
+    if out is None:
+        out = empty_like(t)
+    _lib.check(_fn("vector_shrink", t)(_p(t), _p(out), int(ndim),
+                                       t.numel() // int(ndim), float(thr),
+                                       stream_ptr()), "nsol_vector_shrink")
+    return out

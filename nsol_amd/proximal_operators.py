@@ -1,0 +1,116 @@
+"""Proximal operators (drop-in for nsol/proximal_operators.py).
+
+Static methods with the reference's names/arguments.  `x` may be a NumPy
+array (host round trip through the GPU), a torch HIP tensor (device path used
+by the solvers) or the solvers' symbolic probe.  All arithmetic is done by
+libnsol_hip.so.
+"""
+import numpy as np
+
+from . import ops
+from .device import is_device_tensor, to_device, to_numpy
+from .symbolic import Sym, TraceAbort, TauSym
+
+
+# small cache of b/x_scale on the device, keyed by the identity of the host
+# array the caller's lambda closes over (run_denoising.py:109-131 pass x0=b on
+# every call).  Mutating that array in place between calls is not supported.
+_bt_cache = []
+
+
+def scaled_data_on_device(x0, x_scale, like):
+    """b~ = x0 / x_scale as a device tensor with the dtype of `like`."""
+    if is_device_tensor(x0):
+        src = x0.to(like.dtype).contiguous().view(-1)
+        return ops.scale(src, float(x_scale), divide=True)
+    arr = np.asarray(x0)
+    key = (id(x0), arr.__array_interface__["data"][0], arr.size,
+           float(x_scale), like.dtype, like.device.index)
+    for k, ref, val in _bt_cache:
+        if k == key and ref is x0:
+            return val
+    dev = to_device(arr.reshape(-1), np.float64)
+    bt = ops.scale(dev, float(x_scale), divide=True)   # divide in float64
+    bt = bt.to(like.dtype)                             # then round once
+    _bt_cache.append((key, x0, bt))
+    del _bt_cache[:-4]
+    return bt
+
+
+def _elementwise(x, fn, desc):
+    if isinstance(x, Sym):
+        if x.desc is not None:
+            raise TraceAbort("prox applied to a transformed probe")
+        return Sym(x.shape, desc)
+    if is_device_tensor(x):
+        shape = tuple(x.shape)
+        return fn(x.contiguous().view(-1)).view(shape)
+    arr = np.asarray(x)
+    dt = arr.dtype.type if arr.dtype in (np.float32, np.float64) \
+        else np.float64
+    return to_numpy(fn(to_device(arr, dt).view(-1)), dt).reshape(arr.shape)
+
+
+class ProximalOperators(object):
+
+    @staticmethod
+    def prox_linear_least_squares(x, tau, A, A_adj, b, x0, iter_max=10,
+                                  verbose=0, data_loss="linear",
+                                  data_loss_scale=1, minimizer="lsmr",
+                                  x_scale=1, bounds=(0, np.inf)):
+        """Tikhonov solve with B = I, b_reg = x, alpha = 1/tau
+        (proximal_operators.py:43-78)."""
+        from . import tikhonov_linear_solver as tk
+        if isinstance(x, Sym):
+            raise TraceAbort("prox_linear_least_squares is not fused")
+        identity = lambda v: v.flatten()
+        if is_device_tensor(b):
+            b_s = ops.scale(b.contiguous().view(-1), float(x_scale), True)
+        else:
+            b_s = np.asarray(b) / float(x_scale)
+        if is_device_tensor(x0):
+            x0_s = ops.scale(x0.contiguous().view(-1), float(x_scale), True)
+        else:
+            x0_s = np.asarray(x0) / float(x_scale)
+        tikhonov = tk.TikhonovLinearSolver(
+            A=A, A_adj=A_adj, B=identity, B_adj=identity, x0=x0_s, b=b_s,
+            b_reg=x, alpha=1. / tau, iter_max=iter_max, verbose=verbose,
+            x_scale=x_scale, data_loss=data_loss,
+            data_loss_scale=data_loss_scale, minimizer=minimizer,
+            bounds=bounds,
+            dtype=(np.float32 if is_device_tensor(x) and "32" in str(x.dtype)
+                   else (np.float64 if is_device_tensor(x) else None)))
+        tikhonov.run()
+        if is_device_tensor(x):
+            return tikhonov.get_x_device()
+        return tikhonov.get_x()
+
+    @staticmethod
+    def prox_ell1_denoising(x, tau, x0, x_scale=1.):
+        # proximal_operators.py:95-98
+        return _elementwise(
+            x, lambda d: ops.prox_ell1(
+                d, scaled_data_on_device(x0, x_scale, d), tau),
+            ("prox_ell1", x0, float(x_scale), tau))
+
+    @staticmethod
+    def prox_ell2_denoising(x, tau, x0, x_scale=1.):
+        # proximal_operators.py:117-120
+        return _elementwise(
+            x, lambda d: ops.prox_ell2(
+                d, scaled_data_on_device(x0, x_scale, d), tau),
+            ("prox_ell2", x0, float(x_scale), tau))
+
+    @staticmethod
+    def prox_tv_conj(x, sigma):
+        # proximal_operators.py:138-140
+        return _elementwise(x, lambda d: ops.prox_dual_clamp(d, 1.0),
+                            ("prox_tv_conj", sigma))
+
+    @staticmethod
+    def prox_huber_conj(x, sigma, gamma=0.05):
+        # proximal_operators.py:156-159; the reference divides its argument
+        # in place, here the argument is left untouched
+        return _elementwise(
+            x, lambda d: ops.prox_dual_clamp(d, 1. + sigma * gamma),
+            ("prox_huber_conj", sigma, float(gamma)))

@@ -1,0 +1,111 @@
+"""Solver base class (drop-in for nsol/solver.py:21-174).
+
+State lives in HBM as torch HIP tensors of the working dtype (float32 by
+default, float64 for validation; the reference is float64 throughout,
+solver.py:37).  `x0` may be a NumPy array (as in the reference) or a 1-D torch
+HIP tensor that is already resident.
+"""
+import datetime
+import time
+
+import numpy as np
+
+from . import ops
+from .device import (get_default_dtype, is_device_tensor, to_device, to_numpy,
+                     torch_dtype)
+
+
+class Solver(object):
+
+    def __init__(self, x0, x_scale, verbose, dtype=None):
+        self._dtype = np.dtype(dtype or get_default_dtype()).type
+        if self._dtype not in (np.float32, np.float64):
+            raise ValueError("dtype must be float32 or float64")
+        self._x_scale = float(x_scale)
+        self._verbose = verbose
+        self._computational_time = datetime.timedelta(seconds=0)
+        self._observer = None
+        self._set_x0(x0)
+
+    # x0 is kept as given (host float64 or device) and uploaded lazily so that
+    # solvers can be constructed and inspected on a machine without a GPU.
+    def _set_x0(self, x0):
+        if is_device_tensor(x0):
+            self._x0_ndim = x0.dim()
+            self._x0_host = None
+            self._x0_dev = ops.scale(
+                x0.to(torch_dtype(self._dtype)).contiguous().view(-1),
+                self._x_scale, divide=True)
+        else:
+            arr = np.array(x0, dtype=np.float64)
+            self._x0_ndim = arr.ndim
+            self._x0_host = arr / self._x_scale      # solver.py:37
+            self._x0_dev = None
+        self._x = None
+
+    def _x0_device(self):
+        if self._x0_dev is None:
+            self._x0_dev = to_device(self._x0_host.reshape(-1), self._dtype)
+        return self._x0_dev
+
+    def get_dtype(self):
+        return self._dtype
+
+    def set_x_scale(self, x_scale):
+        self._x_scale = x_scale
+
+    def get_x_scale(self):
+        return self._x_scale
+
+    def set_verbose(self, verbose):
+        self._verbose = verbose
+
+    def get_verbose(self):
+        return self._verbose
+
+    def set_x0(self, x0):
+        self._set_x0(x0)
+
+    def get_x0(self):
+        if self._x0_host is not None:
+            return np.array(self._x0_host) * self._x_scale
+        return to_numpy(ops.scale(self._x0_dev, self._x_scale))
+
+    def get_x_device(self):
+        """Current iterate times x_scale as a NEW flat device tensor."""
+        cur = self._x if self._x is not None else self._x0_device()
+        return ops.scale(cur, self._x_scale)
+
+    def get_x(self):
+        # solver.py:117-118: copy, multiplied by x_scale, float64 on the host
+        if self._x is None and self._x0_host is not None:
+            return np.array(self._x0_host) * self._x_scale
+        return to_numpy(self.get_x_device())
+
+    def get_computational_time(self):
+        return self._computational_time
+
+    def set_observer(self, observer):
+        self._observer = observer
+
+    def run(self):
+        if self._x0_ndim != 1:
+            raise ValueError("Initial value x0 must be a 1D array")
+        import torch
+        t0 = time.time()
+        self._run()
+        torch.cuda.synchronize()
+        self._computational_time = datetime.timedelta(
+            seconds=time.time() - t0)
+        if self._verbose:
+            print("Required computational time: %s" %
+                  (self.get_computational_time()))
+        if self._observer is not None:
+            self._observer.set_computational_time(
+                self.get_computational_time())
+
+    def _run(self):
+        raise NotImplementedError
+
+    def print_statistics(self):
+        raise NotImplementedError

@@ -1,0 +1,205 @@
+"""Tikhonov-regularised linear least squares on MI355X (drop-in for
+nsol/tikhonov_linear_solver.py:30-280):
+
+    min_x 1/2 sum rho((A x - b)^2) + alpha/2 ||B x - b_reg||^2
+
+* minimizer "lsmr" (linear loss): GPU-resident LSMR on the augmented system
+  [A; sqrt(alpha) B] x = [b; sqrt(alpha) b_reg] (tikhonov :146-158, :226-274),
+  started from 0, result clipped to `bounds`.
+* any other minimizer string goes to scipy.optimize.minimize exactly as the
+  reference does (:197-220) -- including its quirk of ignoring b_reg there --
+  with cost and gradient evaluated by HIP kernels; only the optimiser's own
+  vector bookkeeping runs in SciPy on the host.
+* "lsq_linear" / "least_squares" use SciPy's drivers over a LinearOperator whose
+  matvec / rmatvec run on the GPU (:160-195).
+"""
+import numpy as np
+import scipy.optimize
+import scipy.sparse.linalg
+
+from . import ops
+from .bridge import BridgedCallable
+from .definitions import EPS
+from .device import is_device_tensor, to_device, to_numpy
+from .linear_solver import LinearSolver
+from .lsmr import lsmr
+
+
+class TikhonovLinearSolver(LinearSolver):
+
+    def __init__(self, A, A_adj, b, B, B_adj, x0, alpha=0.01, b_reg=0,
+                 data_loss="linear", data_loss_scale=1, minimizer="lsmr",
+                 iter_max=10, x_scale=1, verbose=0, bounds=(0, np.inf),
+                 dtype=None):
+        LinearSolver.__init__(
+            self, A=A, A_adj=A_adj, b=b, x0=x0, alpha=alpha, iter_max=iter_max,
+            minimizer=minimizer, data_loss=data_loss,
+            data_loss_scale=data_loss_scale, x_scale=x_scale, verbose=verbose,
+            dtype=dtype)
+        self._B = B
+        self._B_adj = B_adj
+        self._b_reg = self._scaled(b_reg)          # tikhonov :91
+        self._bounds = bounds
+
+    def get_B(self):
+        return self._B
+
+    def get_B_adj(self):
+        return self._B_adj
+
+    def get_b_reg(self):
+        if is_device_tensor(self._b_reg):
+            return to_numpy(ops.scale(self._b_reg, self._x_scale))
+        return self._b_reg * self._x_scale
+
+    # ------------------------------------------------------------------
+    def _callables(self):
+        dt = self._dtype
+        return (BridgedCallable(self._A, dt), BridgedCallable(self._A_adj, dt),
+                BridgedCallable(self._B, dt), BridgedCallable(self._B_adj, dt))
+
+    def _run(self):
+        if self._minimizer == "lsmr" and self._data_loss != "linear":
+            raise ValueError(
+                "lsmr solver cannot be used with non-linear data loss")
+        elif self._minimizer == "lsq_linear" and self._data_loss != "linear":
+            raise ValueError(
+                "lsq_linear solver cannot be used with non-linear data loss")
+
+        if self._observer is not None:
+            self._observer.add_x(self.get_x())
+
+        x0 = self._x0_device()
+        if self._bounds is not None:                       # tikhonov :142-143
+            x0 = ops.clip(x0, self._bounds[0], self._bounds[1])
+            self._x0_dev = x0
+            if self._x0_host is not None:
+                self._x0_host = np.clip(self._x0_host, self._bounds[0],
+                                        self._bounds[1])
+
+        if self._minimizer == "lsmr" and self._data_loss == "linear":
+            x = self._run_lsmr(x0)
+            if self._bounds is not None:
+                x = ops.clip(x, self._bounds[0], self._bounds[1], out=x)
+            self._x = x
+        elif self._minimizer in ("lsq_linear", "least_squares"):
+            self._x = self._run_scipy_least_squares(x0)
+        else:
+            self._x = self._run_minimize(x0)
+
+        if self._observer is not None:
+            self._observer.add_x(self.get_x())
+
+    # ------------------------------------------------------------------
+    def _augmented(self, x0):
+        """Block form of tikhonov :226-274: (matvec, rmatvec, rhs blocks)."""
+        A, A_adj, B, B_adj = self._callables()
+        b = self._dev(self._b)
+        if self._alpha > EPS:
+            sa = float(np.sqrt(self._alpha))
+            if is_device_tensor(self._b_reg) or np.ndim(self._b_reg) > 0:
+                lower = ops.scale(self._dev(self._b_reg), sa)
+            else:
+                # scalar b_reg (default 0): broadcast over the rows of B
+                nrows = B(x0).numel()
+                import torch
+                lower = torch.full((nrows,), sa * float(self._b_reg),
+                                   dtype=x0.dtype, device=x0.device)
+
+            def matvec(v):
+                return [A(v), ops.scale(B(v), sa)]
+
+            def rmatvec(u):
+                return ops.lincomb2(1.0, A_adj(u[0]), sa, B_adj(u[1]))
+            return matvec, rmatvec, [b.clone(), lower]
+
+        def matvec(v):
+            return [A(v)]
+
+        def rmatvec(u):
+            return A_adj(u[0])
+        return matvec, rmatvec, [b.clone()]
+
+    def _run_lsmr(self, x0):
+        matvec, rmatvec, rhs = self._augmented(x0)
+        x, _, _ = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
+        return x
+
+    # ------------------------------------------------------------------
+    def _host_linear_operator(self, x0):
+        matvec, rmatvec, rhs = self._augmented(x0)
+        sizes = [r.numel() for r in rhs]
+        dt = self._dtype
+
+        def mv(v):
+            parts = matvec(to_device(np.asarray(v, dtype=np.float64)
+                                     .reshape(-1), dt))
+            return np.concatenate([to_numpy(p) for p in parts])
+
+        def rmv(u):
+            u = np.asarray(u, dtype=np.float64).reshape(-1)
+            parts, o = [], 0
+            for s in sizes:
+                parts.append(to_device(u[o:o + s], dt))
+                o += s
+            return to_numpy(rmatvec(parts))
+        op = scipy.sparse.linalg.LinearOperator(
+            shape=(sum(sizes), x0.numel()), matvec=mv, rmatvec=rmv,
+            dtype=np.float64)
+        return op, np.concatenate([to_numpy(r) for r in rhs])
+
+    def _run_scipy_least_squares(self, x0):
+        op, rhs = self._host_linear_operator(x0)
+        if self._minimizer == "lsq_linear":
+            x = scipy.optimize.lsq_linear(
+                op, rhs, max_iter=self._iter_max, lsq_solver='lsmr',
+                lsmr_tol='auto', bounds=self._bounds,
+                verbose=2 * self._verbose).x
+        else:
+            x = scipy.optimize.least_squares(
+                fun=lambda x: op * x - rhs, jac=lambda x: op,
+                jac_sparsity=lambda x: op, x0=to_numpy(x0), tr_solver='lsmr',
+                bounds=self._bounds, loss=self._data_loss,
+                f_scale=self._data_loss_scale, max_nfev=self._iter_max,
+                verbose=2 * self._verbose).x
+        return to_device(x, self._dtype)
+
+    # ------------------------------------------------------------------
+    def _run_minimize(self, x0):
+        A, A_adj, B, B_adj = self._callables()
+        b = self._dev(self._b)
+        dt = self._dtype
+        use_reg = self._alpha > EPS
+        alpha = self._alpha
+        loss, fscale = self._data_loss, self._data_loss_scale
+
+        def fun_and_jac(xh):
+            x = to_device(np.asarray(xh, dtype=np.float64).reshape(-1), dt)
+            r = ops.lincomb2(1.0, A(x), -1.0, b)
+            cost, g = ops.loss_cost_grad(r, loss, fscale, out=r)
+            grad = A_adj(g)
+            if use_reg:
+                Bx = B(x)
+                # reference quirk kept: 1/2||Bx||^2, b_reg is ignored here
+                cost = cost + alpha * (0.5 * ops.dot(Bx, Bx))
+                grad = ops.lincomb2(1.0, grad, alpha, B_adj(Bx))
+            return cost, to_numpy(grad)
+
+        n = x0.numel()
+        lo, hi = self._bounds
+        bounds = scipy.optimize.Bounds(np.full(n, lo, dtype=np.float64),
+                                       np.full(n, hi, dtype=np.float64))
+        res = scipy.optimize.minimize(
+            method=self._minimizer, fun=fun_and_jac, jac=True,
+            x0=to_numpy(x0), bounds=bounds,
+            options={'maxiter': self._iter_max, 'disp': self._verbose})
+        return to_device(res.x, dt)
+
+    def _get_cost_regularization_term(self, x):
+        Bx = BridgedCallable(self._B, self._dtype)(self._dev(x))
+        return 0.5 * ops.dot(Bx, Bx)
+
+    def _get_gradient_cost_regularization_term(self, x):
+        B = BridgedCallable(self._B, self._dtype)
+        Ba = BridgedCallable(self._B_adj, self._dtype)
+        return Ba(B(self._dev(x)))

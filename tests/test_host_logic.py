@@ -1,0 +1,229 @@
+"""CPU-only tests: C-ABI library loads and exports every declared symbol, the
+host-side step schedule, operator recognition through caller lambdas, tap
+definitions, error behaviour, synthetic inputs and the sharded batch runner
+(gloo, world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_builds_loads_and_exports_declared_symbols():
+    from nsol_amd.build import build_library
+    from nsol_amd import _lib
+    path = build_library()
+    assert os.path.exists(path)
+    decl = _lib.declared_symbols()
+    assert len(decl) >= 40
+    for base in ("grad", "grad_adj", "diff_axis", "corr_axis", "corr_dense",
+                 "lincomb2", "lincomb3", "scale", "clip", "prox_dual_clamp",
+                 "prox_ell1", "prox_ell2", "dot", "pd_dual_step",
+                 "pd_primal_step", "pd_fused_iter", "pd_run",
+                 "admm_vw_update", "vector_shrink", "loss_cost_grad",
+                 "loss_eval", "vector_norm_sum"):
+        for suf in ("f32", "f64"):
+            assert "nsol_%s_%s" % (base, suf) in decl
+    lib = _lib.load()            # binds every symbol or raises
+    assert lib.nsol_hip_abi_version() == 1
+    assert lib.nsol_hip_reduce_ws_doubles() == 1024
+
+
+def test_product_does_not_import_the_oracle():
+    import re
+    pkg = os.path.join(ROOT, "nsol_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt,
+                                     re.M), f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from nsol_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnsol_hip.so")
+    with pytest.raises(_lib.NsolHipError):
+        _lib.load()
+
+
+@pytest.mark.parametrize("alg", ["ALG2", "ALG2_AHMOD", "ALG3"])
+def test_step_schedule_matches_oracle(alg):
+    from nsol_amd.primal_dual_solver import step_schedule
+    from oracle import nsol_oracle as orc
+    a = step_schedule(alg, 16.0, 1 / 0.03, 40)
+    b = orc.pd_schedule(alg, 16.0, 1 / 0.03, 40)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    with pytest.raises(KeyError):
+        step_schedule("ALG9", 16.0, 1.0, 3)
+
+
+def test_taps_match_reference_goldens(golden):
+    import nsol_amd.kernels as K
+    g = golden("ops")
+    assert np.array_equal(K.Kernels1D().get_gaussian(2.0), g["taps_1d"])
+    assert np.array_equal(K.Kernels2D().get_gaussian(g["cov_2d_full"]),
+                          g["taps_2d_full"])
+    assert np.array_equal(K.Kernels3D().get_gaussian(g["cov_3d_aniso"]),
+                          g["taps_3d_aniso"])
+    k3 = K.Kernels3D(spacing=np.array([2., 4., 8.]))
+    # tests/kernels_test.py:59-136: nonzero taps equal 1/spacing[axis]
+    assert k3.get_dx_forward_difference().shape == (1, 1, 2)
+    assert np.allclose(np.abs(k3.get_dx_forward_difference()), 0.5)
+    assert k3.get_dy_backward_difference().shape == (1, 3, 1)
+    assert np.allclose(k3.get_dy_backward_difference().ravel(),
+                       [0, 0.25, -0.25])
+    assert np.allclose(k3.get_dz_forward_difference().ravel(),
+                       [0.125, -0.125])
+    with pytest.raises(ValueError):
+        K.Kernels3D(spacing=np.ones(2))
+    with pytest.raises(ValueError):
+        K.Kernels2D().get_gaussian(np.ones((3, 3)))
+
+
+def _wired_solver(obs, data="L2", reg="TV"):
+    import nsol_amd.linear_operators as LO
+    import nsol_amd.primal_dual_solver as pd
+    from nsol_amd.proximal_operators import ProximalOperators as prox
+    from nsol_amd.symbolic import Sym
+    lo = {1: LO.LinearOperators1D, 2: LO.LinearOperators2D,
+          3: LO.LinearOperators3D}[obs.ndim](spacing=np.ones(obs.ndim) * 2.0)
+    grad, grad_adj = lo.get_gradient_operators()
+    X = obs.shape
+    Z = grad(Sym(X)).shape
+    b = obs.flatten()
+    D = lambda x: grad(x.reshape(*X)).flatten()
+    Da = lambda x: grad_adj(x.reshape(*Z)).flatten()
+    if data == "L2":
+        pf = lambda x, tau: prox.prox_ell2_denoising(x, tau, x0=b, x_scale=3.)
+    else:
+        pf = lambda x, tau: prox.prox_ell1_denoising(x, tau, x0=b, x_scale=3.)
+    pg = prox.prox_huber_conj if reg == "Huber" else prox.prox_tv_conj
+    return pd.PrimalDualSolver(prox_f=pf, prox_g_conj=pg, B=D, B_conj=Da,
+                               L2=16, x0=b, x_scale=3.), b
+
+
+def test_plan_recognises_native_wiring_through_lambdas():
+    from nsol_amd import ops
+    obs = np.arange(4 * 5 * 6, dtype=float).reshape(4, 5, 6)
+    s, b = _wired_solver(obs, "L1", "Huber")
+    plan = s.plan()
+    assert plan is not None
+    assert plan["shape"] == (4, 5, 6) and plan["dim"] == 3
+    assert plan["w"] == (0.5, 0.5, 0.5)
+    assert plan["flags"] == ops.PD_REG_HUBER | ops.PD_DATA_L1
+    assert plan["data"] is b and plan["data_scale"] == 3.0
+    s2, _ = _wired_solver(np.ones((7, 9)), "L2", "TV")
+    assert s2.plan()["flags"] == 0 and s2.plan()["dim"] == 2
+
+
+def test_plan_rejects_foreign_or_modified_callables():
+    obs = np.ones((4, 5, 6))
+    s, b = _wired_solver(obs)
+    s._prox_f = lambda x, tau: np.asarray(x) * 2          # NumPy arithmetic
+    assert s.plan() is None
+    s, b = _wired_solver(obs)
+    from nsol_amd.proximal_operators import ProximalOperators as prox
+    s._prox_f = lambda x, tau: prox.prox_ell2_denoising(x, 2 * tau, x0=b)
+    assert s.plan() is None                               # tau was modified
+    s, b = _wired_solver(obs)
+    B = s._B
+    s._B = lambda x: B(B(x))                              # composition
+    assert s.plan() is None
+    s, b = _wired_solver(obs)
+    s._B_conj = s._B                                      # not the adjoint
+    assert s.plan() is None
+
+
+def test_solver_api_surface_without_gpu():
+    obs = np.ones((3, 4, 8)) * 6.0
+    s, b = _wired_solver(obs)
+    assert s.get_alpha() == 0.01 and s.get_L2() == 16.0
+    assert s.get_alg_type() == "ALG2" and s.get_iterations() == 10
+    s.set_alpha(0.5), s.set_iterations(3), s.set_alg_type("ALG3")
+    s.set_L2(12.)
+    assert (s.get_alpha(), s.get_iterations(), s.get_alg_type(),
+            s.get_L2()) == (0.5, 3, "ALG3", 12.)
+    assert np.array_equal(s.get_x0(), b)          # x0 / x_scale * x_scale
+    assert np.array_equal(s.get_x(), b)
+    assert s.get_x_scale() == 3.0
+    assert s.get_computational_time().total_seconds() == 0
+
+
+def test_separable_detection_and_ndimage_centre():
+    import nsol_amd.linear_operators as LO
+    lo = LO.LinearOperators3D()
+    A, A_adj = lo.get_gaussian_blurring_operators(np.diag([4., 4., 4.]))
+    assert A is A_adj and A.separable
+    assert [p[1].size for p in A._passes] == [13, 13, 13]
+    assert [p[0] for p in A._passes] == [0, 1, 2]
+    A2, _ = LO.LinearOperators2D().get_gaussian_blurring_operators(
+        np.array([[2., .6], [.6, 1.]]))
+    assert not A2.separable
+    flipped, centre = LO._ndimage_convolve_params(np.arange(8.).reshape(2, 4))
+    assert centre == [0, 1] and flipped[0, 0] == 7.0
+    with pytest.raises(RuntimeError):
+        LO.ConvolutionOperator(3, np.ones((3, 3)))
+
+
+def test_synthetic_volume_matches_oracle_copy():
+    from nsol_amd.synthetic import synth_volume
+    from oracle import nsol_oracle as orc
+    for kind in ("clean", "gauss", "sp"):
+        assert np.array_equal(synth_volume(16, 2, kind),
+                              orc.synth_volume(16, 2, kind))
+
+
+def test_shard_indices():
+    from nsol_amd.batch import shard_indices
+    assert shard_indices(8, 1, 4) == [1, 5]
+    assert shard_indices(8, 0, 1) == list(range(8))
+    assert sorted(sum((shard_indices(7, r, 3) for r in range(3)), [])) == \
+        list(range(7))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from nsol_amd.batch import solve_batch
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]),
+                        world_size=int(os.environ["WORLD_SIZE"]))
+calls = []
+def solve_one(i):
+    calls.append(i)
+    return torch.full((5,), float(i) * 10.0) + torch.arange(5.)
+out = solve_batch(solve_one, 5)
+rank = dist.get_rank()
+assert calls == list(range(rank, 5, 2)), calls
+if rank == 0:
+    assert len(out) == 5
+    for i, t in enumerate(out):
+        assert torch.equal(t, torch.full((5,), float(i) * 10.0)
+                           + torch.arange(5.)), (i, t)
+    print("BATCH_OK")
+else:
+    assert out is None
+dist.destroy_process_group()
+'''
+
+
+def test_solve_batch_gloo_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "BATCH_OK" in outs[0]
