@@ -54,6 +54,20 @@ class HipEvents(object):
         return float(ms.value)
 
 
+def measured_traffic(n):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3
+    PMC passes (profiles/latest_pmc.json, written by tools/summarize_profiles.py);
+    None when no profile of this problem size is on record."""
+    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    try:
+        rec = json.load(open(path))
+        if int(rec.get("size", 0)) == n:
+            return float(rec["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sample_n, iters):
     """Reference-style NumPy/SciPy iteration (oracle port) on the host."""
     from oracle import nsol_oracle as orc
@@ -187,7 +201,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic(n),
                 "bytes_per_launch": BYTES_PER_VOXEL * nvox,
                 "avg_launch_ms": kernel_ms},
         }

@@ -28,6 +28,7 @@ struct PdTuning {
   int zchunk = 0;   // 0 = auto
   int ry = 2;       // rows per lane (1, 2 or 4)
   int force_two_pass = 0;
+  int xcd_map = 1;  // 0 = plain block order, 1 = XCD-aware slabs
 };
 PdTuning g_tune;
 
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out, T *x,
     const T *__restrict__ bt, const T *__restrict__ p_in,
     T *__restrict__ p_out, Geom<T> G, PdScalars<T> S, int ntx, int nty,
-    int zchunk) {
+    int zchunk, int slab) {
   constexpr int LY = kWave / LX;
   constexpr int WAVES = kBlock / kWave;
   constexpr int TY = WAVES * LY * RY;
@@ -163,11 +164,27 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
   const int wave = threadIdx.x / kWave;
   const int lx = lane % LX;
   const int ly = lane / LX;
-  int bid = blockIdx.x;
-  const int tx = bid % ntx;
-  bid /= ntx;
-  const int ty = bid % nty;
-  const int zc = bid / nty;
+  // Block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs
+  // (blockIdx % 8 names the group that shares an L2), so with slab > 0 each
+  // XCD walks its own slab of `slab` consecutive y-tiles: the halo rows and
+  // columns that neighbouring tiles re-read are then served by that XCD's L2.
+  // Placement only affects speed, never results.
+  int tx, ty, zc;
+  if (slab > 0) {
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    tx = j % ntx;
+    j /= ntx;
+    ty = xcd * slab + j % slab;
+    zc = j / slab;
+    if (ty >= nty) return;
+  } else {
+    int bid = blockIdx.x;
+    tx = bid % ntx;
+    bid /= ntx;
+    ty = bid % nty;
+    zc = bid / nty;
+  }
 
   const int64_t x0 = ((int64_t)tx * LX + lx) * VEC;
   const int64_t y0 = (int64_t)ty * TY + (int64_t)(wave * LY + ly) * RY;
@@ -382,11 +399,16 @@ int launch_fused_t(const T *xbar_in, T *xbar_out, T *x, const T *bt,
   }
   if (zchunk > G.nz) zchunk = G.nz;
   const int64_t nzc = (G.nz + zchunk - 1) / zchunk;
-  const int64_t blocks = ntx * nty * nzc;
+  int64_t slab = 0;
+  int64_t blocks = ntx * nty * nzc;
+  if (g_tune.xcd_map && nty >= 16) {
+    slab = (nty + 7) / 8;
+    blocks = 8 * slab * ntx * nzc;
+  }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
   hipLaunchKernelGGL((k_pd_fused<T, VEC, LX, RY, NDIM>), dim3((unsigned)blocks),
                      dim3(kBlock), 0, st, xbar_in, xbar_out, x, bt, p_in, p_out,
-                     G, S, (int)ntx, (int)nty, (int)zchunk);
+                     G, S, (int)ntx, (int)nty, (int)zchunk, (int)slab);
   return launch_status();
 }
 
@@ -528,6 +550,7 @@ int nsol_hip_set_param(const char *name, int value) {
   if (!strcmp(name, "pd_zchunk")) g_tune.zchunk = value;
   else if (!strcmp(name, "pd_ry")) g_tune.ry = value;
   else if (!strcmp(name, "pd_two_pass")) g_tune.force_two_pass = value;
+  else if (!strcmp(name, "pd_xcd_map")) g_tune.xcd_map = value;
   else return NSOL_EINVAL;
   return 0;
 }

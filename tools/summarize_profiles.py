@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/<dir>/**) into small tracked files
+under profiles/: the --stats kernel summary and the per-kernel PMC means
+(FETCH_SIZE / WRITE_SIZE, KiB per dispatch).  Also refreshes
+profiles/latest_pmc.json which bench.py quotes as `roofline.traffic`.
+
+gfx950 correction (MI355X_MICROARCH.md, section HBM): FETCH_SIZE reports 1/2 of
+the bytes of a wide coalesced streaming read, WRITE_SIZE is exact; so
+traffic = 2*FETCH_SIZE + WRITE_SIZE.  The doubling was re-calibrated here on the
+512 MiB nsol_scale_f32 copy in the same trace (FETCH 256 MiB, WRITE 512 MiB).
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def pmc_means(d):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"),
+                  recursive=True)
+    acc = collections.defaultdict(list)
+    for path in f:
+        for r in csv.DictReader(open(path)):
+            acc[(r["Kernel_Name"], r["Counter_Name"])].append(
+                float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True, help="e.g. r01")
+    ap.add_argument("--stats", help="rocprofv3 --stats output dir")
+    ap.add_argument("--fetch", help="--pmc FETCH_SIZE output dir")
+    ap.add_argument("--write", help="--pmc WRITE_SIZE output dir")
+    ap.add_argument("--kernel", default="k_pd_fused")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--skip-first", type=int, default=1,
+                    help="dispatches of --kernel to drop (p = 0 first launch)")
+    args = ap.parse_args()
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    if args.stats:
+        for f in glob.glob(os.path.join(args.stats, "**", "*_kernel_stats.csv"),
+                           recursive=True):
+            shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % args.tag))
+    summary = {"kernel": args.kernel, "size": args.size, "tag": args.tag}
+    rows = []
+    for name, d in (("FETCH_SIZE", args.fetch), ("WRITE_SIZE", args.write)):
+        if not d:
+            continue
+        for (kern, ctr), vals in sorted(pmc_means(d).items()):
+            use = vals
+            if args.kernel in kern and len(vals) > args.skip_first:
+                use = vals[args.skip_first:]
+            mean = sum(use) / len(use)
+            rows.append((kern[:100], ctr, len(use), mean))
+            if args.kernel in kern and ctr == name:
+                summary[name.lower() + "_kib"] = mean
+    with open(os.path.join(out, "%s_pmc_summary.csv" % args.tag), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "mean_KiB_per_dispatch"])
+        w.writerows(rows)
+    if "fetch_size_kib" in summary and "write_size_kib" in summary:
+        summary["traffic_bytes_per_launch"] = 1024.0 * (
+            2.0 * summary["fetch_size_kib"] + summary["write_size_kib"])
+        summary["note"] = ("traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950: "
+                           "FETCH_SIZE counts half of a wide coalesced read)")
+        with open(os.path.join(out, "latest_pmc.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
