@@ -284,6 +284,48 @@ int nsol_vector_norm_sum_f64(const double *t, int ndim, int64_t m, int mode,
                              double gamma, double *result, double *ws,
                              void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * Fused LSMR vector kernels for [A; sqrt(alpha) B] (tikhonov_linear_solver.py
+ * :226-274 driving scipy lsmr.py:320-413).  bmode: 0 = no regulariser block,
+ * 1 = B is the gradient (ndim, extents, inverse spacings as above), 2 = B is the
+ * identity.  Each call leaves the squared 2-norm of what it wrote in result[0].
+ * ---------------------------------------------------------------------- */
+#define NSOL_B_NONE 0
+#define NSOL_B_GRAD 1
+#define NSOL_B_IDENTITY 2
+/* u_top = c_av*Av + c_u*u_top;  u_bot = c_bv*B(v) + c_u*u_bot */
+int nsol_lsmr_u_update_f32(const float *Av, const float *v, float *u_top,
+                           float *u_bot, int bmode, int ndim, int64_t nz,
+                           int64_t ny, int64_t nx, double wx, double wy,
+                           double wz, double c_av, double c_bv, double c_u,
+                           double *result, double *ws, void *stream);
+int nsol_lsmr_u_update_f64(const double *Av, const double *v, double *u_top,
+                           double *u_bot, int bmode, int ndim, int64_t nz,
+                           int64_t ny, int64_t nx, double wx, double wy,
+                           double wz, double c_av, double c_bv, double c_u,
+                           double *result, double *ws, void *stream);
+/* v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v */
+int nsol_lsmr_v_update_f32(const float *Atu, const float *u_bot, float *v,
+                           int bmode, int ndim, int64_t nz, int64_t ny,
+                           int64_t nx, double wx, double wy, double wz,
+                           double c_atu, double c_btu, double c_v,
+                           double *result, double *ws, void *stream);
+int nsol_lsmr_v_update_f64(const double *Atu, const double *u_bot, double *v,
+                           int bmode, int ndim, int64_t nz, int64_t ny,
+                           int64_t nx, double wx, double wy, double wz,
+                           double c_atu, double c_btu, double c_v,
+                           double *result, double *ws, void *stream);
+/* hbar = h + c_hbar*hbar;  x = x + c_x*hbar;  h = c_v*v + c_h*h;
+ * result[0] = sum x^2   (scipy lsmr.py:367-371, 407) */
+int nsol_lsmr_hx_update_f32(float *hbar, float *x, float *h, const float *v,
+                            int64_t n, double c_hbar, double c_x, double c_h,
+                            double c_v, double *result, double *ws,
+                            void *stream);
+int nsol_lsmr_hx_update_f64(double *hbar, double *x, double *h,
+                            const double *v, int64_t n, double c_hbar,
+                            double c_x, double c_h, double c_v, double *result,
+                            double *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,7 @@ def declared_symbols(header=HEADER):
                 else:
                     argtypes.append(_CTYPE[a.split()[-2]])
         out[name] = (c_int, argtypes)
+    out.pop("nsol_hip_set_param", None)
     return out
 
 

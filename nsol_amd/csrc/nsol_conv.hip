@@ -109,6 +109,143 @@ __global__ __launch_bounds__(kBlock) void k_corr_dense(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Specialised periodic ("wrap") passes for odd tap counts with the centre in
+// the middle -- every Gaussian of linear_operators.py:82-86.  16-byte
+// accesses, taps unrolled at compile time, no integer division on the hot
+// path; accumulation order t = 0..NT-1 as in ndimage.
+//   * strided pass (array axis 0 or 1): a lane owns VEC consecutive x and RA
+//     consecutive positions along the axis -> NT+RA-1 vector loads for RA
+//     vector outputs (sliding window in registers);
+//   * x pass (array axis 2): a lane owns VEC consecutive x and reads the
+//     aligned vectors that cover [x-R, x+VEC-1+R]; neighbouring lanes read the
+//     same lines, so all but ~1/(2*ceil(R/VEC)+1) of the loads are L1 hits.
+// ---------------------------------------------------------------------------
+template <typename T, int V>
+struct VecOf {
+  typedef T type __attribute__((ext_vector_type(V)));
+};
+
+__device__ __forceinline__ int64_t wrap_once(int64_t j, int64_t n) {
+  // valid for -n <= j < 2n
+  return j < 0 ? j + n : (j >= n ? j - n : j);
+}
+
+template <typename T, int VEC, int NT, int RA>
+__global__ __launch_bounds__(kBlock) void k_corr_strided_wrap(
+    const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny,
+    int64_t nx, int axis, Taps<T> taps) {
+  typedef typename VecOf<T, VEC>::type V;
+  constexpr int R = NT / 2;
+  const int64_t nxv = nx / VEC;
+  const int64_t xv = (int64_t)blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;   // 4 waves: 4 different lines
+  // the two non-axis coordinates of this lane
+  const int64_t len = axis == 0 ? nz : ny;
+  const int64_t other = axis == 0 ? ny : nz;        // the remaining slow axis
+  const int64_t o = (int64_t)blockIdx.x * 4 + sub;  // index along `other`
+  const int64_t a0 = (int64_t)blockIdx.z * RA;      // first output along axis
+  if (xv >= nxv || o >= other || a0 >= len) return;
+  const int64_t step = axis == 0 ? ny * nx : nx;
+  const int64_t ostep = axis == 0 ? nx : ny * nx;
+  const T *base = x + o * ostep + xv * VEC;
+  V win[NT + RA - 1];
+#pragma unroll
+  for (int t = 0; t < NT + RA - 1; ++t) {
+    int64_t j = a0 - R + t;
+    if (j < 0 || j >= len) { j %= len; if (j < 0) j += len; }
+    win[t] = *reinterpret_cast<const V *>(base + j * step);
+  }
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    if (a0 + r < len) {
+      V acc = taps.w[0] * win[r];
+#pragma unroll
+      for (int t = 1; t < NT; ++t) acc += taps.w[t] * win[r + t];
+      *reinterpret_cast<V *>(out + o * ostep + xv * VEC + (a0 + r) * step) = acc;
+    }
+  }
+}
+
+template <typename T, int VEC, int NT>
+__global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
+    const T *__restrict__ x, T *__restrict__ out, int64_t nrows, int64_t nx,
+    Taps<T> taps) {
+  typedef typename VecOf<T, VEC>::type V;
+  constexpr int R = NT / 2;
+  constexpr int NBH = (R + VEC - 1) / VEC;  // vectors on each side
+  constexpr int NB = 2 * NBH + 1;
+  const int64_t nxv = nx / VEC;
+  const int64_t xv = (int64_t)blockIdx.y * 64 + (threadIdx.x & 63);
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (xv >= nxv || row >= nrows) return;
+  const T *rp = x + row * nx;
+  T win[NB * VEC];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    int64_t j = xv + b - NBH;
+    if (j < 0 || j >= nxv) { j %= nxv; if (j < 0) j += nxv; }
+    const V v = *reinterpret_cast<const V *>(rp + j * VEC);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) win[b * VEC + k] = v[k];
+  }
+  V res;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    T acc = taps.w[0] * win[NBH * VEC + k - R];
+#pragma unroll
+    for (int t = 1; t < NT; ++t) acc += taps.w[t] * win[NBH * VEC + k - R + t];
+    res[k] = acc;
+  }
+  *reinterpret_cast<V *>(out + row * nx + xv * VEC) = res;
+}
+
+template <typename T, int VEC, int NT>
+int launch_wrap_nt(const T *x, T *out, int axis, int64_t nz, int64_t ny,
+                   int64_t nx, const Taps<T> &taps, hipStream_t st) {
+  constexpr int RA = 4;
+  const int64_t nxv = nx / VEC;
+  if (axis == 2) {
+    const int64_t nrows = nz * ny;
+    dim3 grid((unsigned)((nrows + 3) / 4), (unsigned)((nxv + 63) / 64), 1);
+    hipLaunchKernelGGL((k_corr_x_wrap<T, VEC, NT>), grid, dim3(kBlock), 0, st, x,
+                       out, nrows, nx, taps);
+  } else {
+    const int64_t len = axis == 0 ? nz : ny;
+    const int64_t other = axis == 0 ? ny : nz;
+    dim3 grid((unsigned)((other + 3) / 4), (unsigned)((nxv + 63) / 64),
+              (unsigned)((len + RA - 1) / RA));
+    hipLaunchKernelGGL((k_corr_strided_wrap<T, VEC, NT, RA>), grid, dim3(kBlock),
+                       0, st, x, out, nz, ny, nx, axis, taps);
+  }
+  return launch_status();
+}
+
+// returns -2 when no specialisation applies
+template <typename T>
+int try_launch_wrap(const T *x, T *out, int axis, int64_t nz, int64_t ny,
+                    int64_t nx, const Taps<T> &taps, int ntaps, int centre,
+                    int mode, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (mode != NSOL_MODE_WRAP || (ntaps & 1) == 0 || centre != ntaps / 2 ||
+      nx % VEC != 0 || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(out) & 15u))
+    return -2;
+  // grid limits: x < 2^31 blocks, y and z <= 65535
+  if (nx / VEC > (int64_t)65535 * 64 || nz * ny > (int64_t)0x7fffffff) return -2;
+  if (axis != 2 && (axis == 0 ? nz : ny) > (int64_t)65535 * 4) return -2;
+#define NSOL_NT_CASE(N) \
+  case N: return launch_wrap_nt<T, VEC, N>(x, out, axis, nz, ny, nx, taps, st);
+  switch (ntaps) {
+    NSOL_NT_CASE(3) NSOL_NT_CASE(5) NSOL_NT_CASE(7) NSOL_NT_CASE(9)
+    NSOL_NT_CASE(11) NSOL_NT_CASE(13) NSOL_NT_CASE(15) NSOL_NT_CASE(17)
+    NSOL_NT_CASE(19) NSOL_NT_CASE(21) NSOL_NT_CASE(23) NSOL_NT_CASE(25)
+    default: return -2;
+  }
+#undef NSOL_NT_CASE
+}
+
 template <typename T>
 int corr_axis_impl(const T *x, T *out, int axis, int64_t nz, int64_t ny,
                    int64_t nx, const double *taps_host, int ntaps, int centre,
@@ -119,6 +256,9 @@ int corr_axis_impl(const T *x, T *out, int axis, int64_t nz, int64_t ny,
     return NSOL_EINVAL;
   Taps<T> taps;
   for (int t = 0; t < kMaxTaps; ++t) taps.w[t] = t < ntaps ? (T)taps_host[t] : T(0);
+  const int rc = try_launch_wrap<T>(x, out, axis, nz, ny, nx, taps, ntaps, centre,
+                                    mode, as_stream(stream));
+  if (rc != -2) return rc;
   const int64_t n = nz * ny * nx;
   hipLaunchKernelGGL(k_corr_axis<T>, dim3(grid_for(n)), dim3(kBlock), 0,
                      as_stream(stream), x, out, nz, ny, nx, axis, taps, ntaps,

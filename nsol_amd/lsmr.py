@@ -153,3 +153,121 @@ def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
         if istop > 0:
             break
     return x, istop, itn
+
+
+def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
+               atol=0.0, btol=0.0, conlim=1e8):
+    """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
+    identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
+    are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
+    A, A_adj: device callables (flat tensor -> flat tensor)."""
+    import torch
+    ut, ub = b_top, b_bot
+    normb = math.sqrt(ops.dot(ut, ut) +
+                      (ops.dot(ub, ub) if ub is not None else 0.0))
+    x = torch.zeros_like(x_like)
+    beta = normb
+    su = beta if beta > 0 else 1.0
+    if beta > 0:
+        vt = torch.zeros_like(x_like)
+        # vt = A^T ut + sa B^T ub  (raw, = su * A^T u)
+        nv2 = ops.lsmr_v_update(A_adj(ut), ub, vt, bmode, shape, w, 1.0, sa,
+                                0.0)
+        alpha = math.sqrt(nv2) / su
+    else:
+        vt = torch.zeros_like(x_like)
+        alpha = 0.0
+    sv = su * alpha if alpha > 0 else 1.0
+
+    itn = 0
+    zetabar = alpha * beta
+    alphabar = alpha
+    rho = rhobar = cbar = 1.0
+    sbar = 0.0
+    h = ops.scale(vt, 1.0 / sv)
+    hbar = torch.zeros_like(x_like)
+    betadd, betad = beta, 0.0
+    rhodold = 1.0
+    tautildeold = thetatilde = zeta = d = 0.0
+    normA2 = alpha * alpha
+    maxrbar, minrbar = 0.0, 1e100
+    istop = 0
+    ctol = 1.0 / conlim if conlim > 0 else 0.0
+    if alpha * beta == 0 or normb == 0:
+        return x, istop, itn
+
+    while itn < maxiter:
+        itn += 1
+        # ut <- A v - alpha u   (v = vt/sv, u = ut/su)
+        nu2 = ops.lsmr_u_update(A(vt), vt, ut, ub, bmode, shape, w, 1.0 / sv,
+                                sa / sv, -alpha / su)
+        beta = math.sqrt(nu2)
+        su = beta if beta > 0 else 1.0
+        if beta > 0:
+            # vt <- A^T u - beta v
+            nv2 = ops.lsmr_v_update(A_adj(ut), ub, vt, bmode, shape, w,
+                                    1.0 / beta, sa / beta, -beta / sv)
+            alpha = math.sqrt(nv2)
+            sv = alpha if alpha > 0 else 1.0
+
+        chat, shat, alphahat = _sym_ortho(alphabar, 0.0)
+        rhoold = rho
+        c, s, rho = _sym_ortho(alphahat, beta)
+        thetanew = s * alpha
+        alphabar = c * alpha
+        rhobarold, zetaold = rhobar, zeta
+        thetabar = sbar * rho
+        rhotemp = cbar * rho
+        cbar, sbar, rhobar = _sym_ortho(cbar * rho, thetanew)
+        zeta = cbar * zetabar
+        zetabar = -sbar * zetabar
+
+        normx2 = ops.lsmr_hx_update(
+            hbar, x, h, vt, -(thetabar * rho / (rhoold * rhobarold)),
+            zeta / (rho * rhobar), -(thetanew / rho), 1.0 / sv)
+
+        betaacute = chat * betadd
+        betacheck = -shat * betadd
+        betahat = c * betaacute
+        betadd = -s * betaacute
+        thetatildeold = thetatilde
+        ctildeold, stildeold, rhotildeold = _sym_ortho(rhodold, thetabar)
+        thetatilde = stildeold * rhobar
+        rhodold = ctildeold * rhobar
+        betad = -stildeold * betad + ctildeold * betahat
+        tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold
+        taud = (zeta - thetatilde * tautildeold) / rhodold
+        d = d + betacheck * betacheck
+        normr = math.sqrt(d + (betad - taud) ** 2 + betadd * betadd)
+        normA2 = normA2 + beta * beta
+        normA = math.sqrt(normA2)
+        normA2 = normA2 + alpha * alpha
+        maxrbar = max(maxrbar, rhobarold)
+        if itn > 1:
+            minrbar = min(minrbar, rhobarold)
+        condA = max(maxrbar, rhotemp) / min(minrbar, rhotemp)
+
+        normar = abs(zetabar)
+        normx = math.sqrt(normx2)
+        test1 = normr / normb
+        test2 = normar / (normA * normr) if (normA * normr) != 0 else np.inf
+        test3 = 1.0 / condA
+        t1 = test1 / (1 + normA * normx / normb)
+        rtol = btol + atol * normA * normx / normb
+        if itn >= maxiter:
+            istop = 7
+        if 1 + test3 <= 1:
+            istop = 6
+        if 1 + test2 <= 1:
+            istop = 5
+        if 1 + t1 <= 1:
+            istop = 4
+        if test3 <= ctol:
+            istop = 3
+        if test2 <= atol:
+            istop = 2
+        if test1 <= rtol:
+            istop = 1
+        if istop > 0:
+            break
+    return x, istop, itn

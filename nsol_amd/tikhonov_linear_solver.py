@@ -22,7 +22,12 @@ from .bridge import BridgedCallable
 from .definitions import EPS
 from .device import is_device_tensor, to_device, to_numpy
 from .linear_solver import LinearSolver
-from .lsmr import lsmr
+from .lsmr import lsmr, lsmr_fused
+from .symbolic import trace_operator
+
+
+# set to False to force the generic (un-fused) LSMR vector kernels
+USE_FUSED_LSMR = True
 
 
 class TikhonovLinearSolver(LinearSolver):
@@ -121,9 +126,53 @@ class TikhonovLinearSolver(LinearSolver):
         return matvec, rmatvec, [b.clone()]
 
     def _run_lsmr(self, x0):
+        fused = self._fused_lsmr_setup(x0) if USE_FUSED_LSMR else None
+        if fused is not None:
+            x, _, _ = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max)
+            return x
         matvec, rmatvec, rhs = self._augmented(x0)
         x, _, _ = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
         return x
+
+    def _fused_lsmr_setup(self, x0):
+        """Arguments for lsmr_fused when the regulariser operator is
+        recognised (gradient / identity / absent); None otherwise."""
+        n = x0.numel()
+        A, A_adj, _, _ = self._callables()
+        b = self._dev(self._b)
+        if b.numel() != n:
+            return None
+        if not (self._alpha > EPS):
+            return (A, A_adj, b.clone(), None, ops.B_NONE, (n,),
+                    (1.0, 1.0, 1.0), 0.0)
+        dB = trace_operator(self._B, n)
+        if dB is None:
+            return None
+        if dB[0] == "identity":
+            bmode, shape, w, rows = ops.B_IDENTITY, (n,), (1., 1., 1.), n
+            dBt = trace_operator(self._B_adj, n)
+            if dBt is None or dBt[0] != "identity":
+                return None
+        elif dB[0] == "grad":
+            gop, shape = dB[1], tuple(dB[2])
+            dBt = trace_operator(self._B_adj, gop.dimension * n)
+            if dBt is None or dBt[0] != "grad_adj" or \
+                    tuple(dBt[1].w) != tuple(gop.w) or \
+                    dBt[1].dimension != gop.dimension:
+                return None
+            bmode, w, rows = ops.B_GRAD, gop.w, gop.dimension * n
+        else:
+            return None
+        sa = float(np.sqrt(self._alpha))
+        if is_device_tensor(self._b_reg) or np.ndim(self._b_reg) > 0:
+            lower = ops.scale(self._dev(self._b_reg), sa)
+            if lower.numel() != rows:
+                return None
+        else:
+            import torch
+            lower = torch.full((rows,), sa * float(self._b_reg),
+                               dtype=x0.dtype, device=x0.device)
+        return (A, A_adj, b.clone(), lower, bmode, shape, w, sa)
 
     # ------------------------------------------------------------------
     def _host_linear_operator(self, x0):

@@ -333,8 +333,16 @@ def _dec_ops(golden, k):
     return g, shape, A_, Aa_, D_, Da_
 
 
+@pytest.fixture(params=["fused-lsmr", "generic-lsmr"])
+def lsmr_form(request):
+    import nsol_amd.tikhonov_linear_solver as tk
+    tk.USE_FUSED_LSMR = request.param == "fused-lsmr"
+    yield request.param
+    tk.USE_FUSED_LSMR = True
+
+
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
-def test_tikhonov_lsmr_matches_reference_goldens(nsol, golden, k):
+def test_tikhonov_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
     import nsol_amd.tikhonov_linear_solver as tk
     g, shape, A, Aa, D, Da = _dec_ops(golden, k)
     y = g["y_" + k]
@@ -359,7 +367,7 @@ def test_tikhonov_lsmr_matches_reference_goldens(nsol, golden, k):
 
 
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
-def test_admm_lsmr_matches_reference_goldens(nsol, golden, k):
+def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
     import nsol_amd.admm_linear_solver as admm
     g, shape, A, Aa, D, Da = _dec_ops(golden, k)
     y = g["y_" + k]
