@@ -11,7 +11,7 @@ namespace nsol {
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kBlock = 256;          // 4 waves, one per SIMD
 constexpr int kMaxGridBlocks = 4096; // grid-stride cap: 256 CUs x 16
-constexpr int kReducePartials = 1024;
+constexpr int kReducePartials = 16384;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

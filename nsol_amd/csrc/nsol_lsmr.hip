@@ -7,7 +7,10 @@
 // of ~14 axpy/scale/dot launches.  The bidiagonalisation vectors are kept
 // UNNORMALISED in memory (u~ = beta*u, v~ = alpha*v); the 1/beta, 1/alpha
 // factors ride in the coefficients of the consuming kernel.
+#include <type_traits>
+
 #include "nsol_common.hpp"
+#include "nsol_stencil.hpp"
 
 using namespace nsol;
 
@@ -50,82 +53,155 @@ __global__ __launch_bounds__(kBlock) void k_final(const double *ws, int nparts,
   }
 }
 
+// partial sums land in ws[linear block id]
+__device__ __forceinline__ void store_partial3(double v, double *ws) {
+  __shared__ double s[kBlock / kWave];
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s[k];
+    ws[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// sums nblocks partials in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void k_final_big(const double *ws,
+                                                     int64_t nparts,
+                                                     double *result) {
+  double v = 0.0;
+  for (int64_t k = threadIdx.x; k < nparts; k += 1024) v += ws[k];
+  __shared__ double s[16];
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += s[k];
+    result[0] = t;
+  }
+}
+
 // u_top = c_av*Av + c_u*u_top ; u_bot = c_bv*B(v) + c_u*u_bot ; sum of squares
-template <typename T>
+template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_lsmr_u(
     const T *__restrict__ Av, const T *__restrict__ v, T *__restrict__ u_top,
     T *__restrict__ u_bot, Geom<T> G, int bmode, T c_av, T c_bv, T c_u,
     double *ws) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nrg = row_groups<T, ROWS>(G);
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
-       i += stride) {
-    const T ut = c_av * Av[i] + c_u * u_top[i];
-    u_top[i] = ut;
-    acc += (double)ut * (double)ut;
+  for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
+    const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
+    if (!c.ok) continue;
+    {
+    T a[VEC], u[VEC];
+    vload<T, VEC>(Av + c.i, a);
+    vload<T, VEC>(u_top + c.i, u);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      u[k] = c_av * a[k] + c_u * u[k];
+      acc += (double)u[k] * (double)u[k];
+    }
+    vstore<T, VEC>(u_top + c.i, u);
     if (bmode == kBIdentity) {
-      const T ub = c_bv * v[i] + c_u * u_bot[i];
-      u_bot[i] = ub;
-      acc += (double)ub * (double)ub;
+      vload<T, VEC>(v + c.i, a);
+      vload<T, VEC>(u_bot + c.i, u);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        u[k] = c_bv * a[k] + c_u * u[k];
+        acc += (double)u[k] * (double)u[k];
+      }
+      vstore<T, VEC>(u_bot + c.i, u);
     } else if (bmode == kBGrad) {
-      const int64_t ix = i % G.nx;
-      const int64_t r = i / G.nx;
-      const T c = v[i];
-      {
-        const T nb = (ix + 1 < G.nx) ? v[i + 1] : T(0);
-        const T ub = c_bv * (nb * G.wx + c * (-G.wx)) + c_u * u_bot[i];
-        u_bot[i] = ub;
-        acc += (double)ub * (double)ub;
-      }
-      if (G.ndim >= 2) {
-        const T nb = (r % G.ny + 1 < G.ny) ? v[i + G.sy] : T(0);
-        const T ub = c_bv * (nb * G.wy + c * (-G.wy)) + c_u * u_bot[G.n + i];
-        u_bot[G.n + i] = ub;
-        acc += (double)ub * (double)ub;
-      }
-      if (G.ndim >= 3) {
-        const T nb = (r / G.ny + 1 < G.nz) ? v[i + G.sz] : T(0);
-        const T ub =
-            c_bv * (nb * G.wz + c * (-G.wz)) + c_u * u_bot[2 * G.n + i];
-        u_bot[2 * G.n + i] = ub;
-        acc += (double)ub * (double)ub;
+      T vc[VEC], hi[VEC], d[VEC];
+      vload<T, VEC>(v + c.i, vc);
+      for (int dir = 0; dir < G.ndim; ++dir) {
+        if (dir == 0) {
+          const T right = (c.ix + VEC < G.nx) ? v[c.i + VEC] : T(0);
+          fwd_diff_x<T, VEC>(vc, right, G.wx, d);
+        } else if (dir == 1) {
+          vzero(hi);
+          if (c.iy + 1 < G.ny) vload<T, VEC>(v + c.i + G.sy, hi);
+          fwd_diff<T, VEC>(vc, hi, G.wy, d);
+        } else {
+          vzero(hi);
+          if (c.iz + 1 < G.nz) vload<T, VEC>(v + c.i + G.sz, hi);
+          fwd_diff<T, VEC>(vc, hi, G.wz, d);
+        }
+        vload<T, VEC>(u_bot + dir * G.n + c.i, u);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          u[k] = c_bv * d[k] + c_u * u[k];
+          acc += (double)u[k] * (double)u[k];
+        }
+        vstore<T, VEC>(u_bot + dir * G.n + c.i, u);
       }
     }
+    }
   }
-  store_partial(acc, ws);
+  store_partial3(acc, ws);
 }
 
 // v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v ; sum of squares
-template <typename T>
+template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_lsmr_v(
     const T *__restrict__ Atu, const T *__restrict__ u_bot, T *__restrict__ v,
     Geom<T> G, int bmode, T c_atu, T c_btu, T c_v, double *ws) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nrg = row_groups<T, ROWS>(G);
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
-       i += stride) {
-    T val = c_atu * Atu[i];
+  for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
+    const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
+    if (!c.ok) continue;
+    {
+    T val[VEC], t[VEC], lo[VEC];
+    vload<T, VEC>(Atu + c.i, t);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) val[k] = c_atu * t[k];
     if (bmode == kBIdentity) {
-      val += c_btu * u_bot[i];
+      vload<T, VEC>(u_bot + c.i, t);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) val[k] += c_btu * t[k];
     } else if (bmode == kBGrad) {
-      const int64_t ix = i % G.nx;
-      const int64_t r = i / G.nx;
-      T kt = u_bot[i] * (-G.wx) + ((ix > 0) ? u_bot[i - 1] : T(0)) * G.wx;
+      T kt[VEC];
+      vload<T, VEC>(u_bot + c.i, t);
+      const T left = (c.ix > 0) ? u_bot[c.i - 1] : T(0);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T l = (k > 0) ? t[(k + VEC - 1) % VEC] : left;
+        kt[k] = t[k] * (-G.wx) + l * G.wx;
+      }
       if (G.ndim >= 2) {
         const T *py = u_bot + G.n;
-        kt += py[i] * (-G.wy) + ((r % G.ny > 0) ? py[i - G.sy] : T(0)) * G.wy;
+        vload<T, VEC>(py + c.i, t);
+        vzero(lo);
+        if (c.iy > 0) vload<T, VEC>(py + c.i - G.sy, lo);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) kt[k] += t[k] * (-G.wy) + lo[k] * G.wy;
       }
       if (G.ndim >= 3) {
         const T *pz = u_bot + 2 * G.n;
-        kt += pz[i] * (-G.wz) + ((r / G.ny > 0) ? pz[i - G.sz] : T(0)) * G.wz;
+        vload<T, VEC>(pz + c.i, t);
+        vzero(lo);
+        if (c.iz > 0) vload<T, VEC>(pz + c.i - G.sz, lo);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) kt[k] += t[k] * (-G.wz) + lo[k] * G.wz;
       }
-      val += c_btu * kt;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) val[k] += c_btu * kt[k];
     }
-    val += c_v * v[i];
-    v[i] = val;
-    acc += (double)val * (double)val;
+    vload<T, VEC>(v + c.i, t);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      val[k] += c_v * t[k];
+      acc += (double)val[k] * (double)val[k];
+    }
+    vstore<T, VEC>(v + c.i, val);
+    }
   }
-  store_partial(acc, ws);
+  store_partial3(acc, ws);
 }
 
 // hbar = h + c_hbar*hbar ; x = x + c_x*hbar ; h = c_v*v + c_h*h ; sum x^2
@@ -156,6 +232,16 @@ inline int rgrid(int64_t n) {
   return g > kReducePartials ? kReducePartials : g;
 }
 
+// The stencil-mapped kernels leave one partial per workgroup; the caller's
+// workspace holds kReducePartials doubles, so volumes with more workgroups
+// than that reduce through a private scratch area past it is NOT available:
+// instead rows are folded -- see ws_blocks().
+template <int VEC, int ROWS>
+inline int64_t grid_blocks(int64_t nz, int64_t ny, int64_t nx) {
+  const dim3 g = stencil_grid<VEC, ROWS>(nz, ny, nx);
+  return (int64_t)g.x * g.y * g.z;
+}
+
 template <typename T>
 int u_impl(const T *Av, const T *v, T *u_top, T *u_bot, int bmode, int ndim,
            int64_t nz, int64_t ny, int64_t nx, double wx, double wy, double wz,
@@ -166,12 +252,18 @@ int u_impl(const T *Av, const T *v, T *u_top, T *u_bot, int bmode, int ndim,
       (bmode != kBNone && (!v || !u_bot)))
     return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  const int g = rgrid(G.n);
-  hipLaunchKernelGGL(k_lsmr_u<T>, dim3(g), dim3(kBlock), 0, as_stream(stream),
-                     Av, v, u_top, u_bot, G, bmode, (T)c_av, (T)c_bv, (T)c_u, ws);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, g,
-                     result);
-  return launch_status();
+  const bool al = ptr16(Av) && ptr16(u_top) && (!v || ptr16(v)) &&
+                  (!u_bot || ptr16(u_bot)) && G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
+    hipLaunchKernelGGL((k_lsmr_u<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), Av, v, u_top, u_bot, G,
+                       bmode, (T)c_av, (T)c_bv, (T)c_u, ws);
+    hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
+                       nb, result);
+    return launch_status();
+  });
 }
 
 template <typename T>
@@ -184,12 +276,18 @@ int v_impl(const T *Atu, const T *u_bot, T *v, int bmode, int ndim, int64_t nz,
       (bmode != kBNone && !u_bot))
     return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  const int g = rgrid(G.n);
-  hipLaunchKernelGGL(k_lsmr_v<T>, dim3(g), dim3(kBlock), 0, as_stream(stream),
-                     Atu, u_bot, v, G, bmode, (T)c_atu, (T)c_btu, (T)c_v, ws);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, g,
-                     result);
-  return launch_status();
+  const bool al = ptr16(Atu) && ptr16(v) && (!u_bot || ptr16(u_bot)) &&
+                  G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
+    hipLaunchKernelGGL((k_lsmr_v<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), Atu, u_bot, v, G, bmode,
+                       (T)c_atu, (T)c_btu, (T)c_v, ws);
+    hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
+                       nb, result);
+    return launch_status();
+  });
 }
 
 template <typename T>

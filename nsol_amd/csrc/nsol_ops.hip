@@ -3,7 +3,10 @@
 // and the robust data term.  All are HBM-bound maps: one coalesced pass, x is
 // the fastest-varying thread index, neighbours along y/z come from other rows
 // that the same or an adjacent wave touches (L1/L2 hits).
+#include <type_traits>
+
 #include "nsol_common.hpp"
+#include "nsol_stencil.hpp"
 
 using namespace nsol;
 
@@ -11,58 +14,76 @@ namespace {
 
 // ---------------------------------------------------------------- grad ----
 // reference: linear_operators.py:98-106 (D_a = convolve(x, [1,-1]/h, "constant"))
-template <typename T>
+template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_grad(const T *__restrict__ x,
                                                   T *__restrict__ g, Geom<T> G) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
-       i += stride) {
-    const int64_t ix = i % G.nx;
-    const int64_t r = i / G.nx;
-    const int64_t iy = r % G.ny;
-    const int64_t iz = r / G.ny;
-    const T c = x[i];
-    const T xr = (ix + 1 < G.nx) ? x[i + 1] : T(0);
-    g[i] = xr * G.wx + c * (-G.wx);
-    if (G.ndim >= 2) {
-      const T xd = (iy + 1 < G.ny) ? x[i + G.sy] : T(0);
-      g[G.n + i] = xd * G.wy + c * (-G.wy);
-    }
-    if (G.ndim >= 3) {
-      const T xb = (iz + 1 < G.nz) ? x[i + G.sz] : T(0);
-      g[2 * G.n + i] = xb * G.wz + c * (-G.wz);
-    }
+  const int64_t nrg = row_groups<T, ROWS>(G);
+  for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
+  const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
+  if (!c.ok) continue;
+  T v[VEC], hi[VEC], d[VEC];
+  vload<T, VEC>(x + c.i, v);
+  const T right = (c.ix + VEC < G.nx) ? x[c.i + VEC] : T(0);
+  fwd_diff_x<T, VEC>(v, right, G.wx, d);
+  vstore<T, VEC>(g + c.i, d);
+  if (G.ndim >= 2) {
+    vzero(hi);
+    if (c.iy + 1 < G.ny) vload<T, VEC>(x + c.i + G.sy, hi);
+    fwd_diff<T, VEC>(v, hi, G.wy, d);
+    vstore<T, VEC>(g + G.n + c.i, d);
+  }
+  if (G.ndim >= 3) {
+    vzero(hi);
+    if (c.iz + 1 < G.nz) vload<T, VEC>(x + c.i + G.sz, hi);
+    fwd_diff<T, VEC>(v, hi, G.wz, d);
+    vstore<T, VEC>(g + 2 * G.n + c.i, d);
+  }
   }
 }
 
-// reference: linear_operators.py:158-169 (sum of D_a^T, accumulated in the
-// order x, y, z as `D_adj_x += ...` does)
-template <typename T>
-__device__ __forceinline__ T grad_adj_at(const T *__restrict__ p, const Geom<T> &G,
-                                         int64_t i, int64_t ix, int64_t iy,
-                                         int64_t iz) {
-  T acc = p[i] * (-G.wx) + ((ix > 0) ? p[i - 1] : T(0)) * G.wx;
+// K^T at the lane's VEC voxels: sum over a of p_a[i]*(-w_a) + p_a[i-e_a]*w_a,
+// accumulated x, y, z as linear_operators.py:158-169 does (`D_adj_x += ...`)
+template <typename T, int VEC>
+__device__ __forceinline__ void grad_adj_vec(const T *__restrict__ p,
+                                             const Geom<T> &G, const Voxel &c,
+                                             T (&acc)[VEC]) {
+  T v[VEC], lo[VEC];
+  vload<T, VEC>(p + c.i, v);
+  const T left = (c.ix > 0) ? p[c.i - 1] : T(0);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const T l = (k > 0) ? v[(k + VEC - 1) % VEC] : left;
+    acc[k] = v[k] * (-G.wx) + l * G.wx;
+  }
   if (G.ndim >= 2) {
     const T *py = p + G.n;
-    acc += py[i] * (-G.wy) + ((iy > 0) ? py[i - G.sy] : T(0)) * G.wy;
+    vload<T, VEC>(py + c.i, v);
+    vzero(lo);
+    if (c.iy > 0) vload<T, VEC>(py + c.i - G.sy, lo);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k] * (-G.wy) + lo[k] * G.wy;
   }
   if (G.ndim >= 3) {
     const T *pz = p + 2 * G.n;
-    acc += pz[i] * (-G.wz) + ((iz > 0) ? pz[i - G.sz] : T(0)) * G.wz;
+    vload<T, VEC>(pz + c.i, v);
+    vzero(lo);
+    if (c.iz > 0) vload<T, VEC>(pz + c.i - G.sz, lo);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] += v[k] * (-G.wz) + lo[k] * G.wz;
   }
-  return acc;
 }
 
-template <typename T>
+template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
                                                       T *__restrict__ out,
                                                       Geom<T> G) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
-       i += stride) {
-    const int64_t ix = i % G.nx;
-    const int64_t r = i / G.nx;
-    out[i] = grad_adj_at(p, G, i, ix, r % G.ny, r / G.ny);
+  const int64_t nrg = row_groups<T, ROWS>(G);
+  for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
+    const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
+    if (!c.ok) continue;
+    T acc[VEC];
+    grad_adj_vec<T, VEC>(p, G, c, acc);
+    vstore<T, VEC>(out + c.i, acc);
   }
 }
 
@@ -166,7 +187,7 @@ inline int reduce_grid(int64_t n) {
 
 // ------------------------------------------------------------------ ADMM ----
 // admm_linear_solver.py:208-216 with grad fused in
-template <typename T>
+template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
                                                      T *__restrict__ v,
                                                      T *__restrict__ w,
@@ -174,44 +195,55 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
                                                      T *__restrict__ rhs,
                                                      Geom<T> G, T thr,
                                                      T rhs_scale) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G.n;
-       i += stride) {
-    const int64_t ix = i % G.nx;
-    const int64_t r = i / G.nx;
-    const int64_t iy = r % G.ny;
-    const int64_t iz = r / G.ny;
-    const T xc = x[i];
-    T t[3] = {T(0), T(0), T(0)};
-    T cc[3] = {T(0), T(0), T(0)};
-    {
-      const T nb = (ix + 1 < G.nx) ? x[i + 1] : T(0);
-      t[0] = nb * G.wx + xc * (-G.wx);
+  const int64_t nrg = row_groups<T, ROWS>(G);
+  for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
+  const Voxel q = voxel_at<T, VEC, ROWS>(G, rg);
+  if (!q.ok) continue;
+  T xc[VEC], hi[VEC];
+  T t[3][VEC], cc[3][VEC];
+  vload<T, VEC>(x + q.i, xc);
+  const T right = (q.ix + VEC < G.nx) ? x[q.i + VEC] : T(0);
+  fwd_diff_x<T, VEC>(xc, right, G.wx, t[0]);
+  if (G.ndim >= 2) {
+    vzero(hi);
+    if (q.iy + 1 < G.ny) vload<T, VEC>(x + q.i + G.sy, hi);
+    fwd_diff<T, VEC>(xc, hi, G.wy, t[1]);
+  }
+  if (G.ndim >= 3) {
+    vzero(hi);
+    if (q.iz + 1 < G.nz) vload<T, VEC>(x + q.i + G.sz, hi);
+    fwd_diff<T, VEC>(xc, hi, G.wz, t[2]);
+  }
+  T n2[VEC];
+  for (int a = 0; a < G.ndim; ++a) {
+    T wv[VEC];
+    vzero(cc[a]);
+    if (c) vload<T, VEC>(c + a * G.n + q.i, cc[a]);
+    vload<T, VEC>(w + a * G.n + q.i, wv);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      t[a][k] = t[a][k] + wv[k] - cc[a][k];
+      n2[k] = (a == 0) ? t[a][k] * t[a][k] : n2[k] + t[a][k] * t[a][k];
     }
-    if (G.ndim >= 2) {
-      const T nb = (iy + 1 < G.ny) ? x[i + G.sy] : T(0);
-      t[1] = nb * G.wy + xc * (-G.wy);
+  }
+  T nrm[VEC], mag[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    nrm[k] = t_sqrt(n2[k]);
+    mag[k] = t_max(t_abs(nrm[k]) - thr, T(0)) * t_sign(nrm[k]);
+  }
+  for (int a = 0; a < G.ndim; ++a) {
+    T va[VEC], wa[VEC], ra[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      va[k] = (nrm[k] > thr) ? mag[k] * t[a][k] / nrm[k] : T(0);
+      wa[k] = t[a][k] - va[k];
+      ra[k] = rhs_scale * (va[k] - wa[k] + cc[a][k]);
     }
-    if (G.ndim >= 3) {
-      const T nb = (iz + 1 < G.nz) ? x[i + G.sz] : T(0);
-      t[2] = nb * G.wz + xc * (-G.wz);
-    }
-    T n2 = T(0);
-    for (int a = 0; a < G.ndim; ++a) {
-      if (c) cc[a] = c[a * G.n + i];
-      t[a] = t[a] + w[a * G.n + i] - cc[a];
-      n2 = (a == 0) ? t[a] * t[a] : n2 + t[a] * t[a];
-    }
-    const T nrm = t_sqrt(n2);
-    const bool on = nrm > thr;
-    const T mag = t_max(t_abs(nrm) - thr, T(0)) * t_sign(nrm);
-    for (int a = 0; a < G.ndim; ++a) {
-      const T va = on ? mag * t[a] / nrm : T(0);
-      const T wa = t[a] - va;
-      v[a * G.n + i] = va;
-      w[a * G.n + i] = wa;
-      if (rhs) rhs[a * G.n + i] = rhs_scale * (va - wa + cc[a]);
-    }
+    vstore<T, VEC>(v + a * G.n + q.i, va);
+    vstore<T, VEC>(w + a * G.n + q.i, wa);
+    if (rhs) vstore<T, VEC>(rhs + a * G.n + q.i, ra);
+  }
   }
 }
 
@@ -359,9 +391,13 @@ int grad_impl(const T *x, T *g, int ndim, int64_t nz, int64_t ny, int64_t nx,
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (!x || !g) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  hipLaunchKernelGGL(k_grad<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
-                     as_stream(stream), x, g, G);
-  return launch_status();
+  return dispatch_stencil<T>(nz, ny, nx, ptr16(x) && ptr16(g) && G.n % 4 == 0,
+                             [&](auto vec, auto rows) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    hipLaunchKernelGGL((k_grad<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), x, g, G);
+    return launch_status();
+  });
 }
 
 template <typename T>
@@ -370,9 +406,13 @@ int grad_adj_impl(const T *p, T *out, int ndim, int64_t nz, int64_t ny,
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (!p || !out) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  hipLaunchKernelGGL(k_grad_adj<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
-                     as_stream(stream), p, out, G);
-  return launch_status();
+  return dispatch_stencil<T>(nz, ny, nx, ptr16(p) && ptr16(out) && G.n % 4 == 0,
+                             [&](auto vec, auto rows) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    hipLaunchKernelGGL((k_grad_adj<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), p, out, G);
+    return launch_status();
+  });
 }
 
 template <typename T>
@@ -405,10 +445,15 @@ int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (!x || !v || !w) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  hipLaunchKernelGGL(k_admm_vw<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
-                     as_stream(stream), x, v, w, c, rhs, G, (T)thr,
-                     (T)rhs_scale);
-  return launch_status();
+  const bool al = ptr16(x) && ptr16(v) && ptr16(w) && (!c || ptr16(c)) &&
+                  (!rhs || ptr16(rhs)) && G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    hipLaunchKernelGGL((k_admm_vw<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), x, v, w, c, rhs, G,
+                       (T)thr, (T)rhs_scale);
+    return launch_status();
+  });
 }
 
 template <typename T>

@@ -1,0 +1,135 @@
+// Thread <-> voxel mapping shared by the stand-alone stencil kernels.
+//
+// A 256-thread workgroup covers ROWS consecutive y-rows (one wave each when
+// ROWS = 4, all four waves on one row when ROWS = 1) and 64*VEC*(4/ROWS)
+// consecutive x per row; blockIdx.y walks y, blockIdx.z walks z.  No integer
+// division is needed to recover (x, y, z), every own-voxel access is one
+// 16-byte load/store when VEC > 1, and the +-1 neighbours along y / z are again
+// aligned vectors (L2 hits: the adjacent row is read by the adjacent wave).
+#pragma once
+
+#include "nsol_common.hpp"
+
+namespace nsol {
+
+template <typename T, int V>
+struct VecT {
+  typedef T type __attribute__((ext_vector_type(V)));
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void vload(const T *p, T (&v)[V]) {
+  if constexpr (V == 1) {
+    v[0] = *p;
+  } else {
+    typedef typename VecT<T, V>::type P;
+    const P t = *reinterpret_cast<const P *>(p);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = t[k];
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void vstore(T *p, const T (&v)[V]) {
+  if constexpr (V == 1) {
+    *p = v[0];
+  } else {
+    typedef typename VecT<T, V>::type P;
+    P t;
+#pragma unroll
+    for (int k = 0; k < V; ++k) t[k] = v[k];
+    *reinterpret_cast<P *>(p) = t;
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void vzero(T (&v)[V]) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) v[k] = T(0);
+}
+
+struct Voxel {
+  int64_t ix, iy, iz, i;
+  bool ok;
+};
+
+// Row groups (ROWS consecutive rows of one z-plane) are dealt to blockIdx.y
+// grid-stride: rg = blockIdx.y, blockIdx.y + gridDim.y, ...
+template <typename T, int ROWS>
+__device__ __forceinline__ int64_t row_groups(const Geom<T> &G) {
+  return ((G.ny + ROWS - 1) / ROWS) * G.nz;
+}
+
+template <typename T, int VEC, int ROWS>
+__device__ __forceinline__ Voxel voxel_at(const Geom<T> &G, int64_t rg) {
+  Voxel c;
+  constexpr int XT = kBlock / ROWS;  // threads along x
+  const unsigned rgy = (unsigned)((G.ny + ROWS - 1) / ROWS);
+  const unsigned urg = (unsigned)rg;  // < 2^31 (checked on the host)
+  c.iz = urg / rgy;
+  c.iy = (int64_t)(urg - (unsigned)c.iz * rgy) * ROWS + (threadIdx.x / XT);
+  c.ix = ((int64_t)blockIdx.x * XT + (threadIdx.x % XT)) * VEC;
+  c.ok = c.ix < G.nx && c.iy < G.ny;
+  c.i = (c.iz * G.ny + c.iy) * G.nx + c.ix;
+  return c;
+}
+
+constexpr int kStencilMaxBlocks = 16384;  // = reduction partials (kReducePartials)
+
+template <int VEC, int ROWS>
+inline dim3 stencil_grid(int64_t nz, int64_t ny, int64_t nx) {
+  constexpr int XT = kBlock / ROWS;
+  const int64_t gx = (nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
+  const int64_t nrg = ((ny + ROWS - 1) / ROWS) * nz;
+  int64_t gy = kStencilMaxBlocks / (gx > 0 ? gx : 1);
+  if (gy < 1) gy = 1;
+  if (gy > nrg) gy = nrg;
+  return dim3((unsigned)gx, (unsigned)gy, 1);
+}
+
+inline bool stencil_grid_ok(int64_t nz, int64_t ny, int64_t nx) {
+  return ((ny + 3) / 4) * nz < (int64_t)0x7fffffff &&
+         nx / 64 + 1 <= kStencilMaxBlocks;
+}
+
+template <typename T>
+inline bool ptr16(const T *p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// Calls f(integral_constant<VEC>, integral_constant<ROWS>) with the widest
+// legal vector width; all listed pointers must be 16-byte aligned for VEC > 1.
+template <typename T, typename F>
+inline int dispatch_stencil(int64_t nz, int64_t ny, int64_t nx, bool aligned,
+                            F f) {
+  if (!stencil_grid_ok(nz, ny, nx)) return NSOL_EINVAL;
+  constexpr int VW = 16 / sizeof(T);
+  const bool vec = aligned && (nx % VW == 0);
+  if (ny == 1) {
+    if (vec) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 1>());
+    return f(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+  }
+  if (vec) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 4>());
+  return f(std::integral_constant<int, 1>(), std::integral_constant<int, 4>());
+}
+
+// forward difference of the lane's VEC voxels along x/y/z, reference order
+// hi*w + lo*(-w); `right` = value just past the vector (0 at the boundary)
+template <typename T, int VEC>
+__device__ __forceinline__ void fwd_diff_x(const T (&c)[VEC], T right, T w,
+                                           T (&g)[VEC]) {
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const T hi = (k + 1 < VEC) ? c[(k + 1) % VEC] : right;
+    g[k] = hi * w + c[k] * (-w);
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void fwd_diff(const T (&c)[VEC], const T (&hi)[VEC],
+                                         T w, T (&g)[VEC]) {
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) g[k] = hi[k] * w + c[k] * (-w);
+}
+
+}  // namespace nsol

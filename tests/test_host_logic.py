@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_declared_symbols():
             assert "nsol_%s_%s" % (base, suf) in decl
     lib = _lib.load()            # binds every symbol or raises
     assert lib.nsol_hip_abi_version() == 1
-    assert lib.nsol_hip_reduce_ws_doubles() == 1024
+    assert lib.nsol_hip_reduce_ws_doubles() == 16384
 
 
 def test_product_does_not_import_the_oracle():
