@@ -212,24 +212,52 @@ int nsol_pd_fused_iter_f64(const double *xbar_in, double *xbar_out, double *x,
                            double wx, double wy, double wz, double sigma,
                            double hden, double tau, double tl, double theta,
                            int flags, void *stream);
-/* `iterations` fused iterations enqueued back to back with the host-side step
+/* TWO iterations in a single pass over memory (temporal blocking; 11 words per
+ * voxel for both).  *_2 arguments are HOST arrays of two doubles (iteration n,
+ * n+1).  x is ping-pong as well (x_in != x_out): overlapping workgroup
+ * footprints re-read neighbours' old x.  Returns -2 (and launches nothing) when
+ * the kernel does not apply (ndim != 3, nx not a multiple of 16 bytes or
+ * narrower than 64 vectors, unaligned pointers): call the one-iteration form
+ * twice then.  Results are bit-identical to two nsol_pd_fused_iter_* calls. */
+int nsol_pd_fused2_iter_f32(const float *xbar_in, float *xbar_out,
+                            const float *x_in, float *x_out, const float *bt,
+                            const float *p_in, float *p_out, int ndim,
+                            int64_t nz, int64_t ny, int64_t nx, double wx,
+                            double wy, double wz, const double *sigma_2,
+                            const double *hden_2, const double *tau_2,
+                            const double *tl_2, const double *theta_2,
+                            int flags, void *stream);
+int nsol_pd_fused2_iter_f64(const double *xbar_in, double *xbar_out,
+                            const double *x_in, double *x_out,
+                            const double *bt, const double *p_in,
+                            double *p_out, int ndim, int64_t nz, int64_t ny,
+                            int64_t nx, double wx, double wy, double wz,
+                            const double *sigma_2, const double *hden_2,
+                            const double *tau_2, const double *tl_2,
+                            const double *theta_2, int flags, void *stream);
+/* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;
- * iteration n reads buffer (n & 1) and writes buffer ((n+1) & 1).  p0 is
- * treated as zero in iteration 0 when p_is_zero != 0.  gamma_huber is the
- * Huber parameter (0.05). */
-int nsol_pd_run_f32(float *xbar0, float *xbar1, float *x, const float *bt,
-                    float *p0, float *p1, int ndim, int64_t nz, int64_t ny,
-                    int64_t nx, double wx, double wy, double wz, double lambda,
-                    const double *sigma_host, const double *tau_host,
-                    const double *theta_host, int iterations, int p_is_zero,
-                    double gamma_huber, int flags, void *stream);
-int nsol_pd_run_f64(double *xbar0, double *xbar1, double *x, const double *bt,
-                    double *p0, double *p1, int ndim, int64_t nz, int64_t ny,
-                    int64_t nx, double wx, double wy, double wz, double lambda,
-                    const double *sigma_host, const double *tau_host,
-                    const double *theta_host, int iterations, int p_is_zero,
-                    double gamma_huber, int flags, void *stream);
+ * every launch reads slot s and writes slot s^1, starting from slot 0.  Pairs
+ * of iterations use the two-iteration kernel when x_alt (scratch of the size of
+ * x, may be NULL) is given and the kernel applies.  On return x holds the final
+ * primal iterate and *final_slot_host (may be NULL) the slot holding the final
+ * xbar / p.  p0 is treated as zero in iteration 0 when p_is_zero != 0.
+ * gamma_huber is the Huber parameter (0.05). */
+int nsol_pd_run_f32(float *xbar0, float *xbar1, float *x, float *x_alt,
+                    const float *bt, float *p0, float *p1, int ndim,
+                    int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                    double wz, double lambda, const double *sigma_host,
+                    const double *tau_host, const double *theta_host,
+                    int iterations, int p_is_zero, double gamma_huber,
+                    int flags, int *final_slot_host, void *stream);
+int nsol_pd_run_f64(double *xbar0, double *xbar1, double *x, double *x_alt,
+                    const double *bt, double *p0, double *p1, int ndim,
+                    int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                    double wz, double lambda, const double *sigma_host,
+                    const double *tau_host, const double *theta_host,
+                    int iterations, int p_is_zero, double gamma_huber,
+                    int flags, int *final_slot_host, void *stream);
 
 /* ---------------------------------------------------------------------- *
  * ADMM outer update, admm_linear_solver.py:202-218, 239-253

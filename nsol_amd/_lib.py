@@ -65,6 +65,8 @@ def load():
     # experiment knob, not part of the reference-facing ABI
     lib.nsol_hip_set_param.restype = c_int
     lib.nsol_hip_set_param.argtypes = [ctypes.c_char_p, c_int]
+    lib.nsol_hip_set_param_pd2.restype = c_int
+    lib.nsol_hip_set_param_pd2.argtypes = [ctypes.c_char_p, c_int]
     if lib.nsol_hip_abi_version() != 1:
         raise NsolHipError("libnsol_hip.so ABI version mismatch")
     _lib = lib
@@ -79,4 +81,7 @@ def check(rc, what):
 
 
 def set_param(name, value):
-    check(load().nsol_hip_set_param(name.encode(), int(value)), "set_param")
+    lib = load()
+    fn = lib.nsol_hip_set_param_pd2 if name.startswith("pd2_") \
+        else lib.nsol_hip_set_param
+    check(fn(name.encode(), int(value)), "set_param")

@@ -66,9 +66,12 @@ template <typename T> __device__ __forceinline__ T t_sqrt(T v);
 template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return sqrtf(v); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
 
-// x / max(1, |x|)   (proximal_operators.py:139-140)
+// x / max(1, |x|)   (proximal_operators.py:139-140), without the division:
+// |x| <= 1 -> x / 1 = x exactly;  |x| > 1 -> x / |x| = +-1 exactly in IEEE
+// arithmetic, so the result is bit-identical to the quotient.
 template <typename T> __device__ __forceinline__ T dual_clamp(T q) {
-  return q / t_max(T(1), t_abs(q));
+  const T a = t_abs(q);
+  return (a > T(1)) ? (q > T(0) ? T(1) : T(-1)) : q;
 }
 
 // np.sign

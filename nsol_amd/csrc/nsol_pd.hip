@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include "nsol_common.hpp"
+#include "nsol_pd_common.hpp"
 
 using namespace nsol;
 
@@ -99,57 +100,6 @@ __global__ __launch_bounds__(kBlock) void k_primal_step(
 // ---------------------------------------------------------------------------
 // single-pass fused form
 // ---------------------------------------------------------------------------
-template <typename T, int V>
-struct Pack {
-  typedef T type __attribute__((ext_vector_type(V)));
-};
-
-template <typename T, int V>
-__device__ __forceinline__ void ldv(const T *p, T (&v)[V]) {
-  if constexpr (V == 1) {
-    v[0] = *p;
-  } else {
-    typedef typename Pack<T, V>::type P;
-    const P t = *reinterpret_cast<const P *>(p);
-#pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = t[k];
-  }
-}
-
-template <typename T, int V>
-__device__ __forceinline__ void stv(T *p, const T (&v)[V]) {
-  if constexpr (V == 1) {
-    *p = v[0];
-  } else {
-    typedef typename Pack<T, V>::type P;
-    P t;
-#pragma unroll
-    for (int k = 0; k < V; ++k) t[k] = v[k];
-    *reinterpret_cast<P *>(p) = t;
-  }
-}
-
-template <typename T, int V>
-__device__ __forceinline__ void zero(T (&v)[V]) {
-#pragma unroll
-  for (int k = 0; k < V; ++k) v[k] = T(0);
-}
-
-template <typename T>
-struct PdScalars {
-  T sigma, hden, tau, tl, one_plus_tl, theta;
-  int huber, l1, has_p;
-};
-
-// p_new = clamp((p_old + sigma * (hi*w + lo*(-w))) / hden)
-template <typename T>
-__device__ __forceinline__ T dual_update(T p_old, T hi, T lo, T w,
-                                         const PdScalars<T> &S) {
-  T q = p_old + S.sigma * (hi * w + lo * (-w));
-  if (S.huber) q = q / S.hden;
-  return dual_clamp(q);
-}
-
 template <typename T, int VEC, int LX, int RY, int NDIM>
 __global__ __launch_bounds__(kBlock) void k_pd_fused(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out, T *x,
@@ -506,37 +456,82 @@ int primal_step_impl(const T *p, T *x, T *xbar, const T *bt, int ndim,
   return launch_status();
 }
 
+inline int fused2_call(const float *a, float *b, const float *c, float *d,
+                       const float *e, const float *f, float *g, int ndim,
+                       int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                       double wz, const double *s, const double *h,
+                       const double *t, const double *tl, const double *th,
+                       int flags, void *st) {
+  return nsol_pd_fused2_iter_f32(a, b, c, d, e, f, g, ndim, nz, ny, nx, wx, wy, wz,
+                                 s, h, t, tl, th, flags, st);
+}
+inline int fused2_call(const double *a, double *b, const double *c, double *d,
+                       const double *e, const double *f, double *g, int ndim,
+                       int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                       double wz, const double *s, const double *h,
+                       const double *t, const double *tl, const double *th,
+                       int flags, void *st) {
+  return nsol_pd_fused2_iter_f64(a, b, c, d, e, f, g, ndim, nz, ny, nx, wx, wy, wz,
+                                 s, h, t, tl, th, flags, st);
+}
+
 template <typename T>
-int run_impl(T *xbar0, T *xbar1, T *x, const T *bt, T *p0, T *p1, int ndim,
-             int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
+             int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
              double wz, double lambda, const double *sig, const double *tau,
              const double *theta, int iterations, int p_is_zero,
-             double gamma_huber, int flags, void *stream) {
+             double gamma_huber, int flags, int *final_slot, void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (iterations < 0 || !sig || !tau || !theta) return NSOL_EINVAL;
+  if (iterations < 0 || !sig || !tau || !theta || !x) return NSOL_EINVAL;
   T *xb[2] = {xbar0, xbar1};
   T *pp[2] = {p0, p1};
+  T *xcur = x, *xoth = x_alt;
+  int slot = 0;
   const bool huber = (flags & NSOL_PD_REG_HUBER) != 0;
-  for (int n = 0; n < iterations; ++n) {
+  int n = 0;
+  while (n < iterations) {
+    const T *pin = (n == 0 && p_is_zero) ? nullptr : pp[slot];
+    int rc = -2;
+    if (xoth && n + 1 < iterations && !g_tune.force_two_pass) {
+      double h2[2], tl2[2];
+      for (int i = 0; i < 2; ++i) {
+        h2[i] = huber ? 1.0 + sig[n + i] * gamma_huber : 1.0;
+        tl2[i] = tau[n + i] * lambda;
+      }
+      rc = fused2_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
+                       ndim, nz, ny, nx, wx, wy, wz, sig + n, h2, tau + n, tl2,
+                       theta + n, flags, stream);
+      if (rc == 0) {
+        n += 2;
+        slot ^= 1;
+        T *t = xcur; xcur = xoth; xoth = t;
+        continue;
+      }
+      if (rc != -2) return rc;
+    }
     const double hden = huber ? 1.0 + sig[n] * gamma_huber : 1.0;
-    const T *pin = (n == 0 && p_is_zero) ? nullptr : pp[n & 1];
-    int rc;
     if (g_tune.force_two_pass) {
-      rc = dual_step_impl<T>(xb[n & 1], pin, pp[(n + 1) & 1], ndim, nz, ny, nx,
-                             wx, wy, wz, sig[n], hden, stream);
+      rc = dual_step_impl<T>(xb[slot], pin, pp[slot ^ 1], ndim, nz, ny, nx, wx, wy,
+                             wz, sig[n], hden, stream);
       if (rc) return rc;
-      // the two-pass form updates xbar in place: keep the ping-pong contract
-      rc = primal_step_impl<T>(pp[(n + 1) & 1], x, xb[(n + 1) & 1], bt, ndim, nz,
-                               ny, nx, wx, wy, wz, tau[n], tau[n] * lambda,
-                               theta[n], flags, stream);
+      rc = primal_step_impl<T>(pp[slot ^ 1], xcur, xb[slot ^ 1], bt, ndim, nz, ny,
+                               nx, wx, wy, wz, tau[n], tau[n] * lambda, theta[n],
+                               flags, stream);
     } else {
-      rc = fused_iter_impl<T>(xb[n & 1], xb[(n + 1) & 1], x, bt, pin,
-                              pp[(n + 1) & 1], ndim, nz, ny, nx, wx, wy, wz,
-                              sig[n], hden, tau[n], tau[n] * lambda, theta[n],
-                              flags, stream);
+      rc = fused_iter_impl<T>(xb[slot], xb[slot ^ 1], xcur, bt, pin, pp[slot ^ 1],
+                              ndim, nz, ny, nx, wx, wy, wz, sig[n], hden, tau[n],
+                              tau[n] * lambda, theta[n], flags, stream);
     }
     if (rc) return rc;
+    n += 1;
+    slot ^= 1;
   }
+  if (xcur != x) {
+    hipError_t e = hipMemcpyAsync(x, xcur, sizeof(T) * (size_t)(nz * ny * nx),
+                                  hipMemcpyDeviceToDevice, as_stream(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  if (final_slot) *final_slot = slot;
   return 0;
 }
 
@@ -578,13 +573,15 @@ int nsol_hip_set_param(const char *name, int value) {
     return fused_iter_impl<T>(xi, xo, x, bt, pi, po, ndim, nz, ny, nx, wx, wy,   \
                               wz, sigma, hden, tau, tl, theta, flags, s);        \
   }                                                                              \
-  int nsol_pd_run_##SUF(T *xb0, T *xb1, T *x, const T *bt, T *p0, T *p1,         \
-                        int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, \
-                        double wy, double wz, double lambda, const double *sg,   \
-                        const double *ta, const double *th, int iters,           \
-                        int p_is_zero, double gh, int flags, void *s) {          \
-    return run_impl<T>(xb0, xb1, x, bt, p0, p1, ndim, nz, ny, nx, wx, wy, wz,    \
-                       lambda, sg, ta, th, iters, p_is_zero, gh, flags, s);      \
+  int nsol_pd_run_##SUF(T *xb0, T *xb1, T *x, T *x_alt, const T *bt, T *p0,      \
+                        T *p1, int ndim, int64_t nz, int64_t ny, int64_t nx,     \
+                        double wx, double wy, double wz, double lambda,          \
+                        const double *sg, const double *ta, const double *th,    \
+                        int iters, int p_is_zero, double gh, int flags,          \
+                        int *final_slot, void *s) {                              \
+    return run_impl<T>(xb0, xb1, x, x_alt, bt, p0, p1, ndim, nz, ny, nx, wx, wy,  \
+                       wz, lambda, sg, ta, th, iters, p_is_zero, gh, flags,      \
+                       final_slot, s);                                           \
   }
 
 NSOL_PD_DEF(float, f32)

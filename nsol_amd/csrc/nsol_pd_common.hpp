@@ -1,0 +1,60 @@
+// Helpers shared by the single-pass primal-dual kernels (nsol_pd.hip,
+// nsol_pd2.hip).
+#pragma once
+
+#include "nsol_common.hpp"
+
+namespace nsol {
+
+template <typename T, int V>
+struct Pack {
+  typedef T type __attribute__((ext_vector_type(V)));
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void ldv(const T *p, T (&v)[V]) {
+  if constexpr (V == 1) {
+    v[0] = *p;
+  } else {
+    typedef typename Pack<T, V>::type P;
+    const P t = *reinterpret_cast<const P *>(p);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = t[k];
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void stv(T *p, const T (&v)[V]) {
+  if constexpr (V == 1) {
+    *p = v[0];
+  } else {
+    typedef typename Pack<T, V>::type P;
+    P t;
+#pragma unroll
+    for (int k = 0; k < V; ++k) t[k] = v[k];
+    *reinterpret_cast<P *>(p) = t;
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void zero(T (&v)[V]) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) v[k] = T(0);
+}
+
+template <typename T>
+struct PdScalars {
+  T sigma, hden, tau, tl, one_plus_tl, theta;
+  int huber, l1, has_p;
+};
+
+// p_new = clamp((p_old + sigma * (hi*w + lo*(-w))) / hden)
+template <typename T>
+__device__ __forceinline__ T dual_update(T p_old, T hi, T lo, T w,
+                                         const PdScalars<T> &S) {
+  T q = p_old + S.sigma * (hi * w + lo * (-w));
+  if (S.huber) q = q / S.hden;
+  return dual_clamp(q);
+}
+
+}  // namespace nsol

@@ -265,17 +265,41 @@ def pd_fused_iter(xbar_in, xbar_out, x, bt, p_in, p_out, shape, w, sigma,
         "nsol_pd_fused_iter")
 
 
+def pd_fused2_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
+                   sigma2, hden2, tau2, tl2, theta2, flags):
+    """Two iterations in one pass; returns False if the kernel does not apply
+    to this problem (nothing was launched)."""
+    ndim, nz, ny, nx = dims3(shape)
+    arr = [np.ascontiguousarray(a, dtype=np.float64)
+           for a in (sigma2, hden2, tau2, tl2, theta2)]
+    rc = _fn("pd_fused2_iter", x_in)(
+        _p(xbar_in), _p(xbar_out), _p(x_in), _p(x_out), _p(bt), _p(p_in),
+        _p(p_out), ndim, nz, ny, nx, w[0], w[1], w[2], arr[0].ctypes.data,
+        arr[1].ctypes.data, arr[2].ctypes.data, arr[3].ctypes.data,
+        arr[4].ctypes.data, int(flags), stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_pd_fused2_iter")
+    return True
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
-           p_is_zero, gamma_huber, flags):
+           p_is_zero, gamma_huber, flags, x_alt=None):
+    """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that
+    holds the final state.  x holds the final primal iterate."""
+    import ctypes
     ndim, nz, ny, nx = dims3(shape)
     sigma = np.ascontiguousarray(sigma, dtype=np.float64)
     tau = np.ascontiguousarray(tau, dtype=np.float64)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
+    slot = ctypes.c_int(0)
     _lib.check(_fn("pd_run", x)(
-        _p(xbar0), _p(xbar1), _p(x), _p(bt), _p(p0), _p(p1), ndim, nz, ny, nx,
-        w[0], w[1], w[2], float(lmbda), sigma.ctypes.data, tau.ctypes.data,
-        theta.ctypes.data, int(sigma.size), int(bool(p_is_zero)),
-        float(gamma_huber), int(flags), stream_ptr()), "nsol_pd_run")
+        _p(xbar0), _p(xbar1), _p(x), _p(x_alt), _p(bt), _p(p0), _p(p1), ndim,
+        nz, ny, nx, w[0], w[1], w[2], float(lmbda), sigma.ctypes.data,
+        tau.ctypes.data, theta.ctypes.data, int(sigma.size),
+        int(bool(p_is_zero)), float(gamma_huber), int(flags),
+        ctypes.addressof(slot), stream_ptr()), "nsol_pd_run")
+    return int(slot.value)
 
 
 # ----------------------------------------------------------------- ADMM ----

@@ -172,9 +172,11 @@ class PrimalDualSolver(Solver):
              for _ in range(2)]
         bt = scaled_data_on_device(plan["data"], plan["data_scale"], x)
         if self._observer is None and not self._verbose:
+            # scratch for the two-iterations-per-pass kernel (x ping-pong)
+            x_alt = torch.empty_like(x) if self._iterations > 1 else None
             ops.pd_run(xbar[0], xbar[1], x, bt, p[0], p[1], plan["shape"],
                        plan["w"], lmbda, sig, ta, th, True, plan["gamma"],
-                       plan["flags"])
+                       plan["flags"], x_alt=x_alt)
             self._x = x
             return
         for i in range(self._iterations):      # observed / verbose: stepwise

@@ -480,6 +480,70 @@ def test_x_scale_invariance(nsol, golden):
         assert np.linalg.norm(s1.get_x() - xs * s2.get_x()) < 1e-7
 
 
+# ------------------------------------------- two iterations per pass (TB2)
+def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
+                two_pass=0):
+    import torch
+    from nsol_amd import ops, _lib
+    from nsol_amd.primal_dual_solver import step_schedule
+    n = int(np.prod(shape))
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    bt = torch.rand(n, device="cuda", dtype=td, generator=gen)
+    x = bt.clone()
+    xb = [bt.clone(), torch.empty_like(bt)]
+    p = [torch.empty(3 * n, device="cuda", dtype=td) for _ in range(2)]
+    sig, ta, th = step_schedule("ALG2", 12.0, 1 / 0.05, iters)
+    _lib.set_param("pd2_enable", enable2)
+    _lib.set_param("pd2_zchunk", zchunk2)
+    _lib.set_param("pd_two_pass", two_pass)
+    try:
+        slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape,
+                          (1.0, 0.5, 2.0), 20.0, sig, ta, th, True, 0.05,
+                          flags, x_alt=torch.empty_like(x))
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_param("pd2_enable", 1)
+        _lib.set_param("pd2_zchunk", 0)
+        _lib.set_param("pd_two_pass", 0)
+    return x, xb[slot], p[slot], bt
+
+
+@pytest.mark.parametrize("shape,dtype", [
+    ((20, 30, 256), np.float32), ((17, 9, 512), np.float32),
+    ((9, 70, 264), np.float32), ((33, 20, 768), np.float32),
+    ((8, 8, 1280), np.float32), ((21, 13, 130), np.float64),
+    ((10, 37, 256), np.float64), ((12, 11, 600), np.float64)])
+@pytest.mark.parametrize("iters", [2, 5])
+def test_two_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters):
+    """Temporal blocking must not change a single bit: overlapping footprints,
+    z-chunk seams (forced chunk of 4 planes), several x tiles, odd iteration
+    counts (pair + single), Huber + l1 flags."""
+    import torch
+    from nsol_amd import ops
+    flags = ops.PD_REG_HUBER | ops.PD_DATA_L1
+    ref = _run_pd_raw(shape, dtype, iters, flags, enable2=0)
+    for zc in (0, 4):
+        got = _run_pd_raw(shape, dtype, iters, flags, enable2=1, zchunk2=zc)
+        for a, b in zip(ref[:3], got[:3]):
+            assert torch.equal(a, b), (shape, zc)
+
+
+def test_two_iterations_per_pass_vs_oracle(nsol):
+    from oracle import nsol_oracle as orc
+    shape = (12, 21, 256)
+    rng = np.random.default_rng(3)
+    obs = 50.0 + 30.0 * rng.standard_normal(shape)
+    ref = orc.primal_dual_denoise(obs.flatten(), shape, "TV", "L2", 0.05, 8,
+                                  16.0, "ALG2")
+    s = _pd_solver(obs, "TV", "L2", 0.05, 8, 16.0, "ALG2", np.float64)
+    s.run()
+    assert rel_l2(s.get_x(), ref) < F64_TOL
+    s = _pd_solver(obs, "TV", "L2", 0.05, 8, 16.0, "ALG2", np.float32)
+    s.run()
+    assert rel_l2(s.get_x(), ref) < F32_TOL
+
+
 # --------------------------------------------------- full-size properties
 def test_full_size_512_properties(nsol):
     """BASELINE size (512^3 fp32): adjointness <Kx,p> = <x,K^T p> and
@@ -497,23 +561,16 @@ def test_full_size_512_properties(nsol):
     rhs = ops.dot(x, ops.grad_adj(p, shape, w))
     assert abs(lhs - rhs) / abs(lhs) < 1e-6
     del p
-    bt = torch.rand(n ** 3, device="cuda", dtype=torch.float32, generator=gen)
-    sig = np.array([0.25, 0.3, 0.35]); ta = np.array([0.25, 0.2, 0.18])
-    th = np.array([0.9, 0.8, 0.7])
-    outs = []
-    for two_pass in (0, 1):
-        _lib.set_param("pd_two_pass", two_pass)
-        try:
-            xx = x.clone()
-            xb0, xb1 = x.clone(), torch.empty_like(x)
-            p0 = torch.empty(3 * n ** 3, device="cuda", dtype=torch.float32)
-            p1 = torch.empty_like(p0)
-            ops.pd_run(xb0, xb1, xx, bt, p0, p1, shape, w, 30.0, sig, ta, th,
-                       True, 0.05, ops.PD_REG_HUBER | ops.PD_DATA_L2)
-            torch.cuda.synchronize()
-            outs.append((xx, xb1.clone(), p1.clone()))
-            del xb0, xb1, p0, p1
-        finally:
-            _lib.set_param("pd_two_pass", 0)
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    del x
+    torch.cuda.empty_cache()
+    from nsol_amd import ops as _ops
+    flags = _ops.PD_REG_HUBER | _ops.PD_DATA_L2
+    a = _run_pd_raw(shape, np.float32, 5, flags, enable2=1)      # 2 + 2 + 1
+    b = _run_pd_raw(shape, np.float32, 5, flags, enable2=0)      # 5 x 1
+    for u, v in zip(a[:3], b[:3]):
+        assert torch.equal(u, v)
+    del a
+    torch.cuda.empty_cache()
+    c = _run_pd_raw(shape, np.float32, 5, flags, enable2=0, two_pass=1)
+    for u, v in zip(b[:3], c[:3]):
+        assert torch.equal(u, v)

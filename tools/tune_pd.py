@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--zchunk", default="0,8,16,32,64,128")
     ap.add_argument("--two-pass", action="store_true")
     ap.add_argument("--xcd", default="0,1")
+    ap.add_argument("--pd2", default="", help="pd2 zchunk list, e.g. 0,16,32")
+    ap.add_argument("--pd2-variant", default="0")
     args = ap.parse_args()
     n = args.size
     shape = (n, n, n)
@@ -39,18 +41,28 @@ def main():
         args.ry.split(","), args.zchunk.split(","), args.xcd.split(","))]
     if args.two_pass:
         variants.append((2, 0, 1, 0))
+    for var in [int(t) for t in args.pd2_variant.split(",")]:
+        for z in [int(t) for t in args.pd2.split(",") if t != ""]:
+            variants.append(("pd2", z, 0, var))
+    x_alt = torch.empty_like(x)
     times = {v: [] for v in variants}
     for rnd in range(args.rounds + 1):
         for v in variants:
-            _lib.set_param("pd_ry", v[0])
-            _lib.set_param("pd_zchunk", v[1])
+            if v[0] == "pd2":
+                _lib.set_param("pd2_enable", 1)
+                _lib.set_param("pd2_zchunk", v[1])
+                _lib.set_param("pd2_variant", v[3])
+            else:
+                _lib.set_param("pd2_enable", 0)
+                _lib.set_param("pd_ry", v[0])
+                _lib.set_param("pd_zchunk", v[1])
             _lib.set_param("pd_two_pass", v[2])
             _lib.set_param("pd_xcd_map", v[3])
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, (1., 1., 1.),
-                       33.0, sig, ta, th, False, 0.05, 0)
+                       33.0, sig, ta, th, False, 0.05, 0, x_alt=x_alt)
             e1.record()
             torch.cuda.synchronize()
             if rnd > 0:
