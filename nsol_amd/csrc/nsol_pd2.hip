@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
     const T *__restrict__ x_in, T *__restrict__ x_out,
     const T *__restrict__ bt, const T *__restrict__ p_in,
     T *__restrict__ p_out, Geom<T> G, PdScalars<T> S1, PdScalars<T> S2, int ntx,
-    int nty, int zchunk) {
+    int nty, int zchunk, int slab) {
   constexpr int NW = WX * WY;
   constexpr int TXB = WX * 64 * VEC;   // footprint in x
   constexpr int TYV = WY * RY - 2;     // rows with valid second-iteration output
@@ -61,11 +61,26 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
   const int wave = threadIdx.x >> 6;
   const int wxi = wave % WX;
   const int wyi = wave / WX;
-  int bid = blockIdx.x;
-  const int tx = bid % ntx;
-  bid /= ntx;
-  const int ty = bid % nty;
-  const int zc = bid / nty;
+  // Block -> footprint map.  blockIdx % 8 names the XCD (shared L2) under the
+  // round-robin dispatch; with slab > 0 each XCD walks `slab` consecutive
+  // y-tiles, so the rows that overlapping footprints both read meet in one L2.
+  // The whole workgroup takes the same branch (no barrier is skipped).
+  int tx, ty, zc;
+  if (slab > 0) {
+    const int xcd = blockIdx.x & 7;
+    int j = blockIdx.x >> 3;
+    tx = j % ntx;
+    j /= ntx;
+    ty = xcd * slab + j % slab;
+    zc = j / slab;
+    if (ty >= nty) return;
+  } else {
+    int bid = blockIdx.x;
+    tx = bid % ntx;
+    bid /= ntx;
+    ty = bid % nty;
+    zc = bid / nty;
+  }
 
   // ---- geometry of this lane
   const bool single_x = (ntx == 1);
@@ -345,6 +360,7 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
 struct Tuning {
   int zchunk = 0;
   int enable = 1;
+  int xcd_map = 1;
   int variant = 0;   // 0 = one row per lane, (WX x 8) waves [default: 114 VGPRs,
                      //     4 waves/SIMD, measured 0.79 ms/iteration at 512^3];
                      // 1 = two rows per lane, (WX x 4) waves [203 VGPRs, 0.98 ms]
@@ -400,11 +416,17 @@ int launch2(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
   if (zchunk <= 0) zchunk = pick_zchunk(G.nz, ntx * nty, WX * WY >= 16 ? 1 : 2);
   if (zchunk > G.nz) zchunk = G.nz;
   const int64_t nzc = (G.nz + zchunk - 1) / zchunk;
-  const int64_t blocks = ntx * nty * nzc;
+  int64_t blocks = ntx * nty * nzc;
+  int64_t slab = 0;
+  if (g_tune2.xcd_map && nty >= 16) {
+    slab = (nty + 7) / 8;
+    blocks = 8 * slab * ntx * nzc;
+  }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
   hipLaunchKernelGGL((k_pd_fused2<T, VEC, WX, WY, RY, WPE>), dim3((unsigned)blocks),
                      dim3(WX * WY * 64), 0, st, xbar_in, xbar_out, x_in, x_out, bt,
-                     p_in, p_out, G, S1, S2, (int)ntx, (int)nty, (int)zchunk);
+                     p_in, p_out, G, S1, S2, (int)ntx, (int)nty, (int)zchunk,
+                     (int)slab);
   return launch_status();
 }
 
@@ -456,6 +478,7 @@ int nsol_hip_set_param_pd2(const char *name, int value) {
   if (!strcmp(name, "pd2_zchunk")) nsol_pd2::g_tune2.zchunk = value;
   else if (!strcmp(name, "pd2_enable")) nsol_pd2::g_tune2.enable = value;
   else if (!strcmp(name, "pd2_variant")) nsol_pd2::g_tune2.variant = value;
+  else if (!strcmp(name, "pd2_xcd_map")) nsol_pd2::g_tune2.xcd_map = value;
   else return NSOL_EINVAL;
   return 0;
 }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--xcd", default="0,1")
     ap.add_argument("--pd2", default="", help="pd2 zchunk list, e.g. 0,16,32")
     ap.add_argument("--pd2-variant", default="0")
+    ap.add_argument("--pd2-xcd", default="1")
     args = ap.parse_args()
     n = args.size
     shape = (n, n, n)
@@ -43,7 +44,8 @@ def main():
         variants.append((2, 0, 1, 0))
     for var in [int(t) for t in args.pd2_variant.split(",")]:
         for z in [int(t) for t in args.pd2.split(",") if t != ""]:
-            variants.append(("pd2", z, 0, var))
+            for m in [int(t) for t in args.pd2_xcd.split(",")]:
+                variants.append(("pd2", z, m, var))
     x_alt = torch.empty_like(x)
     times = {v: [] for v in variants}
     for rnd in range(args.rounds + 1):
@@ -52,11 +54,12 @@ def main():
                 _lib.set_param("pd2_enable", 1)
                 _lib.set_param("pd2_zchunk", v[1])
                 _lib.set_param("pd2_variant", v[3])
+                _lib.set_param("pd2_xcd_map", v[2])
             else:
                 _lib.set_param("pd2_enable", 0)
                 _lib.set_param("pd_ry", v[0])
                 _lib.set_param("pd_zchunk", v[1])
-            _lib.set_param("pd_two_pass", v[2])
+            _lib.set_param("pd_two_pass", 0 if v[0] == "pd2" else v[2])
             _lib.set_param("pd_xcd_map", v[3])
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
