@@ -69,9 +69,13 @@ template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return 
 // x / max(1, |x|)   (proximal_operators.py:139-140), without the division:
 // |x| <= 1 -> x / 1 = x exactly;  |x| > 1 -> x / |x| = +-1 exactly in IEEE
 // arithmetic, so the result is bit-identical to the quotient.
-template <typename T> __device__ __forceinline__ T dual_clamp(T q) {
-  const T a = t_abs(q);
-  return (a > T(1)) ? (q > T(0) ? T(1) : T(-1)) : q;
+// i.e. the median of (q, -1, 1): one v_med3_f32 in float.
+template <typename T> __device__ __forceinline__ T dual_clamp(T q);
+template <> __device__ __forceinline__ float dual_clamp<float>(float q) {
+  return __builtin_amdgcn_fmed3f(q, -1.0f, 1.0f);
+}
+template <> __device__ __forceinline__ double dual_clamp<double>(double q) {
+  return fmin(fmax(q, -1.0), 1.0);
 }
 
 // np.sign
@@ -80,13 +84,29 @@ template <typename T> __device__ __forceinline__ T t_sign(T v) {
 }
 
 // prox of the data term (proximal_operators.py:95-98, 117-120)
+template <typename T> __device__ __forceinline__ T prox_ell1(T u, T bt, T tl) {
+  const T d = u - bt;
+  return bt + t_max(t_abs(d) - tl, T(0)) * t_sign(d);
+}
+template <typename T>
+__device__ __forceinline__ T prox_ell2(T u, T bt, T tl, T one_plus_tl) {
+  return (u + tl * bt) / one_plus_tl;
+}
+
+// keeps `v` opaque so that the compiler cannot speculate the (expensive) code
+// of a wave-uniform branch and select afterwards
+template <typename T> __device__ __forceinline__ void pin(T &v) {
+  asm volatile("" : "+v"(v));
+}
+
 template <typename T>
 __device__ __forceinline__ T prox_data(T u, T bt, T tl, T one_plus_tl, bool l1) {
   if (l1) {
-    T d = u - bt;
-    return bt + t_max(t_abs(d) - tl, T(0)) * t_sign(d);
+    pin(u);
+    return prox_ell1(u, bt, tl);
   }
-  return (u + tl * bt) / one_plus_tl;
+  pin(u);
+  return prox_ell2(u, bt, tl, one_plus_tl);
 }
 
 }  // namespace nsol

@@ -44,7 +44,7 @@ struct WaveEdges {
   T pad[(16 / sizeof(T)) * 2 - (3 * RY) % ((16 / sizeof(T)) * 2) ];
 };
 
-template <typename T, int VEC, int WX, int WY, int RY, int WPE>
+template <typename T, int VEC, int WX, int WY, int RY, int WPE, bool HUBER, bool L1>
 __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out,
     const T *__restrict__ x_in, T *__restrict__ x_out,
@@ -101,6 +101,16 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
     rin[r] = xin && y >= 0 && y < G.ny;
     rvalid[r] = rin[r] && xvalid && y >= yv_lo && y < yv_hi;
   }
+  // Step sizes masked to zero outside the volume: a voxel there then gets
+  // p' = clamp(0 + 0*g) = 0 and x' = prox(0 - 0*kt) = 0 exactly (K and K^T pad
+  // with zeros) without per-value selects; inside the volume nothing changes.
+  T sig1[RY], sig2[RY], tau1[RY];
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    sig1[r] = rin[r] ? S1.sigma : T(0);
+    sig2[r] = rin[r] ? S2.sigma : T(0);
+    tau1[r] = rin[r] ? S1.tau : T(0);
+  }
   const int64_t zbeg = (int64_t)zc * zchunk;
   int64_t zend = zbeg + zchunk;
   if (zend > G.nz) zend = G.nz;
@@ -147,7 +157,8 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
         if (S1.has_p) ldv<T, VEC>(pin_z + off - G.sz + r * G.sy, pm);
 #pragma unroll
         for (int k = 0; k < VEC; ++k)
-          p1z[r][k] = dual_update(pm[k], xc[r][k], xm[k], G.wz, S1);
+          p1z[r][k] = dual_update_s<HUBER>(pm[k], xc[r][k], xm[k], G.wz, S1.sigma,
+                                           S1.hden);
       }
     }
   }
@@ -208,9 +219,9 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
         for (int k = 0; k < VEC; ++k) {
           const T hx = (k + 1 < VEC) ? xc[r][(k + 1) % VEC] : nb;
           const T hy = (r + 1 < RY) ? xc[(r + 1) % RY][k] : xdown[k];
-          p1x[r][k] = rin[r] ? dual_update(pxo[r][k], hx, xc[r][k], G.wx, S1) : T(0);
-          p1y[r][k] = rin[r] ? dual_update(pyo[r][k], hy, xc[r][k], G.wy, S1) : T(0);
-          p1zn[r][k] = rin[r] ? dual_update(pzo[r][k], xn[r][k], xc[r][k], G.wz, S1) : T(0);
+          p1x[r][k] = dual_update_s<HUBER>(pxo[r][k], hx, xc[r][k], G.wx, sig1[r], S1.hden);
+          p1y[r][k] = dual_update_s<HUBER>(pyo[r][k], hy, xc[r][k], G.wy, sig1[r], S1.hden);
+          p1zn[r][k] = dual_update_s<HUBER>(pzo[r][k], xn[r][k], xc[r][k], G.wz, sig1[r], S1.hden);
         }
       }
       T pxl[RY], pyu[VEC];
@@ -219,12 +230,15 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
         pxl[r] = __shfl_up(p1x[r][VEC - 1], 1, kWave);
         if (lane == 0)
           pxl[r] = (has_left && rin[r])
-                       ? dual_update(pxleft[r], xc[r][0], xleft[r], G.wx, S1)
+                       ? dual_update_s<HUBER>(pxleft[r], xc[r][0], xleft[r], G.wx,
+                                              S1.sigma, S1.hden)
                        : T(0);
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k)
-        pyu[k] = has_up ? dual_update(pyup[k], xc[0][k], xup[k], G.wy, S1) : T(0);
+        pyu[k] = has_up ? dual_update_s<HUBER>(pyup[k], xc[0][k], xup[k], G.wy,
+                                               S1.sigma, S1.hden)
+                        : T(0);
       // primal update, kept in registers
 #pragma unroll
       for (int r = 0; r < RY; ++r)
@@ -235,10 +249,10 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
           T kt = p1x[r][k] * (-G.wx) + pl * G.wx;
           kt += p1y[r][k] * (-G.wy) + pu * G.wy;
           kt += p1zn[r][k] * (-G.wz) + p1z[r][k] * G.wz;
-          const T u = xv[r][k] - S1.tau * kt;
-          const T xnew = prox_data(u, btc[r][k], S1.tl, S1.one_plus_tl, S1.l1 != 0);
-          x1[r][k] = rin[r] ? xnew : T(0);
-          xb1[r][k] = rin[r] ? xnew + S1.theta * (xnew - xv[r][k]) : T(0);
+          const T u = xv[r][k] - tau1[r] * kt;
+          const T xnew = prox_data_s<L1>(u, btc[r][k], S1.tl, S1.one_plus_tl);
+          x1[r][k] = xnew;
+          xb1[r][k] = xnew + S1.theta * (xnew - xv[r][k]);
         }
 #pragma unroll
       for (int r = 0; r < RY; ++r)
@@ -254,12 +268,12 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
         T p2z[VEC], x2[VEC], xb2[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          p2z[k] = rin[r] ? dual_update(p1z[r][k], xb1[r][k], c_xb1[r][k], G.wz, S2)
-                          : T(0);
+          p2z[k] = dual_update_s<HUBER>(p1z[r][k], xb1[r][k], c_xb1[r][k], G.wz,
+                                        sig2[r], S2.hden);
           T kt = c_kt[r][k];
           kt += p2z[k] * (-G.wz) + p2z_prev[r][k] * G.wz;
           const T u = c_x1[r][k] - S2.tau * kt;
-          x2[k] = prox_data(u, c_bt[r][k], S2.tl, S2.one_plus_tl, S2.l1 != 0);
+          x2[k] = prox_data_s<L1>(u, c_bt[r][k], S2.tl, S2.one_plus_tl);
           xb2[k] = x2[k] + S2.theta * (x2[k] - c_x1[r][k]);
           p2z_prev[r][k] = p2z[k];
         }
@@ -306,8 +320,8 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
         for (int k = 0; k < VEC; ++k) {
           const T hx = (k + 1 < VEC) ? xb1[r][(k + 1) % VEC] : nb;
           const T hy = (r + 1 < RY) ? xb1[(r + 1) % RY][k] : below[k];
-          p2x[r][k] = rin[r] ? dual_update(p1x[r][k], hx, xb1[r][k], G.wx, S2) : T(0);
-          p2y[r][k] = rin[r] ? dual_update(p1y[r][k], hy, xb1[r][k], G.wy, S2) : T(0);
+          p2x[r][k] = dual_update_s<HUBER>(p1x[r][k], hx, xb1[r][k], G.wx, sig2[r], S2.hden);
+          p2y[r][k] = dual_update_s<HUBER>(p1y[r][k], hy, xb1[r][k], G.wy, sig2[r], S2.hden);
         }
       }
       T p2xl[RY], p2yu[VEC];
@@ -317,14 +331,16 @@ __global__ __launch_bounds__(WX *WY * 64, WPE) void k_pd_fused2(
         if (lane == 0) {
           p2xl[r] = T(0);
           if (nb_left && dom_left && rin[r])
-            p2xl[r] = dual_update(lds[s & 1][wave - 1].col_r_px[r], xb1[r][0],
-                                  lds[s & 1][wave - 1].col_r[r], G.wx, S2);
+            p2xl[r] = dual_update_s<HUBER>(lds[s & 1][wave - 1].col_r_px[r],
+                                           xb1[r][0], lds[s & 1][wave - 1].col_r[r],
+                                           G.wx, S2.sigma, S2.hden);
         }
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k)
         p2yu[k] = (nb_up && dom_up && xin)
-                      ? dual_update(above_py[k], xb1[0][k], above[k], G.wy, S2)
+                      ? dual_update_s<HUBER>(above_py[k], xb1[0][k], above[k], G.wy,
+                                             S2.sigma, S2.hden)
                       : T(0);
 #pragma unroll
       for (int r = 0; r < RY; ++r) {
@@ -404,8 +420,8 @@ inline bool al16(const T *a) {
   return (reinterpret_cast<uintptr_t>(a) & 15u) == 0;
 }
 
-template <typename T, int VEC, int WX, int WY, int RY, int WPE>
-int launch2(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
+template <typename T, int VEC, int WX, int WY, int RY, int WPE, bool HUBER, bool L1>
+int launch2_f(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
             const T *p_in, T *p_out, const Geom<T> &G, const PdScalars<T> &S1,
             const PdScalars<T> &S2, hipStream_t st) {
   constexpr int TXB = WX * 64 * VEC;
@@ -423,11 +439,24 @@ int launch2(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
     blocks = 8 * slab * ntx * nzc;
   }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
-  hipLaunchKernelGGL((k_pd_fused2<T, VEC, WX, WY, RY, WPE>), dim3((unsigned)blocks),
+  hipLaunchKernelGGL((k_pd_fused2<T, VEC, WX, WY, RY, WPE, HUBER, L1>),
+                     dim3((unsigned)blocks),
                      dim3(WX * WY * 64), 0, st, xbar_in, xbar_out, x_in, x_out, bt,
                      p_in, p_out, G, S1, S2, (int)ntx, (int)nty, (int)zchunk,
                      (int)slab);
   return launch_status();
+}
+
+template <typename T, int VEC, int WX, int WY, int RY, int WPE>
+int launch2(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
+            const T *p_in, T *p_out, const Geom<T> &G, const PdScalars<T> &S1,
+            const PdScalars<T> &S2, hipStream_t st) {
+#define NSOL_F(H, L)                                                            \
+  launch2_f<T, VEC, WX, WY, RY, WPE, H, L>(xbar_in, xbar_out, x_in, x_out, bt,   \
+                                           p_in, p_out, G, S1, S2, st)
+  if (S1.huber) return S1.l1 ? NSOL_F(true, true) : NSOL_F(true, false);
+  return S1.l1 ? NSOL_F(false, true) : NSOL_F(false, false);
+#undef NSOL_F
 }
 
 // returns -2 if the two-iteration kernel does not apply to this problem

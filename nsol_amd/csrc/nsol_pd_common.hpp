@@ -53,8 +53,27 @@ template <typename T>
 __device__ __forceinline__ T dual_update(T p_old, T hi, T lo, T w,
                                          const PdScalars<T> &S) {
   T q = p_old + S.sigma * (hi * w + lo * (-w));
-  if (S.huber) q = q / S.hden;
+  if (S.huber) {
+    pin(q);            // a real (uniform) branch, not a speculated division
+    q = q / S.hden;
+  }
   return dual_clamp(q);
+}
+
+// compile-time flags and an explicit step size (sigma may be masked to zero
+// for voxels outside the volume, which makes the new dual exactly zero)
+template <bool HUBER, typename T>
+__device__ __forceinline__ T dual_update_s(T p_old, T hi, T lo, T w, T sigma,
+                                           T hden) {
+  T q = p_old + sigma * (hi * w + lo * (-w));
+  if constexpr (HUBER) q = q / hden;
+  return dual_clamp(q);
+}
+
+template <bool L1, typename T>
+__device__ __forceinline__ T prox_data_s(T u, T bt, T tl, T one_plus_tl) {
+  if constexpr (L1) return prox_ell1(u, bt, tl);
+  else return prox_ell2(u, bt, tl, one_plus_tl);
 }
 
 }  // namespace nsol

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--nx", type=int, default=0, help="x extent (default size)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--ry", default="1,2,4")
     ap.add_argument("--zchunk", default="0,8,16,32,64,128")
@@ -28,8 +29,8 @@ def main():
     ap.add_argument("--pd2-xcd", default="1")
     args = ap.parse_args()
     n = args.size
-    shape = (n, n, n)
-    nv = n ** 3
+    shape = (n, n, args.nx or n)
+    nv = n * n * (args.nx or n)
     dev = torch.device("cuda")
     bt = torch.rand(nv, device=dev)
     x = bt.clone()
