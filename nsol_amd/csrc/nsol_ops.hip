@@ -547,7 +547,7 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
   int nsol_prox_ell2_##SUF(T *out, const T *x, const T *bt, double tau,          \
                            int64_t n, void *s) {                                 \
     if (n > 0 && (!out || !x || !bt)) return NSOL_EINVAL;                        \
-    const T tl = (T)tau, opt = (T)(1.0 + tau);                                   \
+    const T tl = (T)tau, opt = prox_den<T>(tau);                                   \
     return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
       out[i] = prox_data<T>(x[i], bt[i], tl, opt, false);                        \
     });                                                                          \

@@ -394,7 +394,7 @@ PdScalars<T> make_scalars(double sigma, double hden, double tau, double tl,
                           double theta, int flags, bool has_p) {
   PdScalars<T> S;
   S.sigma = (T)sigma; S.hden = (T)hden; S.tau = (T)tau; S.tl = (T)tl;
-  S.one_plus_tl = (T)(1.0 + tl); S.theta = (T)theta;
+  S.one_plus_tl = prox_den<T>(tl); S.theta = (T)theta;
   S.huber = (flags & NSOL_PD_REG_HUBER) ? 1 : 0;
   S.l1 = (flags & NSOL_PD_DATA_L1) ? 1 : 0;
   S.has_p = has_p ? 1 : 0;
@@ -452,7 +452,7 @@ int primal_step_impl(const T *p, T *x, T *xbar, const T *bt, int ndim,
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   hipLaunchKernelGGL(k_primal_step<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
                      as_stream(stream), p, x, xbar, bt, G, (T)tau, (T)tl,
-                     (T)(1.0 + tl), (T)theta, (flags & NSOL_PD_DATA_L1) != 0);
+                     prox_den<T>(tl), (T)theta, (flags & NSOL_PD_DATA_L1) != 0);
   return launch_status();
 }
 

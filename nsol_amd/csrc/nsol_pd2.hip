@@ -480,7 +480,7 @@ int fused2_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
   PdScalars<T> S[2];
   for (int i = 0; i < 2; ++i) {
     S[i].sigma = (T)sigma[i]; S[i].hden = (T)hden[i]; S[i].tau = (T)tau[i];
-    S[i].tl = (T)tl[i]; S[i].one_plus_tl = (T)(1.0 + tl[i]);
+    S[i].tl = (T)tl[i]; S[i].one_plus_tl = prox_den<T>(tl[i]);
     S[i].theta = (T)theta[i];
     S[i].huber = (flags & NSOL_PD_REG_HUBER) ? 1 : 0;
     S[i].l1 = (flags & NSOL_PD_DATA_L1) ? 1 : 0;
