@@ -27,7 +27,7 @@ namespace {
 
 struct PdTuning {
   int zchunk = 0;   // 0 = auto
-  int ry = 2;       // rows per lane (1, 2 or 4)
+  int ry = 0;       // rows per lane (1, 2 or 4); 0 = auto
   int force_two_pass = 0;
   int xcd_map = 1;  // 0 = plain block order, 1 = XCD-aware slabs
 };
@@ -342,10 +342,12 @@ int launch_fused_t(const T *xbar_in, T *xbar_out, T *x, const T *bt,
   const int64_t nty = (G.ny + TY - 1) / TY;
   int64_t zchunk = g_tune.zchunk;
   if (zchunk <= 0) {
-    // enough workgroups to fill 256 CUs several times, chunks >= 16 planes
+    // enough workgroups to fill 256 CUs several times; cache-resident volumes
+    // get chunks as short as 2 planes (the extra plane per chunk is an L2 hit
+    // there and 8 workgroups would leave the chip idle)
     const int64_t want = (4096 + ntx * nty - 1) / (ntx * nty);
     zchunk = (G.nz + want - 1) / want;
-    if (zchunk < 16) zchunk = 16;
+    if (zchunk < 2) zchunk = 2;
   }
   if (zchunk > G.nz) zchunk = G.nz;
   const int64_t nzc = (G.nz + zchunk - 1) / zchunk;
@@ -377,7 +379,14 @@ template <typename T, int VEC, int LX>
 int launch_fused_ry(const T *xbar_in, T *xbar_out, T *x, const T *bt,
                     const T *p_in, T *p_out, const Geom<T> &G,
                     const PdScalars<T> &S, hipStream_t st) {
-  switch (g_tune.ry) {
+  int ry = g_tune.ry;
+  if (ry == 0) {
+    // two rows per lane unless that leaves fewer than ~2 workgroups per CU
+    constexpr int TY2 = (kBlock / kWave) * (kWave / LX) * 2;
+    const int64_t tiles = ((G.nx + LX * VEC - 1) / (LX * VEC)) * ((G.ny + TY2 - 1) / TY2);
+    ry = (tiles * ((G.nz + 1) / 2) < 512) ? 1 : 2;
+  }
+  switch (ry) {
     case 1: return launch_fused_nd<T, VEC, LX, 1>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
     case 4: return launch_fused_nd<T, VEC, LX, 4>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
     default: return launch_fused_nd<T, VEC, LX, 2>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);

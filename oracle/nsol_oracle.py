@@ -524,10 +524,41 @@ def tikhonov(A, A_adj, B, B_adj, b, x0, alpha=0.01, b_reg=0.,
             x = np.clip(x, bounds[0], bounds[1])
         return x * x_scale
 
+    import scipy.optimize
+    import scipy.sparse.linalg
+    if minimizer in ("lsq_linear", "least_squares"):
+        # SciPy drivers over the augmented operator, called as the reference
+        # does (tikhonov_linear_solver.py:160-195)
+        if minimizer == "lsq_linear" and data_loss != "linear":
+            raise ValueError(
+                "lsq_linear solver cannot be used with non-linear data loss")
+        if alpha > EPS:
+            sa = np.sqrt(alpha)
+            nb = b.size
+            mv = lambda x: np.concatenate((A(x), sa * B(x)))
+            rmv = lambda y: A_adj(y[:nb]) + sa * B_adj(y[nb:])
+            rhs = np.zeros(mv(x0).size)
+            rhs[:nb] = b
+            rhs[nb:] = sa * b_reg
+        else:
+            mv, rmv, rhs = A, A_adj, b
+        op = scipy.sparse.linalg.LinearOperator(
+            shape=(rhs.size, x0.size), matvec=mv, rmatvec=rmv)
+        if minimizer == "lsq_linear":
+            x = scipy.optimize.lsq_linear(
+                op, rhs, max_iter=iter_max, lsq_solver='lsmr',
+                lsmr_tol='auto', bounds=bounds).x
+        else:
+            x = scipy.optimize.least_squares(
+                fun=lambda x: op * x - rhs, jac=lambda x: op,
+                jac_sparsity=lambda x: op, x0=x0, tr_solver='lsmr',
+                bounds=bounds, loss=data_loss, f_scale=data_loss_scale,
+                max_nfev=iter_max).x
+        return x * x_scale
+
     # robust-loss branch: scipy.optimize.minimize (third-party, the reference
     # calls it the same way, tikhonov_linear_solver.py:197-220).  b_reg is
     # ignored by the reference here (regulariser 1/2||Bx||^2).
-    import scipy.optimize
 
     def cost_data(x):
         r = A(x) - b

@@ -204,6 +204,77 @@ def test_tikhonov_minimize_losses_match_reference(golden, lossname):
     assert rel_l2(out, g["tk1_lbfgsb_%s_2d" % lossname]) < 1e-9
 
 
+def _extra_ops():
+    shape = (14, 18)
+    D, Da, A, Aa = orc.flat_operators(shape, np.array([1.0, 2.0]),
+                                      np.diag([1.5, 1.5]))
+    return A, Aa, D, Da
+
+
+EXTRA = [("tk_lsq_linear", dict(minimizer="lsq_linear")),
+         ("tk_least_squares_linear", dict(minimizer="least_squares")),
+         ("tk_least_squares_huber", dict(minimizer="least_squares",
+                                         data_loss="huber",
+                                         data_loss_scale=0.05)),
+         ("tk_tnc_soft_l1", dict(minimizer="TNC", data_loss="soft_l1",
+                                 data_loss_scale=0.1)),
+         ("tk_lsmr_breg", dict(b_reg="vector")),
+         ("tk_lsmr_nobounds", dict(bounds=None, x0_shift=-60.0))]
+
+
+@pytest.mark.parametrize("key,kw", EXTRA)
+def test_tikhonov_scipy_driver_branches(golden, key, kw):
+    g = golden("extra")
+    A, Aa, D, Da = _extra_ops()
+    y = g["y"]
+    kw = dict(kw)
+    if kw.get("b_reg") == "vector":
+        kw["b_reg"] = g["b_reg"]
+    x0 = y + kw.pop("x0_shift", 0.0)
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = orc.tikhonov(A, Aa, D, Da, y, x0, alpha=0.05,
+                               x_scale=float(y.max()), iter_max=8, **kw)
+    assert rel_l2(out, g[key]) < 1e-9
+
+
+def test_least_squares_huber_is_chaotic_under_1e13_perturbations(golden):
+    """Documents why the GPU test holds this branch to the oracle evaluated
+    with the separable blur rather than to the golden: the reference's own
+    result moves by ~2e-2 when A changes by ~6e-14."""
+    import warnings
+    g = golden("extra")
+    shape = (14, 18)
+    D, Da, A, Aa = _extra_ops()[2], _extra_ops()[3], _extra_ops()[0], None
+    f = orc.separable_factors(orc.gaussian_taps(
+        2, np.diag([1.5, 1.5]), np.array([1.0, 2.0])))
+
+    def A_sep(v):
+        v = orc.convolve_nd(v.reshape(shape), f[0].reshape(-1, 1), "wrap")
+        return orc.convolve_nd(v, f[1].reshape(1, -1), "wrap").reshape(-1)
+    y = g["y"]
+    assert np.max(np.abs(A_sep(y) - A(y))) < 1e-12
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = orc.tikhonov(A_sep, A_sep, D, Da, y, y, alpha=0.05,
+                           x_scale=float(y.max()), iter_max=8,
+                           minimizer="least_squares", data_loss="huber",
+                           data_loss_scale=0.05)
+    err = rel_l2(out, g["tk_least_squares_huber"])
+    assert 1e-6 < err < 5e-2
+
+
+def test_admm_with_vector_b_reg(golden):
+    g = golden("extra")
+    A, Aa, D, Da = _extra_ops()
+    y = g["y"]
+    out = orc.admm(A, Aa, D, Da, y, y, 2, b_reg=g["b_reg"], alpha=0.05,
+                   rho=0.5, iterations=4, iter_max=6, x_scale=float(y.max()))
+    assert rel_l2(out, g["admm_breg"]) < 1e-10
+
+
 def test_config1_and_config2_goldens(golden):
     g = golden("configs")
     lena = g["lena_noise_u8"].astype(np.float64)

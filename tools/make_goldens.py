@@ -58,6 +58,9 @@ def read_nifti_f64(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="all", choices=["all", "extra"],
+                    help="'extra' writes only tests/golden/extra.npz (own RNG "
+                         "seed, so the other fixtures stay byte-stable)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     sys.dont_write_bytecode = True
@@ -72,6 +75,10 @@ def main():
     import nsol.admm_linear_solver as ADMM
     import nsol.tikhonov_linear_solver as TK
     from nsol.proximal_operators import ProximalOperators as prox
+
+    if args.only == "extra":
+        make_extra(OUT, LO, TK, ADMM, PD, prox)
+        return
 
     rng = np.random.default_rng(20261003)
 
@@ -353,6 +360,54 @@ def main():
     for f in sorted(os.listdir(OUT)):
         print("  %-16s %8.1f KiB" % (f, os.path.getsize(
             os.path.join(OUT, f)) / 1024.0))
+
+
+def make_extra(out, LO, TK, ADMM, PD, prox):
+    """SciPy-driver branches of TikhonovLinearSolver (lsq_linear,
+    least_squares, another `minimize` method), non-zero b_reg, bounds=None."""
+    rng = np.random.default_rng(777)
+    g = {}
+    shape = (14, 18)
+    lo = LO.LinearOperators2D(spacing=np.array([1.0, 2.0]))
+    A, A_adj = lo.get_gaussian_blurring_operators(np.diag([1.5, 1.5]))
+    grad, grad_adj = lo.get_gradient_operators()
+    Z = grad(np.zeros(shape)).shape
+    A_ = lambda x: A(x.reshape(*shape)).flatten()
+    Aa_ = lambda x: A_adj(x.reshape(*shape)).flatten()
+    D_ = lambda x: grad(x.reshape(*shape)).flatten()
+    Da_ = lambda x: grad_adj(x.reshape(*Z)).flatten()
+    idx = np.indices(shape)
+    gt = 100.0 * ((idx[0] // 4 + idx[1] // 4) % 2) + 20.0
+    y = A_(gt.flatten()) + 2.0 * rng.standard_normal(gt.size)
+    breg = 0.5 * rng.standard_normal(2 * gt.size)
+    g["y"] = y
+    g["b_reg"] = breg
+    xs = float(y.max())
+
+    def tk(**kw):
+        base = dict(A=A_, A_adj=Aa_, B=D_, B_adj=Da_, b=y, x0=y, alpha=0.05,
+                    x_scale=xs, iter_max=8)
+        base.update(kw)
+        s = TK.TikhonovLinearSolver(**base)
+        s.run()
+        return s.get_x()
+
+    g["tk_lsq_linear"] = tk(minimizer="lsq_linear")
+    g["tk_least_squares_linear"] = tk(minimizer="least_squares")
+    g["tk_least_squares_huber"] = tk(minimizer="least_squares",
+                                     data_loss="huber", data_loss_scale=0.05)
+    g["tk_tnc_soft_l1"] = tk(minimizer="TNC", data_loss="soft_l1",
+                             data_loss_scale=0.1)
+    g["tk_lsmr_breg"] = tk(b_reg=breg)
+    g["tk_lsmr_nobounds"] = tk(bounds=None, x0=y - 60.0)
+    s = ADMM.ADMMLinearSolver(A=A_, A_adj=Aa_, b=y, B=D_, B_adj=Da_, x0=y,
+                              dimension=2, b_reg=breg, alpha=0.05, rho=0.5,
+                              iterations=4, iter_max=6, x_scale=xs)
+    s.run()
+    g["admm_breg"] = s.get_x()
+    np.savez_compressed(os.path.join(out, "extra.npz"), **g)
+    print("wrote extra.npz (%.1f KiB)" %
+          (os.path.getsize(os.path.join(out, "extra.npz")) / 1024.0))
 
 
 if __name__ == "__main__":
