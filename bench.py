@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--data", default="L2", choices=["L2", "L1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo only to rehearse N > 1 on a box with fewer "
+                         "GPUs than ranks (collectives then go through host "
+                         "memory)")
     args = ap.parse_args()
 
     import torch
@@ -99,10 +103,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(
-            "cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(
+                "cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    on_host = world > 1 and args.backend == "gloo"
 
     from nsol_amd import ops, _lib
     from nsol_amd.primal_dual_solver import step_schedule
@@ -167,7 +176,8 @@ def main():
     total_ms = ev.elapsed_ms(e0, e1)
     kernel_ms = total_ms / launches                    # avg launch duration
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64,
+                        device="cpu" if on_host else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
@@ -178,6 +188,8 @@ def main():
         dist.barrier()
         g0 = time.perf_counter()
         res = ops.scale(x, x_scale)
+        if on_host:
+            res = res.cpu()
         bucket = [torch.empty_like(res) for _ in range(world)] \
             if rank == 0 else None
         dist.gather(res, gather_list=bucket, dst=0)
