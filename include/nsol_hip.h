@@ -354,6 +354,17 @@ int nsol_lsmr_hx_update_f64(double *hbar, double *x, double *h,
                             double c_x, double c_h, double c_v, double *result,
                             double *ws, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * Pair statistics for the evaluation measures of similarity_measures.py:26-120
+ * (SSD, MAE, MSE, RMSE, PSNR, NCC).  result: device double[8] =
+ *   { sum (x-mx)(y-my), sum (x-mx)^2, sum (y-my)^2, sum |x-y|, sum (x-y)^2,
+ *     max y, sum x, sum y }.  ws: nsol_hip_reduce_ws_doubles() doubles.
+ * ---------------------------------------------------------------------- */
+int nsol_pair_stats_f32(const float *x, const float *y, int64_t n, double mx,
+                        double my, double *result, double *ws, void *stream);
+int nsol_pair_stats_f64(const double *x, const double *y, int64_t n, double mx,
+                        double my, double *result, double *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -359,6 +359,77 @@ __global__ __launch_bounds__(kBlock) void k_vector_norm_sum(
   block_store_partial(acc, ws);
 }
 
+// similarity_measures.py:26-120: all sums of one (x, x_ref) pair in one pass
+constexpr int kPairStats = 8;
+constexpr int kPairBlocks = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pair_stats(const T *__restrict__ x,
+                                                        const T *__restrict__ y,
+                                                        int64_t n, double mx,
+                                                        double my, double *ws) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double a[kPairStats] = {0, 0, 0, 0, 0, -1.7976931348623157e308, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    const double xv = (double)x[i], yv = (double)y[i];
+    const double dx = xv - mx, dy = yv - my, d = xv - yv;
+    a[0] += dx * dy; a[1] += dx * dx; a[2] += dy * dy;
+    a[3] += fabs(d); a[4] += d * d;
+    a[5] = fmax(a[5], yv);
+    a[6] += xv; a[7] += yv;
+  }
+  __shared__ double s[kPairStats][kBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < kPairStats; ++k) {
+    double v = a[k];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      const double o = __shfl_down(v, off, kWave);
+      v = (k == 5) ? fmax(v, o) : v + o;
+    }
+    if (lane == 0) s[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kPairStats) {
+    const int k = threadIdx.x;
+    double t = s[k][0];
+    for (int j = 1; j < kBlock / kWave; ++j)
+      t = (k == 5) ? fmax(t, s[k][j]) : t + s[k][j];
+    ws[(int64_t)k * kPairBlocks + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pair_final(const double *ws,
+                                                        int nparts,
+                                                        double *result) {
+  // one wave per statistic would do; keep it simple: thread k sums row k
+  if (threadIdx.x < kPairStats) {
+    const int k = threadIdx.x;
+    double t = ws[(int64_t)k * kPairBlocks];
+    for (int j = 1; j < nparts; ++j) {
+      const double v = ws[(int64_t)k * kPairBlocks + j];
+      t = (k == 5) ? fmax(t, v) : t + v;
+    }
+    result[k] = t;
+  }
+}
+
+template <typename T>
+int pair_stats_impl(const T *x, const T *y, int64_t n, double mx, double my,
+                    double *result, double *ws, void *stream) {
+  if (n < 1 || !x || !y || !result || !ws) return NSOL_EINVAL;
+  static_assert(kPairStats * kPairBlocks <= kReducePartials, "workspace");
+  int g = grid_for(n);
+  if (g > kPairBlocks) g = kPairBlocks;
+  hipLaunchKernelGGL(k_pair_stats<T>, dim3(g), dim3(kBlock), 0, as_stream(stream),
+                     x, y, n, mx, my, ws);
+  hipLaunchKernelGGL(k_pair_final, dim3(1), dim3(kBlock), 0, as_stream(stream),
+                     ws, g, result);
+  return launch_status();
+}
+
 // ------------------------------------------------------- typed front ends ----
 template <typename T>
 int loss_eval_impl(const T *f2, T *rho, T *drho, int64_t n, int loss,
@@ -586,6 +657,10 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
   int nsol_vector_norm_sum_##SUF(const T *t, int ndim, int64_t m, int mode,      \
                                  double gm, double *res, double *ws, void *s) {  \
     return vector_norm_sum_impl<T>(t, ndim, m, mode, gm, res, ws, s);            \
+  }                                                                              \
+  int nsol_pair_stats_##SUF(const T *x, const T *y, int64_t n, double mx,        \
+                            double my, double *res, double *ws, void *s) {       \
+    return pair_stats_impl<T>(x, y, n, mx, my, res, ws, s);                      \
   }
 
 NSOL_DEF2(_, float, f32)

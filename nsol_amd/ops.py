@@ -219,6 +219,23 @@ def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None):
     return float(res.item()), g
 
 
+_ws8 = {}
+
+
+def pair_stats(x, y, mx=0.0, my=0.0):
+    """NumPy array of the 8 sums documented at nsol_pair_stats_* (syncs)."""
+    _chk(x), _chk(y)
+    ws, _ = _workspace(x.device)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _ws8:
+        _ws8[key] = torch.empty(8, dtype=torch.float64, device=x.device)
+    res = _ws8[key]
+    _lib.check(_fn("pair_stats", x)(_p(x), _p(y), x.numel(), float(mx),
+                                    float(my), _p(res), _p(ws), stream_ptr()),
+               "nsol_pair_stats")
+    return res.cpu().numpy()
+
+
 def loss_eval(f2, loss, f_scale=1.0, huber_gamma=1.345):
     """Element-wise (rho(f2), rho'(f2))."""
     _chk(f2)
