@@ -265,6 +265,26 @@ def test_pd_fused_ragged_shapes_vs_oracle(nsol, shape, ry):
     assert rel_l2(out32, ref) < F32_TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 9, 12), (5, 1, 16), (6, 7, 1),
+                                   (1, 1, 1), (2, 2, 2), (1, 4), (4, 1), (1,)])
+def test_degenerate_extents_vs_oracle(nsol, shape):
+    """Axes of length 1 still get their zero-padded difference (-x/h)."""
+    from oracle import nsol_oracle as orc
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(shape)
+    grad, grad_adj = _lo(len(shape)).get_gradient_operators()
+    assert np.array_equal(grad(x), orc.grad(x))
+    p = rng.standard_normal(grad(x).shape)
+    assert np.allclose(grad_adj(p), orc.grad_adj(p), rtol=0, atol=1e-14)
+    obs = 10.0 + rng.random(shape)
+    ref = orc.primal_dual_denoise(obs.flatten(), shape, "TV", "L1", 0.5, 6,
+                                  4.0 * len(shape), "ALG2")
+    s = _pd_solver(obs, "TV", "L1", 0.5, 6, 4.0 * len(shape), "ALG2",
+                   np.float64)
+    s.run()
+    assert rel_l2(s.get_x(), ref) < F64_TOL
+
+
 def test_pd_observer_and_errors(nsol, golden):
     import nsol_amd.primal_dual_solver as pd
     from nsol_amd.observer import Observer
