@@ -227,7 +227,10 @@ def main():
                 "traffic": measured_traffic(n),
                 "bytes_per_launch": bytes_per_launch,
                 "iterations_per_launch": args.steps / launches,
-                "avg_launch_ms": kernel_ms},
+                "avg_launch_ms": kernel_ms,
+                # what the memory system actually carries (PMC, per launch)
+                "traffic_rate_GBps": (measured_traffic(n) / (kernel_ms * 1e-3)
+                                      / 1e9) if measured_traffic(n) else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             sn = args.cpu_sample
