@@ -365,6 +365,90 @@ int nsol_pair_stats_f32(const float *x, const float *y, int64_t n, double mx,
 int nsol_pair_stats_f64(const double *x, const double *y, int64_t n, double mx,
                         double my, double *result, double *ws, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * Length-n pieces of a GPU-resident L-BFGS-B (nsol_amd/lbfgsb.py), replacing
+ * the host loops of scipy.optimize.minimize(method="L-BFGS-B") behind
+ * tikhonov_linear_solver.py:197-220.  Uniform bounds lo <= x <= hi (+-INFINITY
+ * = absent).  iwhere: int8 per variable (0 free with bounds, -1 unbounded,
+ * 1 / 2 fixed at lower / upper bound, -3 free with zero gradient, 3 fixed);
+ * a NULL iwhere means "all variables".  result / ws as for the reductions.
+ *   projgr        result[0] = max_i |projected gradient|
+ *   mdot          result[0] = sum over free i of x[i]*y[i]
+ *   cauchy_setup  classifies variables, d = -g on moving ones, tbk = breakpoint
+ *                 (INFINITY if none); result[0..3] = sum d^2, #breakpoints,
+ *                 #moving variables without a breakpoint and g != 0, #moving
+ *   select        indices with (tbk, i) > (t_done, i_done) and tbk <= t_hi,
+ *                 unordered, *count = how many (may exceed capacity)
+ *   cauchy_finish xcp = bound for breakpoints up to (t_done, i_done), else
+ *                 x + tsum*d; updates iwhere
+ *   wcomb         out = free ? scale*(sum_k bcoef[k]*base[k] + sum_j wcoef[j]*w[j]) : 0
+ *                 (host arrays of device pointers; nbase <= 3, nw <= 40)
+ *   project_step  xnew = free ? clip(xcp + d) : xcp; result[0] = #free at a bound
+ *   ratio_min     result[0] = min over free i of the feasible step ratio,
+ *                 result[1] = its smallest index (-1 if none)
+ *   trunc_apply   xnew = free ? (i == ibd ? bound : xcp + alpha*d) : xcp
+ * ---------------------------------------------------------------------- */
+int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
+                       double *ws, void *stream);
+int nsol_lb_projgr_f32(const float *x, const float *g, int64_t n, double lo, double hi,
+                       double *result, double *ws, void *stream);
+int nsol_lb_mdot_f32(const float *x, const float *y, const int8_t *iwhere, int64_t n,
+                     double *result, double *ws, void *stream);
+int nsol_lb_cauchy_setup_f32(const float *x, const float *g, int64_t n, double lo,
+                             double hi, int8_t *iwhere, float *d, float *tbk,
+                             double *result, double *ws, void *stream);
+int nsol_lb_select_f32(const float *tbk, int64_t n, double t_done, int64_t i_done,
+                       double t_hi, int64_t *out_idx, int capacity, int *count,
+                       void *stream);
+int nsol_lb_gather_f32(const float *src, const int64_t *idx, int count, float *out,
+                       void *stream);
+int nsol_lb_cauchy_finish_f32(const float *x, const float *d, const float *tbk, int64_t n,
+                              double lo, double hi, int8_t *iwhere, float *xcp,
+                              double tsum, double t_done, int64_t i_done,
+                              void *stream);
+int nsol_lb_wcomb_f32(float *out, int64_t n, const int8_t *iwhere, double scale,
+                      int nbase, const float *const *base_host,
+                      const double *bcoef_host, int nw, const float *const *w_host,
+                      const double *wcoef_host, void *stream);
+int nsol_lb_project_step_f32(const float *xcp, const float *d, int64_t n, double lo,
+                             double hi, const int8_t *iwhere, float *xnew,
+                             double *result, double *ws, void *stream);
+int nsol_lb_ratio_min_f32(const float *x, const float *d, int64_t n, double lo,
+                          double hi, const int8_t *iwhere, double *result,
+                          double *ws, void *stream);
+int nsol_lb_trunc_apply_f32(const float *xcp, const float *d, int64_t n, double lo,
+                            double hi, const int8_t *iwhere, double alpha,
+                            int64_t ibd, float *xnew, void *stream);
+int nsol_lb_projgr_f64(const double *x, const double *g, int64_t n, double lo, double hi,
+                       double *result, double *ws, void *stream);
+int nsol_lb_mdot_f64(const double *x, const double *y, const int8_t *iwhere, int64_t n,
+                     double *result, double *ws, void *stream);
+int nsol_lb_cauchy_setup_f64(const double *x, const double *g, int64_t n, double lo,
+                             double hi, int8_t *iwhere, double *d, double *tbk,
+                             double *result, double *ws, void *stream);
+int nsol_lb_select_f64(const double *tbk, int64_t n, double t_done, int64_t i_done,
+                       double t_hi, int64_t *out_idx, int capacity, int *count,
+                       void *stream);
+int nsol_lb_gather_f64(const double *src, const int64_t *idx, int count, double *out,
+                       void *stream);
+int nsol_lb_cauchy_finish_f64(const double *x, const double *d, const double *tbk, int64_t n,
+                              double lo, double hi, int8_t *iwhere, double *xcp,
+                              double tsum, double t_done, int64_t i_done,
+                              void *stream);
+int nsol_lb_wcomb_f64(double *out, int64_t n, const int8_t *iwhere, double scale,
+                      int nbase, const double *const *base_host,
+                      const double *bcoef_host, int nw, const double *const *w_host,
+                      const double *wcoef_host, void *stream);
+int nsol_lb_project_step_f64(const double *xcp, const double *d, int64_t n, double lo,
+                             double hi, const int8_t *iwhere, double *xnew,
+                             double *result, double *ws, void *stream);
+int nsol_lb_ratio_min_f64(const double *x, const double *d, int64_t n, double lo,
+                          double hi, const int8_t *iwhere, double *result,
+                          double *ws, void *stream);
+int nsol_lb_trunc_apply_f64(const double *xcp, const double *d, int64_t n, double lo,
+                            double hi, const int8_t *iwhere, double alpha,
+                            int64_t ibd, double *xnew, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,469 @@
+// Length-n building blocks of the GPU-resident L-BFGS-B driver
+// (nsol_amd/lbfgsb.py): projected-gradient norm, Cauchy-point set-up and
+// finish, breakpoint selection / gathers, masked dots, limited-memory
+// combinations, projected / truncated subspace steps.  They replace the O(n)
+// host loops of scipy.optimize's L-BFGS-B behind
+// tikhonov_linear_solver.py:197-220.  All are single HBM passes; reductions
+// are deterministic two-stage fp64 sums / mins (no float atomics); only the
+// breakpoint compaction uses an integer atomic counter (its output is sorted
+// on the host, so the result does not depend on arrival order).
+#include <math.h>
+
+#include "nsol_common.hpp"
+
+using namespace nsol;
+
+namespace {
+
+constexpr int kRed = 1024;   // partial blocks per reduction (ws >= 4*kRed doubles)
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+__device__ __forceinline__ double wmaxd(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1)
+    v = fmax(v, __shfl_down(v, off, kWave));
+  return v;
+}
+
+// block reduction of NV values (sum, or max when is_max) -> ws[k*kRed + block]
+template <int NV>
+__device__ __forceinline__ void block_partials(double (&a)[NV], double *ws,
+                                               bool is_max) {
+  __shared__ double s[NV][kBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double v = is_max ? wmaxd(a[k]) : wsum(a[k]);
+    if (lane == 0) s[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    double t = s[k][0];
+    for (int j = 1; j < kBlock / kWave; ++j)
+      t = is_max ? fmax(t, s[k][j]) : t + s[k][j];
+    ws[(int64_t)k * kRed + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_final(const double *ws, int nparts,
+                                                   int nv, bool is_max,
+                                                   double *result) {
+  if ((int)threadIdx.x < nv) {
+    const int k = threadIdx.x;
+    double t = ws[(int64_t)k * kRed];
+    for (int j = 1; j < nparts; ++j) {
+      const double v = ws[(int64_t)k * kRed + j];
+      t = is_max ? fmax(t, v) : t + v;
+    }
+    result[k] = t;
+  }
+}
+
+inline int rgrid(int64_t n) {
+  int g = grid_for(n);
+  return g > kRed ? kRed : g;
+}
+
+#define GRID_STRIDE(i, n)                                                     \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);   \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- max |projected gradient|
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_projgr(const T *__restrict__ x,
+                                                    const T *__restrict__ g,
+                                                    int64_t n, T lo, T hi,
+                                                    bool has_lo, bool has_hi,
+                                                    double *ws) {
+  double a[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    T gi = g[i];
+    if (gi < T(0)) {
+      if (has_hi) gi = t_max(x[i] - hi, gi);
+    } else {
+      if (has_lo) gi = (x[i] - lo < gi) ? x[i] - lo : gi;
+    }
+    a[0] = fmax(a[0], fabs((double)gi));
+  }
+  block_partials<1>(a, ws, true);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_free(const int8_t *iw,
+                                                        int64_t n, double *ws) {
+  double a[1] = {0.0};
+  GRID_STRIDE(i, n) a[0] += (iw[i] <= 0) ? 1.0 : 0.0;
+  block_partials<1>(a, ws, false);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mdot(const T *__restrict__ x,
+                                                  const T *__restrict__ y,
+                                                  const int8_t *iw, int64_t n,
+                                                  double *ws) {
+  double a[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    if (!iw || iw[i] <= 0) a[0] += (double)x[i] * (double)y[i];
+  }
+  block_partials<1>(a, ws, false);
+}
+
+// ---- Cauchy set-up: classify, d = -g on moving variables, breakpoints
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cauchy_setup(
+    const T *__restrict__ x, const T *__restrict__ g, int64_t n, T lo, T hi,
+    bool has_lo, bool has_hi, int8_t *iw, T *__restrict__ d,
+    T *__restrict__ tbk, double *ws) {
+  double a[4] = {0.0, 0.0, 0.0, 0.0};  // sum d^2, #breakpoints, #unbounded movers, #movers
+  const T inf = (T)INFINITY;
+  GRID_STRIDE(i, n) {
+    const T neg = -g[i];
+    int w = iw[i];
+    const T tl = has_lo ? x[i] - lo : inf;
+    const T tu = has_hi ? hi - x[i] : inf;
+    if (w != 3 && w != -1) {
+      const bool xlower = has_lo && tl <= T(0);
+      const bool xupper = has_hi && tu <= T(0);
+      w = 0;
+      if (xlower) { if (neg <= T(0)) w = 1; }
+      else if (xupper) { if (neg >= T(0)) w = 2; }
+      else if (t_abs(neg) <= T(0)) w = -3;
+      iw[i] = (int8_t)w;
+    }
+    T di = T(0), tb = inf;
+    if (w == 0 || w == -1) {
+      di = neg;
+      a[0] += (double)neg * (double)neg;
+      a[3] += 1.0;
+      if (has_lo && neg < T(0)) { tb = tl / (-neg); a[1] += 1.0; }
+      else if (has_hi && neg > T(0)) { tb = tu / neg; a[1] += 1.0; }
+      else if (t_abs(neg) > T(0)) a[2] += 1.0;
+    }
+    d[i] = di;
+    tbk[i] = tb;
+  }
+  block_partials<4>(a, ws, false);
+}
+
+// ---- breakpoints (t, i) lexicographically after (t_done, i_done), t <= t_hi
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_select(const T *__restrict__ tbk,
+                                                    int64_t n, T t_done,
+                                                    int64_t i_done, T t_hi,
+                                                    int64_t *out, int capacity,
+                                                    int *count) {
+  GRID_STRIDE(i, n) {
+    const T t = tbk[i];
+    if (t <= t_hi && (t > t_done || (t == t_done && i > i_done))) {
+      const int slot = atomicAdd(count, 1);
+      if (slot < capacity) out[slot] = i;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather(const T *__restrict__ src,
+                                                    const int64_t *idx,
+                                                    int count, T *out) {
+  GRID_STRIDE(j, count) out[j] = src[idx[j]];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cauchy_finish(
+    const T *__restrict__ x, const T *__restrict__ d,
+    const T *__restrict__ tbk, int64_t n, T lo, T hi, int8_t *iw,
+    T *__restrict__ xcp, T tsum, T t_done, int64_t i_done) {
+  GRID_STRIDE(i, n) {
+    const T t = tbk[i];
+    const bool fixed = (t < t_done) || (t == t_done && i <= i_done);
+    if (fixed) {
+      const bool up = d[i] > T(0);
+      xcp[i] = up ? hi : lo;
+      iw[i] = up ? 2 : 1;
+    } else {
+      xcp[i] = x[i] + tsum * d[i];
+    }
+  }
+}
+
+// ---- out = mask ? scale * (sum base + sum_j c_j W_j) : 0
+constexpr int kMaxW = 40;
+template <typename T>
+struct WComb {
+  const T *base[3];
+  T bcoef[3];
+  const T *w[kMaxW];
+  T wcoef[kMaxW];
+  int nbase, nw;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_wcomb(T *__restrict__ out, int64_t n,
+                                                   const int8_t *iw, T scale,
+                                                   WComb<T> C) {
+  GRID_STRIDE(i, n) {
+    T acc = T(0);
+    if (!iw || iw[i] <= 0) {
+      for (int k = 0; k < C.nbase; ++k) acc += C.bcoef[k] * C.base[k][i];
+      for (int j = 0; j < C.nw; ++j) acc += C.wcoef[j] * C.w[j][i];
+      acc *= scale;
+    }
+    out[i] = acc;
+  }
+}
+
+// ---- projected subspace step
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_project_step(
+    const T *__restrict__ xcp, const T *__restrict__ d, int64_t n, T lo, T hi,
+    bool has_lo, bool has_hi, const int8_t *iw, T *__restrict__ xn,
+    double *ws) {
+  double a[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    T v = xcp[i];
+    if (!iw || iw[i] <= 0) {
+      v = v + d[i];
+      if (has_lo && v < lo) v = lo;
+      if (has_hi && v > hi) v = hi;
+      if ((has_lo && v == lo) || (has_hi && v == hi)) a[0] += 1.0;
+    }
+    xn[i] = v;
+  }
+  block_partials<1>(a, ws, false);
+}
+
+// ---- min over (masked) i of the feasible step ratio, with the smallest index
+//      among ties; ratios: d<0: (lo-x)/d (0 if lo-x >= 0); d>0: (hi-x)/d
+template <typename T>
+__device__ __forceinline__ double step_ratio(T xv, T dv, T lo, T hi, bool has_lo,
+                                             bool has_hi) {
+  if (dv < T(0) && has_lo) {
+    const T t2 = lo - xv;
+    return (t2 >= T(0)) ? 0.0 : (double)(t2 / dv);
+  }
+  if (dv > T(0) && has_hi) {
+    const T t2 = hi - xv;
+    return (t2 <= T(0)) ? 0.0 : (double)(t2 / dv);
+  }
+  return INFINITY;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ratio_min(
+    const T *__restrict__ x, const T *__restrict__ d, int64_t n, T lo, T hi,
+    bool has_lo, bool has_hi, const int8_t *iw, double *ws) {
+  double best = INFINITY;
+  int64_t bidx = -1;
+  GRID_STRIDE(i, n) {
+    if (!iw || iw[i] <= 0) {
+      const double r = step_ratio(x[i], d[i], lo, hi, has_lo, has_hi);
+      if (r < best) { best = r; bidx = i; }   // grid-stride: i increases
+    }
+  }
+  __shared__ double sv[kBlock];
+  __shared__ int64_t si[kBlock];
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bidx;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double v2 = sv[threadIdx.x + s];
+      const int64_t i2 = si[threadIdx.x + s];
+      const double v1 = sv[threadIdx.x];
+      const int64_t i1 = si[threadIdx.x];
+      if (v2 < v1 || (v2 == v1 && i2 >= 0 && (i1 < 0 || i2 < i1))) {
+        sv[threadIdx.x] = v2;
+        si[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = sv[0];
+    ws[kRed + blockIdx.x] = (double)si[0];
+  }
+}
+
+__global__ void k_ratio_final(const double *ws, int nparts, double *result) {
+  if (threadIdx.x == 0) {
+    double v = ws[0], idx = ws[kRed];
+    for (int j = 1; j < nparts; ++j) {
+      const double v2 = ws[j], i2 = ws[kRed + j];
+      if (v2 < v || (v2 == v && i2 >= 0 && (idx < 0 || i2 < idx))) {
+        v = v2;
+        idx = i2;
+      }
+    }
+    result[0] = v;
+    result[1] = idx;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_trunc_apply(
+    const T *__restrict__ xcp, const T *__restrict__ d, int64_t n, T lo, T hi,
+    const int8_t *iw, T alpha, int64_t ibd, T *__restrict__ xn) {
+  GRID_STRIDE(i, n) {
+    T v = xcp[i];
+    if (!iw || iw[i] <= 0) {
+      if (i == ibd) v = (d[i] > T(0)) ? hi : lo;
+      else v = v + alpha * d[i];
+    }
+    xn[i] = v;
+  }
+}
+
+template <typename T>
+inline T cast_bound(double b) {
+  if (b == INFINITY) return (T)INFINITY;
+  if (b == -INFINITY) return (T)(-INFINITY);
+  return (T)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
+                       double *ws, void *stream) {
+  if (n < 0 || !result || !ws || (n > 0 && !iwhere)) return NSOL_EINVAL;
+  const int g = rgrid(n);
+  hipLaunchKernelGGL(k_count_free, dim3(g), dim3(kBlock), 0, as_stream(stream),
+                     iwhere, n, ws);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, g,
+                     1, false, result);
+  return launch_status();
+}
+
+#define NSOL_LB_DEF(T, SUF)                                                      \
+  int nsol_lb_projgr_##SUF(const T *x, const T *g, int64_t n, double lo,         \
+                           double hi, double *result, double *ws, void *s) {     \
+    if (n < 1 || !x || !g || !result || !ws) return NSOL_EINVAL;                 \
+    const int gr = rgrid(n);                                                     \
+    hipLaunchKernelGGL(k_projgr<T>, dim3(gr), dim3(kBlock), 0, as_stream(s), x,  \
+                       g, n, cast_bound<T>(lo), cast_bound<T>(hi),               \
+                       lo > -INFINITY, hi < INFINITY, ws);                       \
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
+                       1, true, result);                                         \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_mdot_##SUF(const T *x, const T *y, const int8_t *iwhere,           \
+                         int64_t n, double *result, double *ws, void *s) {       \
+    if (n < 1 || !x || !y || !result || !ws) return NSOL_EINVAL;                 \
+    const int gr = rgrid(n);                                                     \
+    hipLaunchKernelGGL(k_mdot<T>, dim3(gr), dim3(kBlock), 0, as_stream(s), x, y, \
+                       iwhere, n, ws);                                           \
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
+                       1, false, result);                                        \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_cauchy_setup_##SUF(const T *x, const T *g, int64_t n, double lo,   \
+                                 double hi, int8_t *iwhere, T *d, T *tbk,        \
+                                 double *result, double *ws, void *s) {          \
+    if (n < 1 || !x || !g || !iwhere || !d || !tbk || !result || !ws)            \
+      return NSOL_EINVAL;                                                        \
+    const int gr = rgrid(n);                                                     \
+    hipLaunchKernelGGL(k_cauchy_setup<T>, dim3(gr), dim3(kBlock), 0,             \
+                       as_stream(s), x, g, n, cast_bound<T>(lo),                 \
+                       cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY, iwhere, \
+                       d, tbk, ws);                                              \
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
+                       4, false, result);                                        \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_select_##SUF(const T *tbk, int64_t n, double t_done,               \
+                           int64_t i_done, double t_hi, int64_t *out_idx,        \
+                           int capacity, int *count, void *s) {                  \
+    if (n < 1 || !tbk || !out_idx || !count || capacity < 1)                     \
+      return NSOL_EINVAL;                                                        \
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), as_stream(s));          \
+    if (e != hipSuccess) return (int)e;                                          \
+    hipLaunchKernelGGL(k_select<T>, dim3(grid_for(n)), dim3(kBlock), 0,          \
+                       as_stream(s), tbk, n, (T)t_done, i_done, (T)t_hi,         \
+                       out_idx, capacity, count);                                \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_gather_##SUF(const T *src, const int64_t *idx, int count, T *out,  \
+                           void *s) {                                            \
+    if (count < 0 || !src || !idx || !out) return NSOL_EINVAL;                   \
+    if (count == 0) return 0;                                                    \
+    hipLaunchKernelGGL(k_gather<T>, dim3(grid_for(count)), dim3(kBlock), 0,      \
+                       as_stream(s), src, idx, count, out);                      \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_cauchy_finish_##SUF(const T *x, const T *d, const T *tbk,          \
+                                  int64_t n, double lo, double hi,               \
+                                  int8_t *iwhere, T *xcp, double tsum,           \
+                                  double t_done, int64_t i_done, void *s) {      \
+    if (n < 1 || !x || !d || !tbk || !iwhere || !xcp) return NSOL_EINVAL;        \
+    hipLaunchKernelGGL(k_cauchy_finish<T>, dim3(grid_for(n)), dim3(kBlock), 0,   \
+                       as_stream(s), x, d, tbk, n, cast_bound<T>(lo),            \
+                       cast_bound<T>(hi), iwhere, xcp, (T)tsum, (T)t_done,       \
+                       i_done);                                                  \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_wcomb_##SUF(T *out, int64_t n, const int8_t *iwhere, double scale, \
+                          int nbase, const T *const *base_host,                  \
+                          const double *bcoef_host, int nw,                      \
+                          const T *const *w_host, const double *wcoef_host,      \
+                          void *s) {                                             \
+    if (n < 1 || !out || nbase < 0 || nbase > 3 || nw < 0 || nw > kMaxW)         \
+      return NSOL_EINVAL;                                                        \
+    WComb<T> C;                                                                  \
+    C.nbase = nbase;                                                             \
+    C.nw = nw;                                                                   \
+    for (int k = 0; k < 3; ++k) {                                                \
+      C.base[k] = k < nbase ? base_host[k] : nullptr;                            \
+      C.bcoef[k] = k < nbase ? (T)bcoef_host[k] : T(0);                          \
+    }                                                                            \
+    for (int j = 0; j < kMaxW; ++j) {                                            \
+      C.w[j] = j < nw ? w_host[j] : nullptr;                                     \
+      C.wcoef[j] = j < nw ? (T)wcoef_host[j] : T(0);                             \
+    }                                                                            \
+    hipLaunchKernelGGL(k_wcomb<T>, dim3(grid_for(n)), dim3(kBlock), 0,           \
+                       as_stream(s), out, n, iwhere, (T)scale, C);               \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_project_step_##SUF(const T *xcp, const T *d, int64_t n, double lo, \
+                                 double hi, const int8_t *iwhere, T *xnew,       \
+                                 double *result, double *ws, void *s) {          \
+    if (n < 1 || !xcp || !d || !xnew || !result || !ws) return NSOL_EINVAL;      \
+    const int gr = rgrid(n);                                                     \
+    hipLaunchKernelGGL(k_project_step<T>, dim3(gr), dim3(kBlock), 0,             \
+                       as_stream(s), xcp, d, n, cast_bound<T>(lo),               \
+                       cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY, iwhere, \
+                       xnew, ws);                                                \
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
+                       1, false, result);                                        \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_ratio_min_##SUF(const T *x, const T *d, int64_t n, double lo,      \
+                              double hi, const int8_t *iwhere, double *result,   \
+                              double *ws, void *s) {                             \
+    if (n < 1 || !x || !d || !result || !ws) return NSOL_EINVAL;                 \
+    const int gr = rgrid(n);                                                     \
+    hipLaunchKernelGGL(k_ratio_min<T>, dim3(gr), dim3(kBlock), 0, as_stream(s),  \
+                       x, d, n, cast_bound<T>(lo), cast_bound<T>(hi),            \
+                       lo > -INFINITY, hi < INFINITY, iwhere, ws);               \
+    hipLaunchKernelGGL(k_ratio_final, dim3(1), dim3(64), 0, as_stream(s), ws,    \
+                       gr, result);                                              \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_trunc_apply_##SUF(const T *xcp, const T *d, int64_t n, double lo,  \
+                                double hi, const int8_t *iwhere, double alpha,   \
+                                int64_t ibd, T *xnew, void *s) {                 \
+    if (n < 1 || !xcp || !d || !xnew) return NSOL_EINVAL;                        \
+    hipLaunchKernelGGL(k_trunc_apply<T>, dim3(grid_for(n)), dim3(kBlock), 0,     \
+                       as_stream(s), xcp, d, n, cast_bound<T>(lo),               \
+                       cast_bound<T>(hi), iwhere, (T)alpha, ibd, xnew);          \
+    return launch_status();                                                      \
+  }
+
+NSOL_LB_DEF(float, f32)
+NSOL_LB_DEF(double, f64)
+
+}  // extern "C"

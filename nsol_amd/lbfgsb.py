@@ -1,0 +1,612 @@
+"""L-BFGS-B (Byrd, Lu, Nocedal, Zhu, SIAM J. Sci. Comput. 16, 1995; subspace
+step of Morales & Nocedal, ACM TOMS 38, 2011; line search of More & Thuente,
+ACM TOMS 20, 1994) with every length-n vector resident in HBM.
+
+Replaces the host driver behind
+    scipy.optimize.minimize(method="L-BFGS-B", fun, jac, x0, bounds=[[lo, hi]]*n,
+                            options={'maxiter': iter_max})
+of tikhonov_linear_solver.py:197-220 for the robust-loss branch, with SciPy's
+defaults (maxcor = 10, ftol = 2.22e-9, gtol = 1e-5, maxls = 20).  SciPy's own
+driver keeps all O(n) work (Cauchy-point search, subspace step, updates of the
+limited-memory matrices) in single-threaded host code: ~15 s per iteration at
+n = 256^3 even for a trivial objective.
+
+Structure: this module holds the iteration logic and the small (2m x 2m)
+dense algebra on the host in float64; all length-n work goes through a
+`backend` (nsol_amd.lbfgsb_device.DeviceBackend in the product; the tests
+also drive the same logic with a NumPy backend to compare it with SciPy on the
+CPU).  Bounds are uniform (lo, hi) as in the reference (`bounds=(0, inf)`).
+"""
+import math
+
+import numpy as np
+
+EPSMCH = np.finfo(np.float64).eps
+BIG = 1.0e10
+FTOL, GTOL, XTOL = 1.0e-3, 0.9, 0.1     # line search constants of L-BFGS-B
+
+
+# ---------------------------------------------------------------------------
+# More-Thuente line search (dcsrch / dcstep)
+# ---------------------------------------------------------------------------
+class LineSearch(object):
+    """Reverse-communication search for a step satisfying the strong Wolfe
+    conditions  f(stp) <= f(0) + ftol*stp*f'(0),  |f'(stp)| <= gtol*|f'(0)|."""
+
+    def __init__(self, f, g, stp, stpmin, stpmax):
+        self.stpmin, self.stpmax = stpmin, stpmax
+        self.task = "FG"
+        if stp < stpmin:
+            self.task = "ERROR: STP .LT. STPMIN"
+        if stp > stpmax:
+            self.task = "ERROR: STP .GT. STPMAX"
+        if g >= 0:
+            self.task = "ERROR: INITIAL G .GE. ZERO"
+        self.brackt = False
+        self.stage = 1
+        self.finit, self.ginit = f, g
+        self.gtest = FTOL * g
+        self.width = stpmax - stpmin
+        self.width1 = self.width / 0.5
+        self.stx, self.fx, self.gx = 0.0, f, g
+        self.sty, self.fy, self.gy = 0.0, f, g
+        self.stmin = 0.0
+        self.stmax = stp + 4.0 * stp
+        self.stp = stp
+
+    def step(self, f, g):
+        """Feed f, f' at self.stp; updates self.stp / self.task."""
+        stp = self.stp
+        ftest = self.finit + stp * self.gtest
+        if self.stage == 1 and f <= ftest and g >= 0:
+            self.stage = 2
+        task = "FG"
+        if self.brackt and (stp <= self.stmin or stp >= self.stmax):
+            task = "WARNING: ROUNDING ERRORS PREVENT PROGRESS"
+        if self.brackt and self.stmax - self.stmin <= XTOL * self.stmax:
+            task = "WARNING: XTOL TEST SATISFIED"
+        if stp == self.stpmax and f <= ftest and g <= self.gtest:
+            task = "WARNING: STP = STPMAX"
+        if stp == self.stpmin and (f > ftest or g >= self.gtest):
+            task = "WARNING: STP = STPMIN"
+        if f <= ftest and abs(g) <= GTOL * (-self.ginit):
+            task = "CONVERGENCE"
+        if task[:4] in ("WARN", "CONV"):
+            self.task = task
+            return
+        if self.stage == 1 and f <= self.fx and f > ftest:
+            # modified function psi(stp) = f(stp) - f(0) - stp*gtest
+            fm = f - stp * self.gtest
+            fxm = self.fx - self.stx * self.gtest
+            fym = self.fy - self.sty * self.gtest
+            gm = g - self.gtest
+            gxm = self.gx - self.gtest
+            gym = self.gy - self.gtest
+            (self.stx, fxm, gxm, self.sty, fym, gym, stp,
+             self.brackt) = _dcstep(self.stx, fxm, gxm, self.sty, fym, gym,
+                                    stp, fm, gm, self.brackt, self.stmin,
+                                    self.stmax)
+            self.fx = fxm + self.stx * self.gtest
+            self.fy = fym + self.sty * self.gtest
+            self.gx = gxm + self.gtest
+            self.gy = gym + self.gtest
+        else:
+            (self.stx, self.fx, self.gx, self.sty, self.fy, self.gy, stp,
+             self.brackt) = _dcstep(self.stx, self.fx, self.gx, self.sty,
+                                    self.fy, self.gy, stp, f, g, self.brackt,
+                                    self.stmin, self.stmax)
+        if self.brackt:
+            if abs(self.sty - self.stx) >= 0.66 * self.width1:
+                stp = self.stx + 0.5 * (self.sty - self.stx)
+            self.width1 = self.width
+            self.width = abs(self.sty - self.stx)
+        if self.brackt:
+            self.stmin = min(self.stx, self.sty)
+            self.stmax = max(self.stx, self.sty)
+        else:
+            self.stmin = stp + 1.1 * (stp - self.stx)
+            self.stmax = stp + 4.0 * (stp - self.stx)
+        stp = max(stp, self.stpmin)
+        stp = min(stp, self.stpmax)
+        if (self.brackt and (stp <= self.stmin or stp >= self.stmax)) or \
+                (self.brackt and self.stmax - self.stmin <= XTOL * self.stmax):
+            stp = self.stx
+        self.stp = stp
+        self.task = "FG"
+
+
+def _dcstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
+    """Safeguarded cubic / quadratic step of More-Thuente."""
+    sgnd = dp * (dx / abs(dx))
+    if fp > fx:                                   # case 1: higher value
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        s = max(abs(theta), abs(dx), abs(dp))
+        gamma = s * math.sqrt((theta / s) ** 2 - (dx / s) * (dp / s))
+        if stp < stx:
+            gamma = -gamma
+        p = (gamma - dx) + theta
+        q = ((gamma - dx) + gamma) + dp
+        r = p / q
+        stpc = stx + r * (stp - stx)
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * \
+            (stp - stx)
+        if abs(stpc - stx) < abs(stpq - stx):
+            stpf = stpc
+        else:
+            stpf = stpc + (stpq - stpc) / 2.0
+        brackt = True
+    elif sgnd < 0.0:                              # case 2: derivative flips
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        s = max(abs(theta), abs(dx), abs(dp))
+        gamma = s * math.sqrt((theta / s) ** 2 - (dx / s) * (dp / s))
+        if stp > stx:
+            gamma = -gamma
+        p = (gamma - dp) + theta
+        q = ((gamma - dp) + gamma) + dx
+        r = p / q
+        stpc = stp + r * (stx - stp)
+        stpq = stp + (dp / (dp - dx)) * (stx - stp)
+        stpf = stpc if abs(stpc - stp) > abs(stpq - stp) else stpq
+        brackt = True
+    elif abs(dp) < abs(dx):                       # case 3: derivative shrinks
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        s = max(abs(theta), abs(dx), abs(dp))
+        gamma = s * math.sqrt(max(0.0, (theta / s) ** 2 - (dx / s) * (dp / s)))
+        if stp > stx:
+            gamma = -gamma
+        p = (gamma - dp) + theta
+        q = (gamma + (dx - dp)) + gamma
+        r = p / q
+        if r < 0.0 and gamma != 0.0:
+            stpc = stp + r * (stx - stp)
+        elif stp > stx:
+            stpc = stpmax
+        else:
+            stpc = stpmin
+        stpq = stp + (dp / (dp - dx)) * (stx - stp)
+        if brackt:
+            stpf = stpc if abs(stpc - stp) < abs(stpq - stp) else stpq
+            if stp > stx:
+                stpf = min(stp + 0.66 * (sty - stp), stpf)
+            else:
+                stpf = max(stp + 0.66 * (sty - stp), stpf)
+        else:
+            stpf = stpc if abs(stpc - stp) > abs(stpq - stp) else stpq
+            stpf = min(stpmax, stpf)
+            stpf = max(stpmin, stpf)
+    else:                                         # case 4
+        if brackt:
+            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp
+            s = max(abs(theta), abs(dy), abs(dp))
+            gamma = s * math.sqrt((theta / s) ** 2 - (dy / s) * (dp / s))
+            if stp > sty:
+                gamma = -gamma
+            p = (gamma - dp) + theta
+            q = ((gamma - dp) + gamma) + dy
+            r = p / q
+            stpf = stp + r * (sty - stp)
+        elif stp > stx:
+            stpf = stpmax
+        else:
+            stpf = stpmin
+    if fp > fx:
+        sty, fy, dy = stp, fp, dp
+    else:
+        if sgnd < 0.0:
+            sty, fy, dy = stx, fx, dx
+        stx, fx, dx = stp, fp, dp
+    return stx, fx, dx, sty, fy, dy, stpf, brackt
+
+
+# ---------------------------------------------------------------------------
+# Small dense algebra of the compact representation (host, float64)
+# ---------------------------------------------------------------------------
+class CompactMatrix(object):
+    """B = theta*I - W M W^T with W = [Y, theta*S]; keeps S^T S (upper), the
+    lower triangle of S^T Y and the Cholesky factor of
+    T = theta*S^T S + L D^-1 L^T."""
+
+    def __init__(self, m):
+        self.m = m
+        self.col = 0
+        self.theta = 1.0
+        self.ss = np.zeros((m, m))
+        self.sy = np.zeros((m, m))
+        self.wt = None
+
+    def reset(self):
+        self.col = 0
+        self.theta = 1.0
+
+    def form_t(self):
+        c, th = self.col, self.theta
+        T = np.zeros((c, c))
+        for i in range(c):
+            for j in range(i, c):
+                k1 = min(i, j)
+                acc = 0.0
+                for k in range(k1):
+                    acc += self.sy[i, k] * self.sy[j, k] / self.sy[k, k]
+                T[i, j] = acc + th * self.ss[i, j]
+        T = np.triu(T) + np.triu(T, 1).T
+        try:
+            self.wt = np.linalg.cholesky(T).T        # upper: T = wt^T wt
+        except np.linalg.LinAlgError:
+            return False
+        return True
+
+    def bmv(self, v):
+        """Product of the 2col x 2col middle matrix M with v."""
+        c = self.col
+        if c == 0:
+            return np.zeros(0)
+        sy, wt = self.sy, self.wt
+        p = np.zeros(2 * c)
+        p[c] = v[c]
+        for i in range(1, c):
+            acc = 0.0
+            for k in range(i):
+                acc += sy[i, k] * v[k] / sy[k, k]
+            p[c + i] = v[c + i] + acc
+        p[c:] = _solve_upper_t(wt, p[c:])            # wt^T z = rhs
+        for i in range(c):
+            p[i] = v[i] / math.sqrt(sy[i, i])
+        p[c:] = _solve_upper(wt, p[c:])              # wt z = rhs
+        for i in range(c):
+            p[i] = -p[i] / math.sqrt(sy[i, i])
+        for i in range(c):
+            acc = 0.0
+            for k in range(i + 1, c):
+                acc += sy[k, i] * p[c + k] / sy[i, i]
+            p[i] += acc
+        return p
+
+
+def _solve_upper(R, b):
+    import scipy.linalg
+    return scipy.linalg.solve_triangular(R, b, lower=False)
+
+
+def _solve_upper_t(R, b):
+    import scipy.linalg
+    return scipy.linalg.solve_triangular(R, b, lower=False, trans='T')
+
+
+def form_k(cm, yzzy, szzs, szzy):
+    """LEL^T factorisation of the indefinite subspace matrix; the masked Gram
+    blocks are over the FREE variables: yzzy = Y^T Z Z^T Y, szzs = S^T Z Z^T S,
+    szzy = S^T Z Z^T Y.  Returns (R11, W12, R22) or None."""
+    c, th = cm.col, cm.theta
+    saas = (np.triu(cm.ss[:c, :c]) + np.triu(cm.ss[:c, :c], 1).T) - szzs
+    # (1,1) block  D + Y'ZZ'Y/theta
+    k11 = yzzy / th + np.diag(np.diag(cm.sy[:c, :c]))
+    # (1,2) block  -L_a' + R_z'  (row: y index, column: s index)
+    k12 = np.zeros((c, c))
+    for iy in range(c):           # s index
+        for jy in range(c):       # y index
+            if jy < iy:
+                la = cm.sy[iy, jy] - szzy[iy, jy]     # S'AA'Y, strictly lower
+                k12[jy, iy] = -la
+            else:
+                k12[jy, iy] = szzy[iy, jy]            # R_z (upper incl. diag)
+    try:
+        r11 = np.linalg.cholesky(k11).T               # k11 = r11^T r11
+    except np.linalg.LinAlgError:
+        return None
+    w12 = _solve_upper_t(r11, k12)                    # r11^-T k12
+    k22 = th * saas + w12.T.dot(w12)
+    try:
+        r22 = np.linalg.cholesky(k22).T
+    except np.linalg.LinAlgError:
+        return None
+    return r11, w12, r22
+
+
+def solve_k(fac, wv, c):
+    """wv := K^-1 wv with the factors of form_k."""
+    r11, w12, r22 = fac
+    out = np.array(wv, dtype=np.float64)
+    # forward: [r11^T 0; w12^T r22^T] z = wv
+    z1 = _solve_upper_t(r11, out[:c])
+    z2 = _solve_upper_t(r22, out[c:] - w12.T.dot(z1))
+    z1 = -z1
+    # backward: [r11 w12; 0 r22] x = z
+    x2 = _solve_upper(r22, z2)
+    x1 = _solve_upper(r11, z1 - w12.dot(x2))
+    out[:c], out[c:] = x1, x2
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Driver
+# ---------------------------------------------------------------------------
+def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
+             factr=1.0e7, pgtol=1.0e-5, maxls=20, maxfun=15000):
+    """Minimise f subject to lo <= x <= hi (uniform bounds, +-inf allowed).
+
+    fun_and_grad(x) -> (float f, vector g) with backend vectors.  Returns
+    (x, info dict).  Follows scipy's iteration accounting: stops after
+    `maxiter` accepted iterations."""
+    be = backend
+    has_lo, has_hi = np.isfinite(lo), np.isfinite(hi)
+    cnstnd = has_lo or has_hi
+    boxed = has_lo and has_hi
+    x = be.clip(x0, lo, hi)
+    cm = CompactMatrix(m)
+    ws, wy = [], []                   # stored s_k, y_k (oldest first)
+    iwhere = be.init_where(x, lo, hi)
+    f, g = fun_and_grad(x)
+    nfgv = 1
+    it = 0
+    nskip = 0
+    updatd = False
+    sbgnrm = be.projgr(x, g, lo, hi)
+    info = {"task": "START", "nit": 0, "nfev": 1}
+    if sbgnrm <= pgtol:
+        info["task"] = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL"
+        return x, info
+
+    while True:
+        col, theta = cm.col, cm.theta
+        # ---------------- generalized Cauchy point ------------------------
+        if not cnstnd and col > 0:
+            z = be.copy(x)
+            c_vec = np.zeros(2 * col)
+            nfree_all = True
+        else:
+            z, c_vec, iwhere = _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm,
+                                       sbgnrm)
+            nfree_all = False
+        # ---------------- subspace minimisation ---------------------------
+        nfree = be.count_free(iwhere) if not nfree_all else be.size(x)
+        if nfree != 0 and col != 0:
+            ok = True
+            if nfree_all:
+                free = None
+            else:
+                free = iwhere
+            yzzy, szzs, szzy = be.masked_grams(ws, wy, free)
+            fac = form_k(cm, yzzy, szzs, szzy)
+            if fac is None:
+                ok = False
+            if ok:
+                # r = -Z'(B(xcp - x) + g)
+                if not cnstnd and col > 0:
+                    r = be.scale(g, -1.0)
+                else:
+                    mc = cm.bmv(c_vec)
+                    coef_y = mc[:col]
+                    coef_s = theta * mc[col:]
+                    r = be.reduced_gradient(z, x, g, theta, ws, wy, coef_s,
+                                            coef_y, free)
+                z = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free)
+            else:
+                # refresh the memory and restart the iteration
+                cm.reset()
+                ws, wy = [], []
+                updatd = False
+                continue
+        # ---------------- line search --------------------------------------
+        d = be.lincomb2(1.0, z, -1.0, x)
+        dtd = be.dot(d, d)
+        dnorm = math.sqrt(dtd)
+        stpmx = BIG
+        if cnstnd:
+            if it == 0:
+                stpmx = 1.0
+            else:
+                stpmx = be.max_step(x, d, lo, hi, BIG)
+        if it == 0 and not boxed:
+            stp = min(1.0 / dnorm, stpmx) if dnorm > 0 else stpmx
+        else:
+            stp = 1.0
+        xold = be.copy(x)
+        gold = be.copy(g)
+        fold = f
+        gd = be.dot(g, d)
+        gdold = gd
+        restart = False
+        if gd >= 0:
+            # the search direction is not a descent direction
+            restart = True
+            ls_info = -4
+        else:
+            ls = LineSearch(f, gd, stp, 0.0, stpmx)
+            ifun = 0
+            iback = 0
+            ls_info = 0
+            while True:
+                if ls.task[:5] == "ERROR":
+                    ls_info = -3
+                    restart = True
+                    break
+                if ls.task[:4] in ("CONV", "WARN"):
+                    break
+                # the search asks for f, g at the trial step
+                ifun += 1
+                iback = ifun - 1
+                if iback >= maxls:
+                    restart = True
+                    break
+                nfgv += 1
+                stp = ls.stp
+                if stp == 1.0:
+                    x = be.copy(z)
+                else:
+                    x = be.lincomb2(stp, d, 1.0, xold)
+                f, g = fun_and_grad(x)
+                gd = be.dot(g, d)
+                ls.step(f, gd)
+            stp = ls.stp
+        if restart:
+            x, g, f = xold, gold, fold
+            if col == 0:
+                info["task"] = "ABNORMAL_TERMINATION_IN_LNSRCH"
+                break
+            cm.reset()
+            ws, wy = [], []
+            updatd = False
+            continue
+        # ---------------- new iterate ---------------------------------------
+        it += 1
+        sbgnrm = be.projgr(x, g, lo, hi)
+        if it >= maxiter:
+            info["task"] = "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT"
+            break
+        if nfgv > maxfun:
+            info["task"] = "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT"
+            break
+        if sbgnrm <= pgtol:
+            info["task"] = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL"
+            break
+        ddum = max(abs(fold), abs(f), 1.0)
+        if (fold - f) <= EPSMCH * factr * ddum:
+            info["task"] = "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"
+            break
+        # ---------------- BFGS update ---------------------------------------
+        r = be.lincomb2(1.0, g, -1.0, gold)
+        rr = be.dot(r, r)
+        if stp == 1.0:
+            dr = gd - gdold
+            ddum = -gdold
+        else:
+            dr = (gd - gdold) * stp
+            d = be.scale(d, stp)
+            ddum = -gdold * stp
+        if dr <= EPSMCH * ddum:
+            nskip += 1
+            updatd = False
+            continue
+        updatd = True
+        if cm.col < m:
+            cm.col += 1
+        else:                                     # drop the oldest pair
+            ws.pop(0)
+            wy.pop(0)
+            cm.ss[:m - 1, :m - 1] = cm.ss[1:, 1:]
+            cm.sy[:m - 1, :m - 1] = cm.sy[1:, 1:]
+        ws.append(d)
+        wy.append(r)
+        c = cm.col
+        cm.theta = rr / dr
+        sdots = be.dots(ws[:c - 1], d)            # S_old^T d
+        ydots = be.dots(wy[:c - 1], d)            # d^T Y_old
+        for j in range(c - 1):
+            cm.sy[c - 1, j] = ydots[j]
+            cm.ss[j, c - 1] = sdots[j]
+        cm.ss[c - 1, c - 1] = dtd if stp == 1.0 else stp * stp * dtd
+        cm.sy[c - 1, c - 1] = dr
+        if not cm.form_t():
+            cm.reset()
+            ws, wy = [], []
+            updatd = False
+    info["nit"] = it
+    info["nfev"] = nfgv
+    info["fun"] = f
+    return x, info
+
+
+def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
+    """Generalized Cauchy point along the projected steepest-descent path.
+    Returns (xcp, c = W^T (xcp - x), iwhere)."""
+    col, theta = cm.col, cm.theta
+    if sbgnrm <= 0.0:
+        return be.copy(x), np.zeros(2 * col), iwhere
+    d, tbk, iwhere, st = be.cauchy_setup(x, g, lo, hi, iwhere)
+    f1 = st["f1"]
+    nbreak = st["nbreak"]
+    bnded = st["bnded"]
+    any_move = st["any_move"]
+    p = np.zeros(2 * col)
+    if col > 0:
+        p[:col] = be.dots(wy, d)
+        p[col:] = theta * np.asarray(be.dots(ws, d))
+    if not any_move:
+        return be.copy(x), np.zeros(2 * col), iwhere
+    c = np.zeros(2 * col)
+    f2 = -theta * f1
+    f2_org = f2
+    if col > 0:
+        f2 -= float(np.dot(cm.bmv(p), p))
+    dtm = -f1 / f2
+    tsum = 0.0
+    t_done, i_done = -1.0, -1            # last breakpoint that was fixed
+    all_fixed = False
+    if nbreak > 0:
+        tj = 0.0
+        nleft = nbreak
+        finished = False
+        fetch = be.breakpoint_stream(tbk, d, ws, wy)
+        while not finished:
+            batch = fetch(t_done, i_done, tsum + dtm)
+            if batch is None:
+                break                    # minimiser before the next breakpoint
+            for (tj_new, ibp, dibp, xibp, wrow_y, wrow_s) in batch:
+                dt = tj_new - tj
+                if dtm < dt:
+                    finished = True
+                    break
+                tj = tj_new
+                tsum += dt
+                nleft -= 1
+                t_done, i_done = tj_new, ibp
+                zibp = (hi - xibp) if dibp > 0 else (lo - xibp)
+                if nleft == 0 and nbreak == be.size(x):
+                    dtm = dt
+                    all_fixed = True
+                    finished = True
+                    break
+                dibp2 = dibp * dibp
+                f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp
+                f2 = f2 - theta * dibp2
+                if col > 0:
+                    c += dt * p
+                    wbp = np.concatenate((wrow_y, theta * wrow_s))
+                    v = cm.bmv(wbp)
+                    wmc = float(np.dot(c, v))
+                    wmp = float(np.dot(p, v))
+                    wmw = float(np.dot(wbp, v))
+                    p -= dibp * wbp
+                    f1 += dibp * wmc
+                    f2 += 2.0 * dibp * wmp - dibp2 * wmw
+                f2 = max(EPSMCH * f2_org, f2)
+                if nleft > 0:
+                    dtm = -f1 / f2
+                elif bnded:
+                    f1 = f2 = dtm = 0.0
+                    finished = True
+                    break
+                else:
+                    dtm = -f1 / f2
+                    finished = True
+                    break
+    if not all_fixed:
+        if dtm <= 0.0:
+            dtm = 0.0
+        tsum += dtm
+    xcp, iwhere = be.cauchy_finish(x, d, tbk, lo, hi, iwhere, tsum, t_done,
+                                   i_done, all_fixed)
+    if col > 0:
+        c += dtm * p
+    return xcp, c, iwhere
+
+
+def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free):
+    """Subspace minimisation over the free variables at the Cauchy point with
+    the projection refinement; returns the new point."""
+    col, theta = cm.col, cm.theta
+    wv = np.zeros(2 * col)
+    wv[:col] = be.dots(wy, r, free)
+    wv[col:] = theta * np.asarray(be.dots(ws, r, free))
+    wv = solve_k(fac, wv, col)
+    # d = (1/theta) r + (1/theta^2) Z'W wv   (wv already carries theta in S)
+    d = be.subspace_direction(r, ws, wy, wv[:col] / theta, wv[col:], theta,
+                              free)
+    xnew, hit = be.project_step(xcp, d, lo, hi, free)
+    if not hit:
+        return xnew
+    dd_p = be.dot_diff(xnew, x, g)
+    if dd_p <= 0.0:
+        return xnew
+    # projected point is not a descent direction: truncate instead
+    return be.truncated_step(xcp, d, lo, hi, free)

@@ -1,0 +1,253 @@
+"""Device backend of nsol_amd.lbfgsb: every length-n operation of the
+L-BFGS-B iteration is a HIP kernel of libnsol_hip.so (nsol_lbfgsb.hip) on
+torch HIP tensors; only scalars, <= 2m x 2m matrices and the (few) breakpoints
+the Cauchy search actually crosses travel to the host."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .device import suffix, stream_ptr
+
+
+def _fn(name, t):
+    return getattr(_lib.load(), "nsol_lb_%s_%s" % (name, suffix(t)))
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class DeviceBackend(object):
+
+    CAPACITY = 1 << 16        # breakpoints fetched per round trip
+
+    def __init__(self):
+        self._res = None
+        self._sel = None
+
+    # ---- small helpers
+    def _bufs(self, like):
+        ws, _ = ops._workspace(like.device)
+        if self._res is None or self._res.device != like.device:
+            self._res = torch.empty(8, dtype=torch.float64, device=like.device)
+        return ws, self._res
+
+    def _check(self, rc, what):
+        _lib.check(rc, "nsol_lb_" + what)
+
+    def size(self, x):
+        return x.numel()
+
+    def copy(self, x):
+        return x.clone()
+
+    def clip(self, x, lo, hi):
+        return ops.clip(x, lo, hi)
+
+    def scale(self, x, a):
+        return ops.scale(x, a)
+
+    def lincomb2(self, a, x, b, y):
+        return ops.lincomb2(a, x, b, y)
+
+    def dot(self, x, y):
+        return ops.dot(x, y)
+
+    def dot_diff(self, a, b, g):
+        return ops.dot(ops.lincomb2(1.0, a, -1.0, b), g)
+
+    def init_where(self, x, lo, hi):
+        bounded = np.isfinite(lo) or np.isfinite(hi)
+        val = 0 if bounded else -1
+        if np.isfinite(lo) and np.isfinite(hi) and hi - lo <= 0:
+            val = 3
+        return torch.full((x.numel(),), val, dtype=torch.int8,
+                          device=x.device)
+
+    def count_free(self, iwhere):
+        ws, res = self._bufs(iwhere)
+        self._check(_lib.load().nsol_lb_count_free(
+            _p(iwhere), iwhere.numel(), _p(res), _p(ws), stream_ptr()),
+            "count_free")
+        return int(round(float(res[0].item())))
+
+    def projgr(self, x, g, lo, hi):
+        ws, res = self._bufs(x)
+        self._check(_fn("projgr", x)(_p(x), _p(g), x.numel(), float(lo),
+                                     float(hi), _p(res), _p(ws),
+                                     stream_ptr()), "projgr")
+        return float(res[0].item())
+
+    def dots(self, vecs, v, free=None):
+        """[sum_free vecs[k]*v]: one kernel per vector, one read-back."""
+        if not vecs:
+            return []
+        ws, _ = self._bufs(v)
+        out = torch.empty(len(vecs), dtype=torch.float64, device=v.device)
+        fn = _fn("mdot", v)
+        for k, w in enumerate(vecs):
+            self._check(fn(_p(w), _p(v), _p(free), v.numel(),
+                           out.data_ptr() + 8 * k, _p(ws), stream_ptr()),
+                        "mdot")
+        return [float(t) for t in out.cpu().numpy()]
+
+    def masked_grams(self, ws_list, wy_list, free):
+        """Y'ZZ'Y, S'ZZ'S, S'ZZ'Y over the free variables (Z), col x col."""
+        c = len(ws_list)
+        like = ws_list[0]
+        wsb, _ = self._bufs(like)
+        out = torch.empty(3 * c * c, dtype=torch.float64, device=like.device)
+        fn = _fn("mdot", like)
+        n = like.numel()
+
+        def launch(a, b, slot):
+            self._check(fn(_p(a), _p(b), _p(free), n,
+                           out.data_ptr() + 8 * slot, _p(wsb), stream_ptr()),
+                        "mdot")
+        for i in range(c):
+            for j in range(i, c):
+                launch(wy_list[i], wy_list[j], i * c + j)
+                launch(ws_list[i], ws_list[j], c * c + i * c + j)
+            for j in range(c):
+                launch(ws_list[i], wy_list[j], 2 * c * c + i * c + j)
+        h = out.cpu().numpy().reshape(3, c, c)
+        yy = np.triu(h[0]) + np.triu(h[0], 1).T
+        ss = np.triu(h[1]) + np.triu(h[1], 1).T
+        return yy, ss, h[2]
+
+    # ---- Cauchy point
+    def cauchy_setup(self, x, g, lo, hi, iwhere):
+        ws, res = self._bufs(x)
+        d = torch.empty_like(x)
+        tbk = torch.empty_like(x)
+        iw = iwhere.clone()
+        self._check(_fn("cauchy_setup", x)(
+            _p(x), _p(g), x.numel(), float(lo), float(hi), _p(iw), _p(d),
+            _p(tbk), _p(res), _p(ws), stream_ptr()), "cauchy_setup")
+        r = res[:4].cpu().numpy()
+        st = {"f1": -float(r[0]), "nbreak": int(round(r[1])),
+              "bnded": int(round(r[2])) == 0, "any_move": int(round(r[3])) > 0}
+        self._x = x
+        return d, tbk, iw, st
+
+    def breakpoint_stream(self, tbk, d, ws_list, wy_list):
+        x = self._x
+        dev = tbk.device
+        n = tbk.numel()
+        cap = min(self.CAPACITY, n)
+        idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        sel = _fn("select", tbk)
+        gat = _fn("gather", tbk)
+        f32 = tbk.dtype == torch.float32
+        pending = []
+
+        def gather(src, count):
+            out = torch.empty(count, dtype=src.dtype, device=dev)
+            self._check(gat(_p(src), _p(idx), count, _p(out), stream_ptr()),
+                        "gather")
+            return out.cpu().numpy().astype(np.float64)
+
+        def fetch(t_done, i_done, t_hi):
+            if pending:
+                return [pending.pop(0)]
+            # widen the window slightly: the host loop applies the exact test
+            lim = t_hi * (1.0 + (1e-6 if f32 else 1e-12)) + 1e-300
+            while True:
+                self._check(sel(_p(tbk), n, float(t_done), int(i_done),
+                                float(lim), _p(idx), cap, _p(cnt),
+                                stream_ptr()), "select")
+                count = int(cnt.item())
+                if count <= cap:
+                    break
+                # too many candidates: halve the window above t_done
+                base = max(t_done, 0.0)
+                lim = base + 0.5 * (lim - base)
+            if count == 0:
+                return None
+            t = gather(tbk, count)
+            ii = idx[:count].cpu().numpy()
+            dv = gather(d, count)
+            xv = gather(x, count)
+            wyv = np.stack([gather(w, count) for w in wy_list], 1) \
+                if wy_list else np.zeros((count, 0))
+            wsv = np.stack([gather(w, count) for w in ws_list], 1) \
+                if ws_list else np.zeros((count, 0))
+            order = np.lexsort((ii, t))
+            for k in order:
+                pending.append((float(t[k]), int(ii[k]), float(dv[k]),
+                                float(xv[k]), wyv[k], wsv[k]))
+            return [pending.pop(0)]
+        return fetch
+
+    def cauchy_finish(self, x, d, tbk, lo, hi, iwhere, tsum, t_done, i_done,
+                      all_fixed):
+        xcp = torch.empty_like(x)
+        self._check(_fn("cauchy_finish", x)(
+            _p(x), _p(d), _p(tbk), x.numel(), float(lo), float(hi),
+            _p(iwhere), _p(xcp), float(tsum), float(t_done), int(i_done),
+            stream_ptr()), "cauchy_finish")
+        return xcp, iwhere
+
+    # ---- limited-memory combinations
+    def _wcomb(self, like, free, scale, base, bcoef, wvecs, wcoef):
+        out = torch.empty_like(like)
+        PT = ctypes.c_void_p * max(len(base), 1)
+        PW = ctypes.c_void_p * max(len(wvecs), 1)
+        bp = PT(*[b.data_ptr() for b in base])
+        wp = PW(*[w.data_ptr() for w in wvecs])
+        bc = np.ascontiguousarray(bcoef, dtype=np.float64)
+        wc = np.ascontiguousarray(wcoef if len(wcoef) else [0.0],
+                                  dtype=np.float64)
+        self._check(_fn("wcomb", like)(
+            _p(out), like.numel(), _p(free), float(scale), len(base),
+            ctypes.cast(bp, ctypes.c_void_p), bc.ctypes.data, len(wvecs),
+            ctypes.cast(wp, ctypes.c_void_p), wc.ctypes.data, stream_ptr()),
+            "wcomb")
+        return out
+
+    def reduced_gradient(self, z, x, g, theta, ws_list, wy_list, coef_s,
+                         coef_y, free):
+        return self._wcomb(x, free, 1.0, [z, x, g], [-theta, theta, -1.0],
+                           list(wy_list) + list(ws_list),
+                           list(coef_y) + list(coef_s))
+
+    def subspace_direction(self, r, ws_list, wy_list, cy, cs, theta, free):
+        return self._wcomb(r, free, 1.0 / theta, [r], [1.0],
+                           list(wy_list) + list(ws_list),
+                           list(cy) + list(cs))
+
+    # ---- subspace step and line-search bound
+    def project_step(self, xcp, d, lo, hi, free):
+        ws, res = self._bufs(xcp)
+        xn = torch.empty_like(xcp)
+        self._check(_fn("project_step", xcp)(
+            _p(xcp), _p(d), xcp.numel(), float(lo), float(hi), _p(free),
+            _p(xn), _p(res), _p(ws), stream_ptr()), "project_step")
+        return xn, float(res[0].item()) > 0
+
+    def _ratio_min(self, x, d, lo, hi, free):
+        ws, res = self._bufs(x)
+        self._check(_fn("ratio_min", x)(
+            _p(x), _p(d), x.numel(), float(lo), float(hi), _p(free),
+            _p(res), _p(ws), stream_ptr()), "ratio_min")
+        r = res[:2].cpu().numpy()
+        return float(r[0]), int(r[1])
+
+    def truncated_step(self, xcp, d, lo, hi, free):
+        ratio, k = self._ratio_min(xcp, d, lo, hi, free)
+        alpha, ibd = 1.0, -1
+        if k >= 0 and ratio < alpha:
+            alpha, ibd = ratio, k
+        xn = torch.empty_like(xcp)
+        self._check(_fn("trunc_apply", xcp)(
+            _p(xcp), _p(d), xcp.numel(), float(lo), float(hi), _p(free),
+            float(alpha), int(ibd if alpha < 1.0 else -1), _p(xn),
+            stream_ptr()), "trunc_apply")
+        return xn
+
+    def max_step(self, x, d, lo, hi, big):
+        ratio, k = self._ratio_min(x, d, lo, hi, None)
+        return min(big, ratio) if k >= 0 else big

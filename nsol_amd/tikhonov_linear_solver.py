@@ -28,6 +28,10 @@ from .symbolic import trace_operator
 
 # set to False to force the generic (un-fused) LSMR vector kernels
 USE_FUSED_LSMR = True
+# minimizer="L-BFGS-B": True = GPU-resident driver (nsol_amd/lbfgsb.py, same
+# algorithm and defaults as SciPy's, iterates agree to rounding); False = SciPy's
+# host driver with GPU-evaluated cost / gradient
+USE_DEVICE_LBFGSB = True
 
 
 class TikhonovLinearSolver(LinearSolver):
@@ -214,7 +218,36 @@ class TikhonovLinearSolver(LinearSolver):
         return to_device(x, self._dtype)
 
     # ------------------------------------------------------------------
+    def _device_objective(self):
+        """cost(x), gradient(x) of tikhonov :201-208 on device vectors."""
+        A, A_adj, B, B_adj = self._callables()
+        b = self._dev(self._b)
+        use_reg = self._alpha > EPS
+        alpha = self._alpha
+        loss, fscale = self._data_loss, self._data_loss_scale
+
+        def fun_and_grad(x):
+            r = ops.lincomb2(1.0, A(x), -1.0, b)
+            cost, g = ops.loss_cost_grad(r, loss, fscale, out=r)
+            grad = A_adj(g)
+            if use_reg:
+                Bx = B(x)
+                # reference quirk kept: 1/2||Bx||^2, b_reg is ignored here
+                cost = cost + alpha * (0.5 * ops.dot(Bx, Bx))
+                grad = ops.lincomb2(1.0, grad, alpha, B_adj(Bx))
+            return cost, grad
+        return fun_and_grad
+
     def _run_minimize(self, x0):
+        if self._minimizer == "L-BFGS-B" and USE_DEVICE_LBFGSB:
+            from . import lbfgsb
+            from .lbfgsb_device import DeviceBackend
+            lo, hi = self._bounds
+            x, info = lbfgsb.minimize(self._device_objective(), x0, float(lo),
+                                      float(hi), DeviceBackend(),
+                                      maxiter=self._iter_max)
+            self._minimize_info = info
+            return x
         A, A_adj, B, B_adj = self._callables()
         b = self._dev(self._b)
         dt = self._dtype

@@ -401,8 +401,55 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
         assert rel_l2(s.get_x(), g["admm_lsmr_" + k]) < tol
 
 
+@pytest.fixture(params=["device-lbfgsb", "scipy-lbfgsb"])
+def lbfgsb_form(request):
+    import nsol_amd.tikhonov_linear_solver as tk
+    tk.USE_DEVICE_LBFGSB = request.param == "device-lbfgsb"
+    yield request.param
+    tk.USE_DEVICE_LBFGSB = True
+
+
+def test_device_lbfgsb_tracks_scipy(nsol):
+    """The GPU-resident L-BFGS-B and scipy.optimize's reach the same iterates
+    (same iteration and evaluation counts) on bound-constrained problems."""
+    import scipy.optimize
+    import torch
+    from nsol_amd import lbfgsb
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    for seed, n, lo, hi, iters in ((0, 300, 0.0, np.inf, 8),
+                                   (1, 300, 0.0, 1.5, 25),
+                                   (2, 40, -np.inf, 0.7, 25),
+                                   (3, 2000, 0.0, np.inf, 12),
+                                   (4, 150, -np.inf, np.inf, 10)):
+        rng = np.random.default_rng(seed)
+        A = rng.standard_normal((n + 5, n))
+        b = 3.0 * rng.standard_normal(n + 5)
+        c = rng.standard_normal(n)
+
+        def fg(x):
+            r = A @ x - b
+            z = r * r
+            return (float(np.sum(np.sqrt(1 + z) - 1)) +
+                    0.05 * float(np.sum((x - c) ** 4)),
+                    A.T @ (r / np.sqrt(1 + z)) + 0.2 * (x - c) ** 3)
+
+        def fg_dev(xd):
+            f, g = fg(xd.cpu().numpy())
+            return f, torch.from_numpy(g).cuda()
+        x0 = 2.0 * rng.standard_normal(n) + 1.0
+        ref = scipy.optimize.minimize(
+            fg, x0, jac=True, method="L-BFGS-B",
+            bounds=scipy.optimize.Bounds(np.full(n, lo), np.full(n, hi)),
+            options={"maxiter": iters})
+        x, info = lbfgsb.minimize(fg_dev, torch.from_numpy(x0).cuda(), lo, hi,
+                                  DeviceBackend(), maxiter=iters)
+        assert info["nit"] == ref.nit and info["nfev"] == ref.nfev
+        assert rel_l2(x.cpu().numpy(), ref.x) < 1e-9
+
+
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
-def test_admm_lbfgsb_huber_matches_reference_goldens(nsol, golden, k):
+def test_admm_lbfgsb_huber_matches_reference_goldens(nsol, golden, k,
+                                                     lbfgsb_form):
     import nsol_amd.admm_linear_solver as admm
     g, shape, A, Aa, D, Da = _dec_ops(golden, k)
     y = g["y_" + k]
@@ -417,7 +464,7 @@ def test_admm_lbfgsb_huber_matches_reference_goldens(nsol, golden, k):
 
 @pytest.mark.parametrize("lossname", ["huber", "soft_l1", "cauchy", "arctan",
                                       "linear"])
-def test_tikhonov_minimize_losses(nsol, golden, lossname):
+def test_tikhonov_minimize_losses(nsol, golden, lossname, lbfgsb_form):
     import nsol_amd.tikhonov_linear_solver as tk
     g, shape, A, Aa, D, Da = _dec_ops(golden, "2d")
     y = g["y_2d"]

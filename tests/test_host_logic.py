@@ -179,6 +179,38 @@ def test_synthetic_volume_matches_oracle_copy():
                               orc.synth_volume(16, 2, kind))
 
 
+@pytest.mark.parametrize("lo,hi", [(0.0, np.inf), (-np.inf, np.inf),
+                                   (0.0, 1.5), (-np.inf, 0.7)])
+@pytest.mark.parametrize("n,iters", [(5, 8), (40, 3), (40, 25), (300, 8),
+                                     (300, 25)])
+def test_lbfgsb_iteration_logic_tracks_scipy(lo, hi, n, iters):
+    """nsol_amd.lbfgsb (the product's L-BFGS-B iteration logic), driven with a
+    NumPy backend, reproduces scipy.optimize.minimize(method='L-BFGS-B'):
+    same iterates, iteration count and function-evaluation count."""
+    import scipy.optimize
+    from nsol_amd import lbfgsb
+    from lbfgsb_numpy_backend import NumpyBackend
+    rng = np.random.default_rng(n + iters)
+    A = rng.standard_normal((n + 5, n))
+    b = 3.0 * rng.standard_normal(n + 5)
+    c = rng.standard_normal(n)
+
+    def fg(x):
+        r = A @ x - b
+        z = r * r
+        return (float(np.sum(np.sqrt(1 + z) - 1)) +
+                0.05 * float(np.sum((x - c) ** 4)),
+                A.T @ (r / np.sqrt(1 + z)) + 0.2 * (x - c) ** 3)
+    x0 = 2.0 * rng.standard_normal(n) + 1.0
+    ref = scipy.optimize.minimize(
+        fg, x0, jac=True, method="L-BFGS-B",
+        bounds=scipy.optimize.Bounds(np.full(n, lo), np.full(n, hi)),
+        options={"maxiter": iters})
+    x, info = lbfgsb.minimize(fg, x0, lo, hi, NumpyBackend(), maxiter=iters)
+    assert info["nit"] == ref.nit and info["nfev"] == ref.nfev
+    assert np.linalg.norm(x - ref.x) <= 1e-10 * max(np.linalg.norm(ref.x), 1)
+
+
 def test_shard_indices():
     from nsol_amd.batch import shard_indices
     assert shard_indices(8, 1, 4) == [1, 5]
