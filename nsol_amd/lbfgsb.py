@@ -21,6 +21,9 @@ import math
 
 import numpy as np
 
+# counters of the last minimize() call (diagnostics for tools/profile_admm.py)
+STATS = {"cauchy_calls": 0, "breakpoints": 0, "crossed": 0, "fetches": 0}
+
 EPSMCH = np.finfo(np.float64).eps
 BIG = 1.0e10
 FTOL, GTOL, XTOL = 1.0e-3, 0.9, 0.1     # line search constants of L-BFGS-B
@@ -508,30 +511,41 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
 
 def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     """Generalized Cauchy point along the projected steepest-descent path.
-    Returns (xcp, c = W^T (xcp - x), iwhere)."""
+    Returns (xcp, c = W^T (xcp - x), iwhere).
+
+    The breakpoints the search crosses arrive from the backend in sorted
+    batches (t, index, d_i, x_i, rows of Y and S).  A batch is walked with
+    prefix sums (the recurrences for p, c, f', f'' are linear between stops), so
+    millions of crossed bounds cost a few NumPy cumsums instead of a Python
+    loop; the scalar walk below is kept for the rare clamp of f'' and for the
+    very last breakpoint, whose bookkeeping differs."""
     col, theta = cm.col, cm.theta
     if sbgnrm <= 0.0:
         return be.copy(x), np.zeros(2 * col), iwhere
     d, tbk, iwhere, st = be.cauchy_setup(x, g, lo, hi, iwhere)
     f1 = st["f1"]
     nbreak = st["nbreak"]
+    STATS["cauchy_calls"] += 1
+    STATS["breakpoints"] += nbreak
     bnded = st["bnded"]
-    any_move = st["any_move"]
     p = np.zeros(2 * col)
     if col > 0:
         p[:col] = be.dots(wy, d)
         p[col:] = theta * np.asarray(be.dots(ws, d))
-    if not any_move:
+    if not st["any_move"]:
         return be.copy(x), np.zeros(2 * col), iwhere
     c = np.zeros(2 * col)
     f2 = -theta * f1
     f2_org = f2
+    mmat = None
     if col > 0:
         f2 -= float(np.dot(cm.bmv(p), p))
+        mmat = np.array([cm.bmv(e) for e in np.eye(2 * col)]).T   # v = mmat @ w
     dtm = -f1 / f2
     tsum = 0.0
     t_done, i_done = -1.0, -1            # last breakpoint that was fixed
     all_fixed = False
+    n_total = be.size(x)
     if nbreak > 0:
         tj = 0.0
         nleft = nbreak
@@ -539,34 +553,89 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
         fetch = be.breakpoint_stream(tbk, d, ws, wy)
         while not finished:
             batch = fetch(t_done, i_done, tsum + dtm)
+            STATS["fetches"] += 1
             if batch is None:
                 break                    # minimiser before the next breakpoint
-            for (tj_new, ibp, dibp, xibp, wrow_y, wrow_s) in batch:
-                dt = tj_new - tj
-                if dtm < dt:
+            bt, bi, bd, bx, bwy, bws = batch
+            k0 = 0
+            K = len(bt)
+            # ---- vectorised walk over all but the globally last breakpoint
+            kv = K if nleft > K else K - 1
+            if kv > 0:
+                t = bt[:kv]
+                dt = np.diff(np.concatenate(([tj], t)))
+                dib = bd[:kv]
+                dib2 = dib * dib
+                zib = np.where(dib > 0, hi - bx[:kv], lo - bx[:kv])
+                inc2 = -theta * dib2
+                inc1x = dib2 - theta * dib * zib
+                if col > 0:
+                    W = np.concatenate((bwy[:kv], theta * bws[:kv]), axis=1)
+                    P_after = p - np.cumsum(dib[:, None] * W, axis=0)
+                    P_before = np.vstack((p, P_after[:-1]))
+                    C_after = c + np.cumsum(dt[:, None] * P_before, axis=0)
+                    V = W.dot(mmat.T)
+                    wmc = np.sum(C_after * V, axis=1)
+                    wmp = np.sum(P_before * V, axis=1)
+                    wmw = np.sum(W * V, axis=1)
+                    inc2 = inc2 + 2.0 * dib * wmp - dib2 * wmw
+                    inc1x = inc1x + dib * wmc
+                f2_after = f2 + np.cumsum(inc2)
+                clamp = f2_after < EPSMCH * f2_org
+                if np.any(clamp):
+                    kv = int(np.argmax(clamp))      # scalar walk from there
+                    f2_after = f2_after[:kv]
+                if kv > 0:
+                    f2_before = np.concatenate(([f2], f2_after[:kv - 1]))
+                    f1_after = f1 + np.cumsum(dt[:kv] * f2_before +
+                                              inc1x[:kv])
+                    dtm_after = -f1_after / f2_after
+                    dtm_before = np.concatenate(([dtm], dtm_after[:kv - 1]))
+                    stop = dtm_before < dt[:kv]
+                    kdone = int(np.argmax(stop)) if np.any(stop) else kv
+                    if kdone > 0:
+                        j = kdone - 1
+                        tj = float(t[j])
+                        tsum = tj
+                        nleft -= kdone
+                        t_done, i_done = float(t[j]), int(bi[j])
+                        f1, f2 = float(f1_after[j]), float(f2_after[j])
+                        dtm = float(dtm_after[j])
+                        if col > 0:
+                            p = P_after[j].copy()
+                            c = C_after[j].copy()
+                    if kdone < kv or np.any(stop):
+                        finished = True
+                        break
+                    k0 = kdone
+            # ---- scalar walk (clamped f'' / last breakpoint)
+            for k in range(k0, K):
+                tj_new, ibp, dibp, xibp = bt[k], int(bi[k]), bd[k], bx[k]
+                dt1 = tj_new - tj
+                if dtm < dt1:
                     finished = True
                     break
-                tj = tj_new
-                tsum += dt
+                tj = float(tj_new)
+                tsum += dt1
                 nleft -= 1
-                t_done, i_done = tj_new, ibp
+                t_done, i_done = float(tj_new), ibp
                 zibp = (hi - xibp) if dibp > 0 else (lo - xibp)
-                if nleft == 0 and nbreak == be.size(x):
-                    dtm = dt
+                if nleft == 0 and nbreak == n_total:
+                    dtm = dt1
                     all_fixed = True
                     finished = True
                     break
                 dibp2 = dibp * dibp
-                f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp
+                f1 = f1 + dt1 * f2 + dibp2 - theta * dibp * zibp
                 f2 = f2 - theta * dibp2
                 if col > 0:
-                    c += dt * p
-                    wbp = np.concatenate((wrow_y, theta * wrow_s))
-                    v = cm.bmv(wbp)
+                    c = c + dt1 * p
+                    wbp = np.concatenate((bwy[k], theta * bws[k]))
+                    v = mmat.dot(wbp)
                     wmc = float(np.dot(c, v))
                     wmp = float(np.dot(p, v))
                     wmw = float(np.dot(wbp, v))
-                    p -= dibp * wbp
+                    p = p - dibp * wbp
                     f1 += dibp * wmc
                     f2 += 2.0 * dibp * wmp - dibp2 * wmw
                 f2 = max(EPSMCH * f2_org, f2)
@@ -580,6 +649,8 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
                     dtm = -f1 / f2
                     finished = True
                     break
+    if nbreak > 0:
+        STATS["crossed"] += nbreak - nleft
     if not all_fixed:
         if dtm <= 0.0:
             dtm = 0.0
@@ -587,7 +658,7 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     xcp, iwhere = be.cauchy_finish(x, d, tbk, lo, hi, iwhere, tsum, t_done,
                                    i_done, all_fixed)
     if col > 0:
-        c += dtm * p
+        c = c + dtm * p
     return xcp, c, iwhere
 
 

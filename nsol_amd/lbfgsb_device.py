@@ -21,7 +21,7 @@ def _p(t):
 
 class DeviceBackend(object):
 
-    CAPACITY = 1 << 16        # breakpoints fetched per round trip
+    CAPACITY = 1 << 20        # breakpoints fetched per round trip
 
     def __init__(self):
         self._res = None
@@ -142,7 +142,6 @@ class DeviceBackend(object):
         sel = _fn("select", tbk)
         gat = _fn("gather", tbk)
         f32 = tbk.dtype == torch.float32
-        pending = []
 
         def gather(src, count):
             out = torch.empty(count, dtype=src.dtype, device=dev)
@@ -151,9 +150,9 @@ class DeviceBackend(object):
             return out.cpu().numpy().astype(np.float64)
 
         def fetch(t_done, i_done, t_hi):
-            if pending:
-                return [pending.pop(0)]
-            # widen the window slightly: the host loop applies the exact test
+            """Sorted batch (t, index, d, x, Y rows, S rows) of the breakpoints
+            after (t_done, i_done) up to t_hi, or None."""
+            # widen the window slightly: the host walk applies the exact test
             lim = t_hi * (1.0 + (1e-6 if f32 else 1e-12)) + 1e-300
             while True:
                 self._check(sel(_p(tbk), n, float(t_done), int(i_done),
@@ -176,10 +175,8 @@ class DeviceBackend(object):
             wsv = np.stack([gather(w, count) for w in ws_list], 1) \
                 if ws_list else np.zeros((count, 0))
             order = np.lexsort((ii, t))
-            for k in order:
-                pending.append((float(t[k]), int(ii[k]), float(dv[k]),
-                                float(xv[k]), wyv[k], wsv[k]))
-            return [pending.pop(0)]
+            return (t[order], ii[order], dv[order], xv[order], wyv[order],
+                    wsv[order])
         return fetch
 
     def cauchy_finish(self, x, d, tbk, lo, hi, iwhere, tsum, t_done, i_done,

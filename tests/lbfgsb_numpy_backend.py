@@ -85,6 +85,8 @@ class NumpyBackend(object):
         self._x = x
         return d, tbk, iw, st
 
+    BATCH = 64
+
     def breakpoint_stream(self, tbk, d, ws, wy):
         order = np.lexsort((np.arange(tbk.size), tbk))
         order = order[np.isfinite(tbk[order])]
@@ -92,17 +94,20 @@ class NumpyBackend(object):
         x = self._x
 
         def fetch(t_done, i_done, t_hi):
-            out = []
             lim = t_hi * (1.0 + 1e-12) + 1e-300
-            while pos[0] < order.size and len(out) < 64:
+            sel = []
+            while pos[0] < order.size and len(sel) < self.BATCH:
                 i = int(order[pos[0]])
                 if tbk[i] > lim:
                     break
-                out.append((float(tbk[i]), i, float(d[i]), float(x[i]),
-                            np.array([w[i] for w in wy]),
-                            np.array([w[i] for w in ws])))
+                sel.append(i)
                 pos[0] += 1
-            return out if out else None
+            if not sel:
+                return None
+            sel = np.array(sel)
+            return (tbk[sel].astype(np.float64), sel, d[sel], x[sel],
+                    np.array([w[sel] for w in wy]).T.reshape(sel.size, len(wy)),
+                    np.array([w[sel] for w in ws]).T.reshape(sel.size, len(ws)))
         return fetch
 
     def cauchy_finish(self, x, d, tbk, lo, hi, iwhere, tsum, t_done, i_done,
