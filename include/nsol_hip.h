@@ -449,6 +449,15 @@ int nsol_lb_trunc_apply_f64(const double *xcp, const double *d, int64_t n, doubl
                             double hi, const int8_t *iwhere, double alpha,
                             int64_t ibd, double *xnew, void *stream);
 
+/* Sort a compacted list of `count` variable indices by (tbk[index], index):
+ * the order in which the Cauchy search meets its breakpoints.  tmp: device
+ * scratch of nsol_lb_sort_tmp_bytes(count, sizeof element) bytes. */
+int64_t nsol_lb_sort_tmp_bytes(int count, int elem_size);
+int nsol_lb_sort_candidates_f32(const float *tbk, int64_t *idx, int count,
+                                void *tmp, int64_t tmp_bytes, void *stream);
+int nsol_lb_sort_candidates_f64(const double *tbk, int64_t *idx, int count,
+                                void *tmp, int64_t tmp_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ def load():
     # experiment knob, not part of the reference-facing ABI
     lib.nsol_hip_set_param.restype = c_int
     lib.nsol_hip_set_param.argtypes = [ctypes.c_char_p, c_int]
+    lib.nsol_lb_sort_tmp_bytes.restype = c_i64
+    lib.nsol_lb_sort_tmp_bytes.argtypes = [c_int, c_int]
     lib.nsol_hip_set_param_pd2.restype = c_int
     lib.nsol_hip_set_param_pd2.argtypes = [ctypes.c_char_p, c_int]
     if lib.nsol_hip_abi_version() != 1:

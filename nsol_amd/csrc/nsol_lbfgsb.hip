@@ -100,14 +100,28 @@ __global__ __launch_bounds__(kBlock) void k_count_free(const int8_t *iw,
   block_partials<1>(a, ws, false);
 }
 
-template <typename T>
+// 16-byte loads when n and the pointers allow (vec = 16 / sizeof(T) elements)
+template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_mdot(const T *__restrict__ x,
                                                   const T *__restrict__ y,
                                                   const int8_t *iw, int64_t n,
                                                   double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
   double a[1] = {0.0};
-  GRID_STRIDE(i, n) {
-    if (!iw || iw[i] <= 0) a[0] += (double)x[i] * (double)y[i];
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    const V xv = reinterpret_cast<const V *>(x)[j];
+    const V yv = reinterpret_cast<const V *>(y)[j];
+    if (iw) {
+      const M m = reinterpret_cast<const M *>(iw)[j];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        if (m[k] <= 0) a[0] += (double)xv[k] * (double)yv[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) a[0] += (double)xv[k] * (double)yv[k];
+    }
   }
   block_partials<1>(a, ws, false);
 }
@@ -156,10 +170,24 @@ __global__ __launch_bounds__(kBlock) void k_select(const T *__restrict__ tbk,
                                                     int64_t i_done, T t_hi,
                                                     int64_t *out, int capacity,
                                                     int *count) {
-  GRID_STRIDE(i, n) {
-    const T t = tbk[i];
-    if (t <= t_hi && (t > t_done || (t == t_done && i > i_done))) {
-      const int slot = atomicAdd(count, 1);
+  // one atomic per wave: lanes that hold a candidate take consecutive slots
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int64_t base = first - lane; base < n; base += stride) {
+    const int64_t i = base + lane;
+    bool take = false;
+    if (i < n) {
+      const T t = tbk[i];
+      take = t <= t_hi && (t > t_done || (t == t_done && i > i_done));
+    }
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) continue;
+    int wave_base = 0;
+    if (lane == 0) wave_base = atomicAdd(count, __popcll(mask));
+    wave_base = __shfl(wave_base, 0, kWave);
+    if (take) {
+      const int slot = wave_base + __popcll(mask & ((1ull << lane) - 1ull));
       if (slot < capacity) out[slot] = i;
     }
   }
@@ -354,9 +382,16 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
   int nsol_lb_mdot_##SUF(const T *x, const T *y, const int8_t *iwhere,           \
                          int64_t n, double *result, double *ws, void *s) {       \
     if (n < 1 || !x || !y || !result || !ws) return NSOL_EINVAL;                 \
-    const int gr = rgrid(n);                                                     \
-    hipLaunchKernelGGL(k_mdot<T>, dim3(gr), dim3(kBlock), 0, as_stream(s), x, y, \
-                       iwhere, n, ws);                                           \
+    constexpr int VW = 16 / sizeof(T);                                           \
+    const bool vec = n % VW == 0 && !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && \
+                     (!iwhere || !((uintptr_t)iwhere & (VW - 1)));               \
+    const int gr = rgrid(vec ? n / VW : n);                                      \
+    if (vec)                                                                     \
+      hipLaunchKernelGGL((k_mdot<T, VW>), dim3(gr), dim3(kBlock), 0,             \
+                         as_stream(s), x, y, iwhere, n, ws);                     \
+    else                                                                         \
+      hipLaunchKernelGGL((k_mdot<T, 1>), dim3(gr), dim3(kBlock), 0,              \
+                         as_stream(s), x, y, iwhere, n, ws);                     \
     hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
                        1, false, result);                                        \
     return launch_status();                                                      \

@@ -25,7 +25,7 @@ class DeviceBackend(object):
 
     def __init__(self):
         self._res = None
-        self._sel = None
+        self._tmp = None
 
     # ---- small helpers
     def _bufs(self, like):
@@ -141,6 +141,8 @@ class DeviceBackend(object):
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         sel = _fn("select", tbk)
         gat = _fn("gather", tbk)
+        srt = _fn("sort_candidates", tbk)
+        lib = _lib.load()
         f32 = tbk.dtype == torch.float32
 
         def gather(src, count):
@@ -166,6 +168,14 @@ class DeviceBackend(object):
                 lim = base + 0.5 * (lim - base)
             if count == 0:
                 return None
+            # order the candidates by (t, index) on the device, then gather
+            need = int(lib.nsol_lb_sort_tmp_bytes(count, 4 if f32 else 8))
+            if self._tmp is None or self._tmp.numel() < need or \
+                    self._tmp.device != dev:
+                self._tmp = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._check(srt(_p(tbk), _p(idx), count, _p(self._tmp),
+                            self._tmp.numel(), stream_ptr()),
+                        "sort_candidates")
             t = gather(tbk, count)
             ii = idx[:count].cpu().numpy()
             dv = gather(d, count)
@@ -174,9 +184,7 @@ class DeviceBackend(object):
                 if wy_list else np.zeros((count, 0))
             wsv = np.stack([gather(w, count) for w in ws_list], 1) \
                 if ws_list else np.zeros((count, 0))
-            order = np.lexsort((ii, t))
-            return (t[order], ii[order], dv[order], xv[order], wyv[order],
-                    wsv[order])
+            return (t, ii, dv, xv, wyv, wsv)
         return fetch
 
     def cauchy_finish(self, x, d, tbk, lo, hi, iwhere, tsum, t_done, i_done,
