@@ -377,8 +377,10 @@ int nsol_pair_stats_f64(const double *x, const double *y, int64_t n, double mx,
  *   cauchy_setup  classifies variables, d = -g on moving ones, tbk = breakpoint
  *                 (INFINITY if none); result[0..3] = sum d^2, #breakpoints,
  *                 #moving variables without a breakpoint and g != 0, #moving
- *   select        indices with (tbk, i) > (t_done, i_done) and tbk <= t_hi,
- *                 unordered, *count = how many (may exceed capacity)
+ *   count_window  result[0] = number of breakpoints with (tbk, i) >
+ *                 (t_done, i_done) and tbk <= t_hi
+ *   select        the indices of those breakpoints, unordered; *count = how
+ *                 many (may exceed capacity: then size the window first)
  *   cauchy_finish xcp = bound for breakpoints up to (t_done, i_done), else
  *                 x + tsum*d; updates iwhere
  *   wcomb         out = free ? scale*(sum_k bcoef[k]*base[k] + sum_j wcoef[j]*w[j]) : 0
@@ -400,6 +402,9 @@ int nsol_lb_cauchy_setup_f32(const float *x, const float *g, int64_t n, double l
 int nsol_lb_select_f32(const float *tbk, int64_t n, double t_done, int64_t i_done,
                        double t_hi, int64_t *out_idx, int capacity, int *count,
                        void *stream);
+int nsol_lb_count_window_f32(const float *tbk, int64_t n, double t_done,
+                             int64_t i_done, double t_hi, double *result,
+                             double *ws, void *stream);
 int nsol_lb_gather_f32(const float *src, const int64_t *idx, int count, float *out,
                        void *stream);
 int nsol_lb_cauchy_finish_f32(const float *x, const float *d, const float *tbk, int64_t n,
@@ -429,6 +434,9 @@ int nsol_lb_cauchy_setup_f64(const double *x, const double *g, int64_t n, double
 int nsol_lb_select_f64(const double *tbk, int64_t n, double t_done, int64_t i_done,
                        double t_hi, int64_t *out_idx, int capacity, int *count,
                        void *stream);
+int nsol_lb_count_window_f64(const double *tbk, int64_t n, double t_done,
+                             int64_t i_done, double t_hi, double *result,
+                             double *ws, void *stream);
 int nsol_lb_gather_f64(const double *src, const int64_t *idx, int count, double *out,
                        void *stream);
 int nsol_lb_cauchy_finish_f64(const double *x, const double *d, const double *tbk, int64_t n,

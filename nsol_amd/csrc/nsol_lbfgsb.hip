@@ -193,6 +193,19 @@ __global__ __launch_bounds__(kBlock) void k_select(const T *__restrict__ tbk,
   }
 }
 
+// how many breakpoints the window holds (no atomics: used to size the window)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_count_window(
+    const T *__restrict__ tbk, int64_t n, T t_done, int64_t i_done, T t_hi,
+    double *ws) {
+  double a[1] = {0.0};
+  GRID_STRIDE(i, n) {
+    const T t = tbk[i];
+    if (t <= t_hi && (t > t_done || (t == t_done && i > i_done))) a[0] += 1.0;
+  }
+  block_partials<1>(a, ws, false);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_gather(const T *__restrict__ src,
                                                     const int64_t *idx,
@@ -420,6 +433,17 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
     hipLaunchKernelGGL(k_select<T>, dim3(grid_for(n)), dim3(kBlock), 0,          \
                        as_stream(s), tbk, n, (T)t_done, i_done, (T)t_hi,         \
                        out_idx, capacity, count);                                \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lb_count_window_##SUF(const T *tbk, int64_t n, double t_done,         \
+                                 int64_t i_done, double t_hi, double *result,    \
+                                 double *ws, void *s) {                          \
+    if (n < 1 || !tbk || !result || !ws) return NSOL_EINVAL;                     \
+    const int gr = rgrid(n);                                                     \
+    hipLaunchKernelGGL(k_count_window<T>, dim3(gr), dim3(kBlock), 0,             \
+                       as_stream(s), tbk, n, (T)t_done, i_done, (T)t_hi, ws);    \
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
+                       1, false, result);                                        \
     return launch_status();                                                      \
   }                                                                              \
   int nsol_lb_gather_##SUF(const T *src, const int64_t *idx, int count, T *out,  \

@@ -142,6 +142,7 @@ class DeviceBackend(object):
         sel = _fn("select", tbk)
         gat = _fn("gather", tbk)
         srt = _fn("sort_candidates", tbk)
+        cntw = _fn("count_window", tbk)
         lib = _lib.load()
         f32 = tbk.dtype == torch.float32
 
@@ -156,11 +157,14 @@ class DeviceBackend(object):
             after (t_done, i_done) up to t_hi, or None."""
             # widen the window slightly: the host walk applies the exact test
             lim = t_hi * (1.0 + (1e-6 if f32 else 1e-12)) + 1e-300
+            # size the window with the (atomic-free) counting pass, then
+            # compact once
+            wsb, res = self._bufs(tbk)
             while True:
-                self._check(sel(_p(tbk), n, float(t_done), int(i_done),
-                                float(lim), _p(idx), cap, _p(cnt),
-                                stream_ptr()), "select")
-                count = int(cnt.item())
+                self._check(cntw(_p(tbk), n, float(t_done), int(i_done),
+                                 float(lim), _p(res), _p(wsb), stream_ptr()),
+                            "count_window")
+                count = int(round(float(res[0].item())))
                 if count <= cap:
                     break
                 # too many candidates: halve the window above t_done
@@ -168,6 +172,10 @@ class DeviceBackend(object):
                 lim = base + 0.5 * (lim - base)
             if count == 0:
                 return None
+            self._check(sel(_p(tbk), n, float(t_done), int(i_done),
+                            float(lim), _p(idx), cap, _p(cnt), stream_ptr()),
+                        "select")
+            assert int(cnt.item()) == count
             # order the candidates by (t, index) on the device, then gather
             need = int(lib.nsol_lb_sort_tmp_bytes(count, 4 if f32 else 8))
             if self._tmp is None or self._tmp.numel() < need or \
