@@ -676,6 +676,20 @@ def test_two_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters):
             assert torch.equal(a, b), (shape, zc)
 
 
+@pytest.mark.parametrize("shape", [(200, 333, 640), (97, 1030, 512),
+                                   (130, 260, 1536), (64, 64, 2048)])
+def test_two_iterations_per_pass_large_shapes(nsol, shape):
+    """HBM-sized, non-cubic volumes incl. several x-tiles (nx > 512) and a
+    ragged last y-tile: still bit-identical to the one-iteration kernel."""
+    import torch
+    from nsol_amd import ops
+    flags = ops.PD_REG_TV | ops.PD_DATA_L2
+    ref = _run_pd_raw(shape, np.float32, 4, flags, enable2=0)
+    got = _run_pd_raw(shape, np.float32, 4, flags, enable2=1)
+    for a, b in zip(ref[:3], got[:3]):
+        assert torch.equal(a, b), shape
+
+
 def test_two_iterations_per_pass_vs_oracle(nsol):
     from oracle import nsol_oracle as orc
     shape = (12, 21, 256)
