@@ -466,6 +466,35 @@ int nsol_lb_sort_candidates_f32(const float *tbk, int64_t *idx, int count,
 int nsol_lb_sort_candidates_f64(const double *tbk, int64_t *idx, int count,
                                 void *tmp, int64_t tmp_bytes, void *stream);
 
+/* Walk of `count` breakpoints sorted by nsol_lb_sort_candidates_* (generalized
+ * Cauchy point) with prefix sums; see nsol_sort.hip.  params (device):
+ * p[2col] | c[2col] | M[2col][2col] row-major (float64).  table:
+ * nsol_lb_walk_table_doubles(count, col) doubles; tmp:
+ * nsol_lb_walk_tmp_bytes(count) bytes; event: device int[2].  out (device
+ * double[8 + 4*col]): [kdone, stopped (1) / not (0), index of a clamped f'' or
+ * -1, t, variable index, f', f'', dt_min at breakpoint kdone-1, p[2col],
+ * c[2col]]. */
+int64_t nsol_lb_walk_table_doubles(int count, int col);
+int64_t nsol_lb_walk_tmp_bytes(int count);
+int nsol_lb_cauchy_walk_f32(const float *tbk, const float *d, const float *x,
+                            const int64_t *idx, int count,
+                            const float *const *wy_host,
+                            const float *const *ws_host, int col, double theta,
+                            double lo, double hi, double tj, double f1,
+                            double f2, double f2_org, double dtm,
+                            const double *params, double *table, void *tmp,
+                            int64_t tmp_bytes, int *event, double *out,
+                            void *stream);
+int nsol_lb_cauchy_walk_f64(const double *tbk, const double *d, const double *x,
+                            const int64_t *idx, int count,
+                            const double *const *wy_host,
+                            const double *const *ws_host, int col, double theta,
+                            double lo, double hi, double tj, double f1,
+                            double f2, double f2_org, double dtm,
+                            const double *params, double *table, void *tmp,
+                            int64_t tmp_bytes, int *event, double *out,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,10 @@ def load():
     lib.nsol_hip_set_param.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_lb_sort_tmp_bytes.restype = c_i64
     lib.nsol_lb_sort_tmp_bytes.argtypes = [c_int, c_int]
+    lib.nsol_lb_walk_table_doubles.restype = c_i64
+    lib.nsol_lb_walk_table_doubles.argtypes = [c_int, c_int]
+    lib.nsol_lb_walk_tmp_bytes.restype = c_i64
+    lib.nsol_lb_walk_tmp_bytes.argtypes = [c_int]
     lib.nsol_hip_set_param_pd2.restype = c_int
     lib.nsol_hip_set_param_pd2.argtypes = [ctypes.c_char_p, c_int]
     if lib.nsol_hip_abi_version() != 1:

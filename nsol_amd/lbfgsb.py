@@ -509,156 +509,177 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     return x, info
 
 
+class _PathState(object):
+    """Scalars and 2col-vectors carried along the projected-gradient path."""
+    __slots__ = ("tj", "tsum", "nleft", "f1", "f2", "dtm", "p", "c", "t_done",
+                 "i_done", "all_fixed")
+
+
 def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     """Generalized Cauchy point along the projected steepest-descent path.
     Returns (xcp, c = W^T (xcp - x), iwhere).
 
-    The breakpoints the search crosses arrive from the backend in sorted
-    batches (t, index, d_i, x_i, rows of Y and S).  A batch is walked with
-    prefix sums (the recurrences for p, c, f', f'' are linear between stops), so
-    millions of crossed bounds cost a few NumPy cumsums instead of a Python
-    loop; the scalar walk below is kept for the rare clamp of f'' and for the
-    very last breakpoint, whose bookkeeping differs."""
+    The breakpoints the search crosses are walked with prefix sums (the
+    recurrences for p, c, f', f'' are linear between stops), so millions of
+    crossed bounds cost a few scans instead of one step each: on the device
+    when the backend offers `breakpoint_walker` (sorted candidate table + hipCUB
+    scans), else with NumPy cumsums over batches from `breakpoint_stream`.  The
+    scalar walk is kept for the rare clamp of f'' and for the very last
+    breakpoint, whose bookkeeping differs."""
     col, theta = cm.col, cm.theta
     if sbgnrm <= 0.0:
         return be.copy(x), np.zeros(2 * col), iwhere
     d, tbk, iwhere, st = be.cauchy_setup(x, g, lo, hi, iwhere)
-    f1 = st["f1"]
     nbreak = st["nbreak"]
+    bnded = st["bnded"]
     STATS["cauchy_calls"] += 1
     STATS["breakpoints"] += nbreak
-    bnded = st["bnded"]
-    p = np.zeros(2 * col)
+    S = _PathState()
+    S.f1 = st["f1"]
+    S.p = np.zeros(2 * col)
     if col > 0:
-        p[:col] = be.dots(wy, d)
-        p[col:] = theta * np.asarray(be.dots(ws, d))
+        S.p[:col] = be.dots(wy, d)
+        S.p[col:] = theta * np.asarray(be.dots(ws, d))
     if not st["any_move"]:
         return be.copy(x), np.zeros(2 * col), iwhere
-    c = np.zeros(2 * col)
-    f2 = -theta * f1
-    f2_org = f2
+    S.c = np.zeros(2 * col)
+    S.f2 = -theta * S.f1
+    f2_org = S.f2
     mmat = None
     if col > 0:
-        f2 -= float(np.dot(cm.bmv(p), p))
+        S.f2 -= float(np.dot(cm.bmv(S.p), S.p))
         mmat = np.array([cm.bmv(e) for e in np.eye(2 * col)]).T   # v = mmat @ w
-    dtm = -f1 / f2
-    tsum = 0.0
-    t_done, i_done = -1.0, -1            # last breakpoint that was fixed
-    all_fixed = False
+    S.dtm = -S.f1 / S.f2
+    S.tsum = 0.0
+    S.tj = 0.0
+    S.t_done, S.i_done = -1.0, -1         # last breakpoint that was fixed
+    S.all_fixed = False
+    S.nleft = nbreak
     n_total = be.size(x)
+
+    def scalar_walk(batch, k0):
+        """One breakpoint at a time; returns True when the search is over."""
+        bt, bi, bd, bx, bwy, bws = batch
+        for k in range(k0, len(bt)):
+            tj_new, ibp, dibp, xibp = bt[k], int(bi[k]), bd[k], bx[k]
+            dt1 = tj_new - S.tj
+            if S.dtm < dt1:
+                return True
+            S.tj = float(tj_new)
+            S.tsum += dt1
+            S.nleft -= 1
+            S.t_done, S.i_done = float(tj_new), ibp
+            zibp = (hi - xibp) if dibp > 0 else (lo - xibp)
+            if S.nleft == 0 and nbreak == n_total:
+                S.dtm = dt1
+                S.all_fixed = True
+                return True
+            dibp2 = dibp * dibp
+            S.f1 = S.f1 + dt1 * S.f2 + dibp2 - theta * dibp * zibp
+            S.f2 = S.f2 - theta * dibp2
+            if col > 0:
+                S.c = S.c + dt1 * S.p
+                wbp = np.concatenate((bwy[k], theta * bws[k]))
+                v = mmat.dot(wbp)
+                wmc = float(np.dot(S.c, v))
+                wmp = float(np.dot(S.p, v))
+                wmw = float(np.dot(wbp, v))
+                S.p = S.p - dibp * wbp
+                S.f1 += dibp * wmc
+                S.f2 += 2.0 * dibp * wmp - dibp2 * wmw
+            S.f2 = max(EPSMCH * f2_org, S.f2)
+            if S.nleft > 0:
+                S.dtm = -S.f1 / S.f2
+            elif bnded:
+                S.f1 = S.f2 = S.dtm = 0.0
+                return True
+            else:
+                S.dtm = -S.f1 / S.f2
+                return True
+        return False
+
+    def cumsum_walk(batch):
+        """NumPy prefix-sum walk; returns (finished, first unprocessed k)."""
+        bt, bi, bd, bx, bwy, bws = batch
+        K = len(bt)
+        kv = K if S.nleft > K else K - 1      # leave the globally last one
+        if kv <= 0:
+            return False, 0
+        t = bt[:kv]
+        dt = np.diff(np.concatenate(([S.tj], t)))
+        dib = bd[:kv]
+        dib2 = dib * dib
+        zib = np.where(dib > 0, hi - bx[:kv], lo - bx[:kv])
+        inc2 = -theta * dib2
+        inc1x = dib2 - theta * dib * zib
+        if col > 0:
+            W = np.concatenate((bwy[:kv], theta * bws[:kv]), axis=1)
+            P_after = S.p - np.cumsum(dib[:, None] * W, axis=0)
+            P_before = np.vstack((S.p, P_after[:-1]))
+            C_after = S.c + np.cumsum(dt[:, None] * P_before, axis=0)
+            V = W.dot(mmat.T)
+            inc2 = inc2 + 2.0 * dib * np.sum(P_before * V, axis=1) - \
+                dib2 * np.sum(W * V, axis=1)
+            inc1x = inc1x + dib * np.sum(C_after * V, axis=1)
+        f2_after = S.f2 + np.cumsum(inc2)
+        clamp = f2_after < EPSMCH * f2_org
+        if np.any(clamp):
+            kv = int(np.argmax(clamp))        # scalar walk from there
+            f2_after = f2_after[:kv]
+        if kv <= 0:
+            return False, 0
+        f2_before = np.concatenate(([S.f2], f2_after[:kv - 1]))
+        f1_after = S.f1 + np.cumsum(dt[:kv] * f2_before + inc1x[:kv])
+        dtm_after = -f1_after / f2_after
+        dtm_before = np.concatenate(([S.dtm], dtm_after[:kv - 1]))
+        stop = dtm_before < dt[:kv]
+        stopped = bool(np.any(stop))
+        kdone = int(np.argmax(stop)) if stopped else kv
+        if kdone > 0:
+            j = kdone - 1
+            S.tj = S.tsum = float(t[j])
+            S.nleft -= kdone
+            S.t_done, S.i_done = float(t[j]), int(bi[j])
+            S.f1, S.f2 = float(f1_after[j]), float(f2_after[j])
+            S.dtm = float(dtm_after[j])
+            if col > 0:
+                S.p = P_after[j].copy()
+                S.c = C_after[j].copy()
+        return stopped, kdone
+
     if nbreak > 0:
-        tj = 0.0
-        nleft = nbreak
+        walker = None
+        if hasattr(be, "breakpoint_walker"):
+            walker = be.breakpoint_walker(tbk, d, ws, wy, theta, lo, hi,
+                                          f2_org, mmat)
+        fetch = None if walker else be.breakpoint_stream(tbk, d, ws, wy)
         finished = False
-        fetch = be.breakpoint_stream(tbk, d, ws, wy)
         while not finished:
-            batch = fetch(t_done, i_done, tsum + dtm)
             STATS["fetches"] += 1
-            if batch is None:
-                break                    # minimiser before the next breakpoint
-            bt, bi, bd, bx, bwy, bws = batch
-            k0 = 0
-            K = len(bt)
-            # ---- vectorised walk over all but the globally last breakpoint
-            kv = K if nleft > K else K - 1
-            if kv > 0:
-                t = bt[:kv]
-                dt = np.diff(np.concatenate(([tj], t)))
-                dib = bd[:kv]
-                dib2 = dib * dib
-                zib = np.where(dib > 0, hi - bx[:kv], lo - bx[:kv])
-                inc2 = -theta * dib2
-                inc1x = dib2 - theta * dib * zib
-                if col > 0:
-                    W = np.concatenate((bwy[:kv], theta * bws[:kv]), axis=1)
-                    P_after = p - np.cumsum(dib[:, None] * W, axis=0)
-                    P_before = np.vstack((p, P_after[:-1]))
-                    C_after = c + np.cumsum(dt[:, None] * P_before, axis=0)
-                    V = W.dot(mmat.T)
-                    wmc = np.sum(C_after * V, axis=1)
-                    wmp = np.sum(P_before * V, axis=1)
-                    wmw = np.sum(W * V, axis=1)
-                    inc2 = inc2 + 2.0 * dib * wmp - dib2 * wmw
-                    inc1x = inc1x + dib * wmc
-                f2_after = f2 + np.cumsum(inc2)
-                clamp = f2_after < EPSMCH * f2_org
-                if np.any(clamp):
-                    kv = int(np.argmax(clamp))      # scalar walk from there
-                    f2_after = f2_after[:kv]
-                if kv > 0:
-                    f2_before = np.concatenate(([f2], f2_after[:kv - 1]))
-                    f1_after = f1 + np.cumsum(dt[:kv] * f2_before +
-                                              inc1x[:kv])
-                    dtm_after = -f1_after / f2_after
-                    dtm_before = np.concatenate(([dtm], dtm_after[:kv - 1]))
-                    stop = dtm_before < dt[:kv]
-                    kdone = int(np.argmax(stop)) if np.any(stop) else kv
-                    if kdone > 0:
-                        j = kdone - 1
-                        tj = float(t[j])
-                        tsum = tj
-                        nleft -= kdone
-                        t_done, i_done = float(t[j]), int(bi[j])
-                        f1, f2 = float(f1_after[j]), float(f2_after[j])
-                        dtm = float(dtm_after[j])
-                        if col > 0:
-                            p = P_after[j].copy()
-                            c = C_after[j].copy()
-                    if kdone < kv or np.any(stop):
-                        finished = True
-                        break
-                    k0 = kdone
-            # ---- scalar walk (clamped f'' / last breakpoint)
-            for k in range(k0, K):
-                tj_new, ibp, dibp, xibp = bt[k], int(bi[k]), bd[k], bx[k]
-                dt1 = tj_new - tj
-                if dtm < dt1:
-                    finished = True
+            if walker:
+                r = walker(S)             # advances S over a sorted window
+                if r is None:
+                    break                 # minimiser before the next breakpoint
+                finished, tail = r
+                if not finished and tail is not None:
+                    finished = scalar_walk(tail, 0)
+            else:
+                batch = fetch(S.t_done, S.i_done, S.tsum + S.dtm)
+                if batch is None:
                     break
-                tj = float(tj_new)
-                tsum += dt1
-                nleft -= 1
-                t_done, i_done = float(tj_new), ibp
-                zibp = (hi - xibp) if dibp > 0 else (lo - xibp)
-                if nleft == 0 and nbreak == n_total:
-                    dtm = dt1
-                    all_fixed = True
-                    finished = True
-                    break
-                dibp2 = dibp * dibp
-                f1 = f1 + dt1 * f2 + dibp2 - theta * dibp * zibp
-                f2 = f2 - theta * dibp2
-                if col > 0:
-                    c = c + dt1 * p
-                    wbp = np.concatenate((bwy[k], theta * bws[k]))
-                    v = mmat.dot(wbp)
-                    wmc = float(np.dot(c, v))
-                    wmp = float(np.dot(p, v))
-                    wmw = float(np.dot(wbp, v))
-                    p = p - dibp * wbp
-                    f1 += dibp * wmc
-                    f2 += 2.0 * dibp * wmp - dibp2 * wmw
-                f2 = max(EPSMCH * f2_org, f2)
-                if nleft > 0:
-                    dtm = -f1 / f2
-                elif bnded:
-                    f1 = f2 = dtm = 0.0
-                    finished = True
-                    break
-                else:
-                    dtm = -f1 / f2
-                    finished = True
-                    break
-    if nbreak > 0:
-        STATS["crossed"] += nbreak - nleft
-    if not all_fixed:
-        if dtm <= 0.0:
-            dtm = 0.0
-        tsum += dtm
-    xcp, iwhere = be.cauchy_finish(x, d, tbk, lo, hi, iwhere, tsum, t_done,
-                                   i_done, all_fixed)
+                finished, k0 = cumsum_walk(batch)
+                if not finished:
+                    finished = scalar_walk(batch, k0)
+        STATS["crossed"] += nbreak - S.nleft
+    if not S.all_fixed:
+        if S.dtm <= 0.0:
+            S.dtm = 0.0
+        S.tsum += S.dtm
+    xcp, iwhere = be.cauchy_finish(x, d, tbk, lo, hi, iwhere, S.tsum,
+                                   S.t_done, S.i_done, S.all_fixed)
+    c = S.c
     if col > 0:
-        c = c + dtm * p
+        c = c + S.dtm * S.p
     return xcp, c, iwhere
 
 

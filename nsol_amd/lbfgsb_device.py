@@ -195,6 +195,114 @@ class DeviceBackend(object):
             return (t, ii, dv, xv, wyv, wsv)
         return fetch
 
+    def breakpoint_walker(self, tbk, d, ws_list, wy_list, theta, lo, hi,
+                          f2_org, mmat):
+        """Device walk of the crossed breakpoints: window -> compaction ->
+        radix sort by (t, index) -> prefix-sum walk (nsol_lb_cauchy_walk_*).
+        The returned callable advances the path state in place and answers
+        None (no breakpoint before the minimiser), (True, None) (search over) or
+        (False, tail) where `tail` is a one-element host batch that needs the
+        scalar rule (clamped f'' or the globally last breakpoint)."""
+        x = self._x
+        dev = tbk.device
+        n = tbk.numel()
+        cap = min(self.CAPACITY, n)
+        col = len(ws_list)
+        f32 = tbk.dtype == torch.float32
+        lib = _lib.load()
+        idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        event = torch.zeros(2, dtype=torch.int32, device=dev)
+        out = torch.empty(8 + 4 * max(col, 1), dtype=torch.float64, device=dev)
+        sel = _fn("select", tbk)
+        gat = _fn("gather", tbk)
+        srt = _fn("sort_candidates", tbk)
+        cntw = _fn("count_window", tbk)
+        walk = _fn("cauchy_walk", tbk)
+        PW = ctypes.c_void_p * max(col, 1)
+        wy_p = PW(*[w.data_ptr() for w in wy_list])
+        ws_p = PW(*[w.data_ptr() for w in ws_list])
+        buf = {}
+
+        def scratch(name, count, dtype):
+            t = buf.get(name)
+            if t is None or t.numel() < count:
+                t = torch.empty(int(count), dtype=dtype, device=dev)
+                buf[name] = t
+            return t
+
+        def host_rows(k_from, k_to):
+            sub = idx[k_from:k_to].contiguous()
+            m = k_to - k_from
+
+            def g(src):
+                o = torch.empty(m, dtype=src.dtype, device=dev)
+                self._check(gat(_p(src), _p(sub), m, _p(o), stream_ptr()),
+                            "gather")
+                return o.cpu().numpy().astype(np.float64)
+            wyv = np.stack([g(w) for w in wy_list], 1) if col else \
+                np.zeros((m, 0))
+            wsv = np.stack([g(w) for w in ws_list], 1) if col else \
+                np.zeros((m, 0))
+            return (g(tbk), sub.cpu().numpy(), g(d), g(x), wyv, wsv)
+
+        def advance(S):
+            lim = (S.tsum + S.dtm) * (1.0 + (1e-6 if f32 else 1e-12)) + 1e-300
+            wsb, res = self._bufs(tbk)
+            while True:
+                self._check(cntw(_p(tbk), n, float(S.t_done), int(S.i_done),
+                                 float(lim), _p(res), _p(wsb), stream_ptr()),
+                            "count_window")
+                count = int(round(float(res[0].item())))
+                if count <= cap:
+                    break
+                base = max(S.t_done, 0.0)
+                lim = base + 0.5 * (lim - base)
+            if count == 0:
+                return None
+            self._check(sel(_p(tbk), n, float(S.t_done), int(S.i_done),
+                            float(lim), _p(idx), cap, _p(cnt), stream_ptr()),
+                        "select")
+            tmp = scratch("sort", lib.nsol_lb_sort_tmp_bytes(
+                count, 4 if f32 else 8), torch.uint8)
+            self._check(srt(_p(tbk), _p(idx), count, _p(tmp), tmp.numel(),
+                            stream_ptr()), "sort_candidates")
+            kv = count if S.nleft > count else count - 1
+            kdone, stopped, clamp_at = 0, False, -1
+            if kv > 0:
+                table = scratch("table", lib.nsol_lb_walk_table_doubles(
+                    kv, col), torch.float64)
+                stmp = scratch("scan", lib.nsol_lb_walk_tmp_bytes(kv),
+                               torch.uint8)
+                params = torch.from_numpy(np.concatenate(
+                    (S.p, S.c, mmat.reshape(-1) if col else np.zeros(0)))
+                ).to(dev) if col else None
+                self._check(walk(
+                    _p(tbk), _p(d), _p(x), _p(idx), kv,
+                    ctypes.cast(wy_p, ctypes.c_void_p),
+                    ctypes.cast(ws_p, ctypes.c_void_p), col, float(theta),
+                    float(lo), float(hi), float(S.tj), float(S.f1),
+                    float(S.f2), float(f2_org), float(S.dtm), _p(params),
+                    _p(table), _p(stmp), stmp.numel(), _p(event), _p(out),
+                    stream_ptr()), "cauchy_walk")
+                o = out.cpu().numpy()
+                kdone, stopped, clamp_at = int(o[0]), o[1] > 0.5, int(o[2])
+                if kdone > 0:
+                    S.tj = S.tsum = float(o[3])
+                    S.nleft -= kdone
+                    S.t_done, S.i_done = float(o[3]), int(o[4])
+                    S.f1, S.f2, S.dtm = float(o[5]), float(o[6]), float(o[7])
+                    if col:
+                        S.p = o[8:8 + 2 * col].copy()
+                        S.c = o[8 + 2 * col:8 + 4 * col].copy()
+            if stopped:
+                return True, None
+            if kdone < count and (kdone == clamp_at or kdone == kv):
+                # clamped f'' or the globally last breakpoint: scalar rule
+                return False, host_rows(kdone, kdone + 1)
+            return False, None
+        return advance
+
     def cauchy_finish(self, x, d, tbk, lo, hi, iwhere, tsum, t_done, i_done,
                       all_fixed):
         xcp = torch.empty_like(x)
