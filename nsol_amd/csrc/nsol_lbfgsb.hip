@@ -50,17 +50,29 @@ __device__ __forceinline__ void block_partials(double (&a)[NV], double *ws,
   }
 }
 
+// one workgroup: every wave strides over the partials of one statistic after
+// the other (fixed order -> deterministic)
 __global__ __launch_bounds__(kBlock) void k_final(const double *ws, int nparts,
                                                    int nv, bool is_max,
                                                    double *result) {
-  if ((int)threadIdx.x < nv) {
-    const int k = threadIdx.x;
-    double t = ws[(int64_t)k * kRed];
-    for (int j = 1; j < nparts; ++j) {
+  __shared__ double s[kBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  for (int k = 0; k < nv; ++k) {
+    double t = is_max ? -INFINITY : 0.0;
+    for (int j = threadIdx.x; j < nparts; j += kBlock) {
       const double v = ws[(int64_t)k * kRed + j];
       t = is_max ? fmax(t, v) : t + v;
     }
-    result[k] = t;
+    t = is_max ? wmaxd(t) : wsum(t);
+    if (lane == 0) s[wv] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = s[0];
+      for (int j = 1; j < kBlock / kWave; ++j)
+        r = is_max ? fmax(r, s[j]) : r + s[j];
+      result[k] = r;
+    }
+    __syncthreads();
   }
 }
 
@@ -170,26 +182,35 @@ __global__ __launch_bounds__(kBlock) void k_select(const T *__restrict__ tbk,
                                                     int64_t i_done, T t_hi,
                                                     int64_t *out, int capacity,
                                                     int *count) {
-  // one atomic per wave: lanes that hold a candidate take consecutive slots
+  // one atomic per workgroup and sweep: waves publish their candidate counts
+  // in LDS, wave 0 reserves the range, lanes take consecutive slots
+  __shared__ int s_cnt[kBlock / kWave];
+  __shared__ int s_base;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
-  for (int64_t base = first - lane; base < n; base += stride) {
-    const int64_t i = base + lane;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
     bool take = false;
     if (i < n) {
       const T t = tbk[i];
       take = t <= t_hi && (t > t_done || (t == t_done && i > i_done));
     }
     const unsigned long long mask = __ballot(take);
-    if (mask == 0ull) continue;
-    int wave_base = 0;
-    if (lane == 0) wave_base = atomicAdd(count, __popcll(mask));
-    wave_base = __shfl(wave_base, 0, kWave);
+    if (lane == 0) s_cnt[wv] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int k = 0; k < kBlock / kWave; ++k) tot += s_cnt[k];
+      s_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
     if (take) {
-      const int slot = wave_base + __popcll(mask & ((1ull << lane) - 1ull));
+      int off = s_base;
+      for (int k = 0; k < wv; ++k) off += s_cnt[k];
+      const int slot = off + __popcll(mask & ((1ull << lane) - 1ull));
       if (slot < capacity) out[slot] = i;
     }
+    __syncthreads();
   }
 }
 
