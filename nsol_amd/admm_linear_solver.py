@@ -17,6 +17,7 @@ from .bridge import BridgedCallable
 from .device import is_device_tensor
 from .linear_solver import LinearSolver
 from .symbolic import trace_operator
+from ._accessors import add_accessors
 from . import tikhonov_linear_solver as tk
 
 
@@ -38,21 +39,6 @@ class ADMMLinearSolver(LinearSolver):
         self._rho = float(rho)
         self._iterations = iterations
         self._execution = None
-
-    def set_rho(self, rho):
-        self._rho = rho
-
-    def get_rho(self):
-        return self._rho
-
-    def get_dimension(self):
-        return self._dimension
-
-    def set_iterations(self, iterations):
-        self._iterations = iterations
-
-    def get_iterations(self):
-        return self._iterations
 
     def get_execution(self):
         return self._execution
@@ -141,3 +127,7 @@ class ADMMLinearSolver(LinearSolver):
     def _get_cost_regularization_term(self, x):
         from .prior_measures import PriorMeasures
         return PriorMeasures.total_variation(x, self._B, self._dimension)
+
+
+add_accessors(ADMMLinearSolver, ["rho", "iterations"])
+add_accessors(ADMMLinearSolver, ["dimension"], setters=False)

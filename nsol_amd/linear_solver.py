@@ -7,6 +7,7 @@ from .bridge import BridgedCallable
 from .device import is_device_tensor, to_device, to_numpy, torch_dtype
 from .loss_functions import LossFunctions as lf
 from .solver import Solver
+from ._accessors import add_accessors
 
 
 class LinearSolver(Solver):
@@ -38,49 +39,16 @@ class LinearSolver(Solver):
         return to_device(np.asarray(v, dtype=np.float64).reshape(-1),
                          self._dtype)
 
-    def get_A(self):
-        return self._A
-
-    def get_A_adj(self):
-        return self._A_adj
-
     def get_b(self):
         if is_device_tensor(self._b):
             return to_numpy(ops.scale(self._b, self._x_scale))
         return np.array(self._b) * self._x_scale
-
-    def set_alpha(self, alpha):
-        self._alpha = alpha
-
-    def get_alpha(self):
-        return self._alpha
 
     def set_data_loss(self, data_loss):
         if data_loss not in lf.get_loss.keys():
             raise ValueError("data_loss must be in " +
                              str(lf.get_loss.keys()))
         self._data_loss = data_loss
-
-    def get_data_loss(self):
-        return self._data_loss
-
-    def set_data_loss_scale(self, data_loss_scale):
-        self._data_loss_scale = data_loss_scale
-
-    def get_data_loss_scale(self):
-        return self._data_loss_scale
-
-    def set_minimizer(self, minimizer):
-        self._minimizer = minimizer
-
-    def get_minimizer(self):
-        return self._minimizer
-
-    def set_iter_max(self, iter_max):
-        self._iter_max = iter_max
-
-    def get_iter_max(self):
-        return self._iter_max
 
     # ---- costs at the current iterate (linear_solver.py:242-312)
     def _current(self):
@@ -134,3 +102,8 @@ class LinearSolver(Solver):
 
     def _get_cost_regularization_term(self, x):
         raise NotImplementedError
+
+
+add_accessors(LinearSolver, ["A", "A_adj", "data_loss"], setters=False)
+add_accessors(LinearSolver, ["alpha", "data_loss_scale", "minimizer",
+                             "iter_max"])

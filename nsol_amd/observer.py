@@ -1,50 +1,43 @@
-"""Iteration observer (drop-in for nsol/observer.py:21-161): keeps a host copy
-of every iterate the solver reports and evaluates user measures afterwards.
-Attaching an observer forces one device-to-host copy per iteration."""
+"""Iteration observer (API of nsol/observer.py:21-161).
+
+The solvers hand it a host copy of every iterate (`add_x`), user-supplied
+measure callables are evaluated afterwards over that history.  Attaching an
+observer therefore costs one device-to-host copy per iteration; the fused
+solvers step iteration by iteration instead of enqueueing the whole run."""
 import numpy as np
+
+from ._accessors import add_accessors
 
 
 class Observer(object):
 
     def __init__(self, name="Observer"):
         self._name = name
-        self._x_list = []
-        self._measures = []
-        self._measures_names = []
-        self._dic_measures = {}
         self._computational_time = None
+        self._x_list = []
+        self._functions = {}        # measure name -> callable(x) -> float
+        self._values = {}           # measure name -> np.ndarray over history
 
     def add_x(self, x):
         self._x_list.append(x)
 
-    def set_name(self, name):
-        self._name = name
-
-    def get_name(self):
-        return self._name
-
     def clear_x_list(self):
-        self._x_list = []
-
-    def get_x_list(self):
-        return self._x_list
+        del self._x_list[:]
 
     def set_measures(self, measures_dic):
-        for name, fn in measures_dic.items():
-            self._measures_names.append(name)
-            self._measures.append(fn)
-            self._dic_measures[name] = None
+        for key, fn in measures_dic.items():
+            self._functions[key] = fn
+            self._values.setdefault(key, None)
 
     def get_measures(self):
-        return self._dic_measures
-
-    def set_computational_time(self, computational_time):
-        self._computational_time = computational_time
-
-    def get_computational_time(self):
-        return self._computational_time
+        return self._values
 
     def compute_measures(self):
-        for name, fn in zip(self._measures_names, self._measures):
-            self._dic_measures[name] = np.array(
-                [fn(x) for x in self._x_list], dtype=float)
+        history = self._x_list
+        for key, fn in self._functions.items():
+            self._values[key] = np.fromiter((fn(x) for x in history),
+                                            dtype=float, count=len(history))
+
+
+add_accessors(Observer, ["name", "computational_time"])
+add_accessors(Observer, ["x_list"], setters=False)

@@ -20,6 +20,7 @@ from .bridge import BridgedCallable
 from .device import is_device_tensor
 from .proximal_operators import scaled_data_on_device
 from .solver import Solver
+from ._accessors import add_accessors
 from .symbolic import TauSym, trace_operator, trace_prox
 
 
@@ -78,30 +79,6 @@ class PrimalDualSolver(Solver):
         self._iterations = iterations
         self._alg_type = alg_type
         self._execution = None
-
-    def set_alpha(self, alpha):
-        self._alpha = alpha
-
-    def get_alpha(self):
-        return self._alpha
-
-    def set_L2(self, L2):
-        self._L2 = L2
-
-    def get_L2(self):
-        return self._L2
-
-    def set_alg_type(self, alg_type):
-        self._alg_type = alg_type
-
-    def get_alg_type(self):
-        return self._alg_type
-
-    def set_iterations(self, iterations):
-        self._iterations = iterations
-
-    def get_iterations(self):
-        return self._iterations
 
     def get_execution(self):
         """'fused', 'device' or 'host' after run() (None before)."""
@@ -225,3 +202,6 @@ class PrimalDualSolver(Solver):
         self._x = x
         self._execution = "device" if all(
             c.on_device for c in (B, Bc, pg, pf)) else "host"
+
+
+add_accessors(PrimalDualSolver, ["alpha", "L2", "alg_type", "iterations"])

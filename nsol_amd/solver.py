@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 from . import ops
+from ._accessors import add_accessors
 from .device import (get_default_dtype, is_device_tensor, to_device, to_numpy,
                      torch_dtype)
 
@@ -48,21 +49,6 @@ class Solver(object):
             self._x0_dev = to_device(self._x0_host.reshape(-1), self._dtype)
         return self._x0_dev
 
-    def get_dtype(self):
-        return self._dtype
-
-    def set_x_scale(self, x_scale):
-        self._x_scale = x_scale
-
-    def get_x_scale(self):
-        return self._x_scale
-
-    def set_verbose(self, verbose):
-        self._verbose = verbose
-
-    def get_verbose(self):
-        return self._verbose
-
     def set_x0(self, x0):
         self._set_x0(x0)
 
@@ -81,12 +67,6 @@ class Solver(object):
         if self._x is None and self._x0_host is not None:
             return np.array(self._x0_host) * self._x_scale
         return to_numpy(self.get_x_device())
-
-    def get_computational_time(self):
-        return self._computational_time
-
-    def set_observer(self, observer):
-        self._observer = observer
 
     def run(self):
         if self._x0_ndim != 1:
@@ -109,3 +89,7 @@ class Solver(object):
 
     def print_statistics(self):
         raise NotImplementedError
+
+
+add_accessors(Solver, ["x_scale", "verbose", "observer"])
+add_accessors(Solver, ["computational_time", "dtype"], setters=False)

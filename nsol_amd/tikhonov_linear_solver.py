@@ -24,6 +24,7 @@ from .device import is_device_tensor, to_device, to_numpy
 from .linear_solver import LinearSolver
 from .lsmr import lsmr, lsmr_fused
 from .symbolic import trace_operator
+from ._accessors import add_accessors
 
 
 # set to False to force the generic (un-fused) LSMR vector kernels
@@ -49,12 +50,6 @@ class TikhonovLinearSolver(LinearSolver):
         self._B_adj = B_adj
         self._b_reg = self._scaled(b_reg)          # tikhonov :91
         self._bounds = bounds
-
-    def get_B(self):
-        return self._B
-
-    def get_B_adj(self):
-        return self._B_adj
 
     def get_b_reg(self):
         if is_device_tensor(self._b_reg):
@@ -285,3 +280,6 @@ class TikhonovLinearSolver(LinearSolver):
         B = BridgedCallable(self._B, self._dtype)
         Ba = BridgedCallable(self._B_adj, self._dtype)
         return Ba(B(self._dev(x)))
+
+
+add_accessors(TikhonovLinearSolver, ["B", "B_adj"], setters=False)
