@@ -85,7 +85,7 @@ def cpu_baseline(sample_n, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--data", default="L2", choices=["L2", "L1"])
