@@ -53,7 +53,9 @@ class ADMMLinearSolver(LinearSolver):
         B = BridgedCallable(self._B, self._dtype)
         desc = trace_operator(self._B, n)
         fused = desc is not None and desc[0] == "grad" and \
-            desc[1].dimension == self._dimension
+            desc[1].dimension == self._dimension and \
+            len(desc[2]) == self._dimension and \
+            int(np.prod(desc[2])) == n
         self._execution = "fused-outer" if fused else "generic-outer"
 
         scalar_c = not is_device_tensor(self._b_reg) and \

@@ -97,7 +97,7 @@ class PrimalDualSolver(Solver):
         if dB is None or dB[0] != "grad":
             return None
         gop, shape = dB[1], dB[2]
-        if int(np.prod(shape)) != n:
+        if int(np.prod(shape)) != n or len(shape) != gop.dimension:
             return None
         dBt = trace_operator(self._B_conj, gop.dimension * n)
         if dBt is None or dBt[0] != "grad_adj":

@@ -154,6 +154,8 @@ class TikhonovLinearSolver(LinearSolver):
                 return None
         elif dB[0] == "grad":
             gop, shape = dB[1], tuple(dB[2])
+            if len(shape) != gop.dimension or int(np.prod(shape)) != n:
+                return None
             dBt = trace_operator(self._B_adj, gop.dimension * n)
             if dBt is None or dBt[0] != "grad_adj" or \
                     tuple(dBt[1].w) != tuple(gop.w) or \

@@ -138,6 +138,12 @@ def test_plan_rejects_foreign_or_modified_callables():
     s, b = _wired_solver(obs)
     s._B_conj = s._B                                      # not the adjoint
     assert s.plan() is None
+    # a 3-D operator handed a flat array without the caller-side reshape
+    import nsol_amd.linear_operators as LO
+    grad3, _ = LO.LinearOperators3D().get_gradient_operators()
+    s, b = _wired_solver(obs)
+    s._B = grad3
+    assert s.plan() is None
 
 
 def test_solver_api_surface_without_gpu():
