@@ -19,9 +19,11 @@
  *  - wx, wy, wz are the INVERSE spacings 1/h of the x, y, z axes
  *    (reference kernels.py:102-112,160-190,240-286 scale taps by 1/spacing);
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
- *  - functions are stateless, never allocate, never synchronise, never throw;
- *    they return 0 on success, a positive hipError_t on a HIP failure and
- *    NSOL_EINVAL (-1) on bad arguments;
+ *  - functions keep no state between calls, never allocate, never synchronise,
+ *    never throw; they return 0 on success, a positive hipError_t on a HIP
+ *    failure and NSOL_EINVAL (-1) on bad arguments.  (The only process-wide
+ *    state are the experiment knobs of nsol_hip_set_param / _pd2(name, value)
+ *    -- tile shapes, z-chunk length -- which never change results.);
  *  - suffix _f32 / _f64 = element type of all volume arguments.  Scalars are
  *    always passed as double and rounded to the element type inside.
  */
