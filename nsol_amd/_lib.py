@@ -71,6 +71,8 @@ def load():
     lib.nsol_lb_walk_table_doubles.argtypes = [c_int, c_int]
     lib.nsol_lb_walk_tmp_bytes.restype = c_i64
     lib.nsol_lb_walk_tmp_bytes.argtypes = [c_int]
+    lib.nsol_hip_set_param_conv.restype = c_int
+    lib.nsol_hip_set_param_conv.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_hip_set_param_pd2.restype = c_int
     lib.nsol_hip_set_param_pd2.argtypes = [ctypes.c_char_p, c_int]
     if lib.nsol_hip_abi_version() != 1:
@@ -89,5 +91,6 @@ def check(rc, what):
 def set_param(name, value):
     lib = load()
     fn = lib.nsol_hip_set_param_pd2 if name.startswith("pd2_") \
-        else lib.nsol_hip_set_param
+        else (lib.nsol_hip_set_param_conv if name.startswith("corr_")
+              else lib.nsol_hip_set_param)
     check(fn(name.encode(), int(value)), "set_param")

@@ -1,6 +1,8 @@
 // Correlation kernels behind the Gaussian blur A = A^T (separable 1-D passes)
 // and arbitrary user kernels (dense taps), with scipy.ndimage's boundary modes.
 // reference call sites: linear_operators.py:60-68, 82-86 (ndimage.convolve).
+#include <string.h>
+
 #include "nsol_common.hpp"
 
 using namespace nsol;
@@ -168,16 +170,17 @@ __global__ __launch_bounds__(kBlock) void k_corr_strided_wrap(
   }
 }
 
-template <typename T, int VEC, int NT>
+template <typename T, int VEC, int NT, int XV>
 __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
     const T *__restrict__ x, T *__restrict__ out, int64_t nrows, int64_t nx,
     Taps<T> taps) {
+  // a lane produces XV adjacent output vectors from XV + 2*NBH input vectors
   typedef typename VecOf<T, VEC>::type V;
   constexpr int R = NT / 2;
   constexpr int NBH = (R + VEC - 1) / VEC;  // vectors on each side
-  constexpr int NB = 2 * NBH + 1;
+  constexpr int NB = 2 * NBH + XV;
   const int64_t nxv = nx / VEC;
-  const int64_t xv = (int64_t)blockIdx.y * 64 + (threadIdx.x & 63);
+  const int64_t xv = ((int64_t)blockIdx.y * 64 + (threadIdx.x & 63)) * XV;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (xv >= nxv || row >= nrows) return;
   const T *rp = x + row * nx;
@@ -190,27 +193,60 @@ __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
 #pragma unroll
     for (int k = 0; k < VEC; ++k) win[b * VEC + k] = v[k];
   }
-  V res;
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) {
-    T acc = taps.w[0] * win[NBH * VEC + k - R];
+  for (int o = 0; o < XV; ++o) {
+    if (xv + o < nxv) {
+      V res;
 #pragma unroll
-    for (int t = 1; t < NT; ++t) acc += taps.w[t] * win[NBH * VEC + k - R + t];
-    res[k] = acc;
+      for (int k = 0; k < VEC; ++k) {
+        T acc = taps.w[0] * win[(NBH + o) * VEC + k - R];
+#pragma unroll
+        for (int t = 1; t < NT; ++t)
+          acc += taps.w[t] * win[(NBH + o) * VEC + k - R + t];
+        res[k] = acc;
+      }
+      *reinterpret_cast<V *>(out + row * nx + (xv + o) * VEC) = res;
+    }
   }
-  *reinterpret_cast<V *>(out + row * nx + xv * VEC) = res;
+}
+
+int g_corr_ra = 8;   // outputs per lane along a strided axis (experiment knob)
+int g_corr_xv = 1;   // output vectors per lane in the x pass (experiment knob)
+
+template <typename T, int VEC, int NT, int RA>
+int launch_strided(const T *x, T *out, int axis, int64_t nz, int64_t ny,
+                   int64_t nx, const Taps<T> &taps, hipStream_t st) {
+  const int64_t nxv = nx / VEC;
+  const int64_t len = axis == 0 ? nz : ny;
+  const int64_t other = axis == 0 ? ny : nz;
+  dim3 grid((unsigned)((other + 3) / 4), (unsigned)((nxv + 63) / 64),
+            (unsigned)((len + RA - 1) / RA));
+  hipLaunchKernelGGL((k_corr_strided_wrap<T, VEC, NT, RA>), grid, dim3(kBlock), 0,
+                     st, x, out, nz, ny, nx, axis, taps);
+  return launch_status();
 }
 
 template <typename T, int VEC, int NT>
 int launch_wrap_nt(const T *x, T *out, int axis, int64_t nz, int64_t ny,
                    int64_t nx, const Taps<T> &taps, hipStream_t st) {
+  if (axis != 2 && g_corr_ra == 8)
+    return launch_strided<T, VEC, NT, 8>(x, out, axis, nz, ny, nx, taps, st);
+  if (axis != 2 && g_corr_ra == 2)
+    return launch_strided<T, VEC, NT, 2>(x, out, axis, nz, ny, nx, taps, st);
+  if (axis == 2 && g_corr_xv == 2) {
+    const int64_t nrows2 = nz * ny, nxv2 = nx / VEC;
+    dim3 grid((unsigned)((nrows2 + 3) / 4), (unsigned)((nxv2 + 127) / 128), 1);
+    hipLaunchKernelGGL((k_corr_x_wrap<T, VEC, NT, 2>), grid, dim3(kBlock), 0, st,
+                       x, out, nrows2, nx, taps);
+    return launch_status();
+  }
   constexpr int RA = 4;
   const int64_t nxv = nx / VEC;
   if (axis == 2) {
     const int64_t nrows = nz * ny;
     dim3 grid((unsigned)((nrows + 3) / 4), (unsigned)((nxv + 63) / 64), 1);
-    hipLaunchKernelGGL((k_corr_x_wrap<T, VEC, NT>), grid, dim3(kBlock), 0, st, x,
-                       out, nrows, nx, taps);
+    hipLaunchKernelGGL((k_corr_x_wrap<T, VEC, NT, 1>), grid, dim3(kBlock), 0, st,
+                       x, out, nrows, nx, taps);
   } else {
     const int64_t len = axis == 0 ? nz : ny;
     const int64_t other = axis == 0 ? ny : nz;
@@ -284,6 +320,13 @@ int corr_dense_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
 }  // namespace
 
 extern "C" {
+int nsol_hip_set_param_conv(const char *name, int value) {
+  if (!name) return NSOL_EINVAL;
+  if (!strcmp(name, "corr_ra")) g_corr_ra = value;
+  else if (!strcmp(name, "corr_xv")) g_corr_xv = value;
+  else return NSOL_EINVAL;
+  return 0;
+}
 int nsol_corr_axis_f32(const float *x, float *out, int axis, int64_t nz,
                        int64_t ny, int64_t nx, const double *taps_host,
                        int ntaps, int centre, int mode, void *stream) {
