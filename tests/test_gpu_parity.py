@@ -556,6 +556,54 @@ def test_admm_with_vector_b_reg(nsol, golden):
     assert rel_l2(s.get_x(), g["admm_breg"]) < 1e-9
 
 
+def test_cost_terms_and_statistics(nsol, golden, capsys):
+    """linear_solver.py:242-312: data / regulariser / total costs at the
+    current iterate, evaluated by the HIP reductions."""
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.admm_linear_solver as admm
+    from nsol_amd.prior_measures import PriorMeasures
+    from oracle import nsol_oracle as orc
+    g, shape, A, Aa, D, Da = _dec_ops(golden, "2d")
+    y = g["y_2d"]
+    xs = float(y.max())
+    Do, Dao, Ao, _ = orc.flat_operators(shape, None, g["cov_2d"])
+    s = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=D, B_adj=Da, b=y, x0=y,
+                                alpha=0.05, x_scale=xs, iter_max=5,
+                                data_loss="huber", data_loss_scale=0.1,
+                                minimizer="L-BFGS-B", dtype=np.float64)
+    s.run()
+    x = s.get_x() / xs
+    r = Ao(x) - y / xs
+    data = 0.5 * np.sum(orc.loss("huber", r ** 2, 0.1))
+    reg = 0.5 * np.sum(Do(x) ** 2)
+    assert np.isclose(s.get_cost_data_term(), data, rtol=1e-10)
+    assert np.isclose(s.get_ell2_cost_data_term(), 0.5 * np.sum(r ** 2),
+                      rtol=1e-10)
+    assert np.isclose(s.get_cost_regularization_term(), reg, rtol=1e-10)
+    assert np.isclose(s.get_total_cost(), data + 0.05 * reg, rtol=1e-10)
+    s.print_statistics()
+    assert "Total cost" in capsys.readouterr().out
+    a = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y,
+                              dimension=2, alpha=0.05, iterations=2,
+                              iter_max=4, x_scale=xs, dtype=np.float64)
+    a.run()
+    xa = a.get_x() / xs
+    gx = Do(xa).reshape(2, -1)
+    tv = np.sum(np.sqrt(gx[0] ** 2 + gx[1] ** 2))
+    assert np.isclose(a.get_cost_regularization_term(), tv, rtol=1e-10)
+    assert np.isclose(PriorMeasures.huber(xa, D, 2),
+                      np.sum(orc.loss("huber", gx[0] ** 2 + gx[1] ** 2) * 0 +
+                             np.where(gx[0] ** 2 + gx[1] ** 2 < 0.05 ** 2,
+                                      gx[0] ** 2 + gx[1] ** 2,
+                                      2 * 0.05 * np.sqrt(gx[0] ** 2 +
+                                                         gx[1] ** 2) -
+                                      0.05 ** 2) / (2 * 0.05)), rtol=1e-10)
+    assert np.isclose(PriorMeasures.zeroth_order_tikhonov(xa),
+                      0.5 * np.sum(xa ** 2), rtol=1e-12)
+    assert np.isclose(PriorMeasures.first_order_tikhonov(xa, D),
+                      0.5 * np.sum(Do(xa) ** 2), rtol=1e-12)
+
+
 def test_tikhonov_rejects_lsmr_with_robust_loss(nsol, golden):
     import nsol_amd.tikhonov_linear_solver as tk
     g, shape, A, Aa, D, Da = _dec_ops(golden, "1d")
