@@ -783,3 +783,118 @@ def test_full_size_512_properties(nsol):
     c = _run_pd_raw(shape, np.float32, 5, flags, enable2=0, two_pass=1)
     for u, v in zip(b[:3], c[:3]):
         assert torch.equal(u, v)
+
+
+def test_mid_size_parity_vs_oracle(nsol):
+    """Sizes the oracle still finishes in seconds: float32 drift of the
+    two-iteration kernel over 60 iterations at 96 x 96 x 256, and the fused ADMM
+    / LSMR path at 40^3 with the sigma = 2 blur of config 4."""
+    from oracle import nsol_oracle as orc
+    import nsol_amd.admm_linear_solver as admm
+    rng = np.random.default_rng(21)
+    shape = (96, 96, 256)
+    obs = orc.synth_volume(256, 5, "gauss")[:96, :96, :]
+    ref = orc.primal_dual_denoise(obs.flatten(), shape, "TV", "L2", 0.03, 60,
+                                  16.0, "ALG2")
+    s = _pd_solver(np.ascontiguousarray(obs), "TV", "L2", 0.03, 60, 16.0,
+                   "ALG2", np.float32)
+    s.run()
+    assert s.get_execution() == "fused"
+    assert rel_l2(s.get_x(), ref) < F32_TOL
+    # ADMM, config-4 operators at 40^3
+    shp = (40, 40, 40)
+    cov = np.diag([4.0, 4.0, 4.0])
+    lo = _lo(3)
+    A, A_adj = lo.get_gaussian_blurring_operators(cov)
+    grad, grad_adj = lo.get_gradient_operators()
+    Z = (120, 40, 40)
+    A_ = lambda x: A(x.reshape(*shp)).flatten()
+    Aa_ = lambda x: A_adj(x.reshape(*shp)).flatten()
+    D_ = lambda x: grad(x.reshape(*shp)).flatten()
+    Da_ = lambda x: grad_adj(x.reshape(*Z)).flatten()
+    Do, Dao, Ao, _ = orc.flat_operators(shp, None, cov)
+    clean = orc.synth_volume(40, 0, "clean")
+    y = Ao(clean.flatten())
+    y = y + 0.02 * y.max() * rng.standard_normal(y.size)
+    ref = orc.admm(Ao, Ao, Do, Dao, y, y, 3, alpha=0.01, rho=0.1,
+                   iterations=3, iter_max=10, x_scale=float(y.max()))
+    for dtype, tol in ((np.float64, 1e-9), (np.float32, 5e-5)):
+        a = admm.ADMMLinearSolver(A=A_, A_adj=Aa_, b=y, B=D_, B_adj=Da_, x0=y,
+                                  dimension=3, alpha=0.01, rho=0.1,
+                                  iterations=3, iter_max=10,
+                                  x_scale=float(y.max()), dtype=dtype)
+        a.run()
+        assert rel_l2(a.get_x(), ref) < tol
+
+
+def test_full_size_admm_path_properties(nsol):
+    """512^3 float32: <Ax, y> = <x, Ay> for the sigma = 2 blur, and the fused
+    LSMR kernels against the generic axpy / dot form on a TK1 solve."""
+    import torch
+    import nsol_amd.tikhonov_linear_solver as tk
+    from nsol_amd import ops
+    n = 512
+    shape = (n, n, n)
+    lo = _lo(3)
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(n ** 3, device="cuda", generator=gen)
+    y = torch.rand(n ** 3, device="cuda", generator=gen)
+    lhs = ops.dot(A(x.view(shape)).view(-1), y)
+    rhs = ops.dot(x, A(y.view(shape)).view(-1))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    del x
+    m = 256
+    shp = (m, m, m)
+    grad, grad_adj = lo.get_gradient_operators()
+    A_ = lambda v: A(v.reshape(*shp)).flatten()
+    D_ = lambda v: grad(v.reshape(*shp)).flatten()
+    Da_ = lambda v: grad_adj(v.reshape(3 * m, m, m)).flatten()
+    b = y[:m ** 3].contiguous()
+    outs = []
+    for fused in (True, False):
+        tk.USE_FUSED_LSMR = fused
+        try:
+            s = tk.TikhonovLinearSolver(A=A_, A_adj=A_, B=D_, B_adj=Da_, b=b,
+                                        x0=b, alpha=0.1, iter_max=6,
+                                        dtype=np.float32)
+            s.run()
+            outs.append(s.get_x_device())
+        finally:
+            tk.USE_FUSED_LSMR = True
+    d = ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, outs[1])) / \
+        ops.norm2(outs[1])
+    assert d < 2e-6
+
+
+def test_device_lbfgsb_vs_scipy_driver_at_64_cubed(nsol):
+    """A size SciPy's host driver still handles: ADMM + Huber through both
+    L-BFGS-B drivers give the same reconstruction."""
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.admm_linear_solver as admm
+    from nsol_amd.synthetic import synth_volume
+    n = 64
+    shp = (n, n, n)
+    lo = _lo(3)
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
+    grad, grad_adj = lo.get_gradient_operators()
+    A_ = lambda v: A(v.reshape(*shp)).flatten()
+    D_ = lambda v: grad(v.reshape(*shp)).flatten()
+    Da_ = lambda v: grad_adj(v.reshape(3 * n, n, n)).flatten()
+    y = A(synth_volume(n, 0, "clean")).flatten()
+    y = y + 0.02 * y.max() * np.random.default_rng(1).standard_normal(y.size)
+    outs = []
+    for device in (True, False):
+        tk.USE_DEVICE_LBFGSB = device
+        try:
+            s = admm.ADMMLinearSolver(A=A_, A_adj=A_, b=y, B=D_, B_adj=Da_,
+                                      x0=y, dimension=3, alpha=0.01, rho=0.1,
+                                      iterations=2, iter_max=10,
+                                      minimizer="L-BFGS-B", data_loss="huber",
+                                      x_scale=float(y.max()),
+                                      dtype=np.float64)
+            s.run()
+            outs.append(s.get_x())
+        finally:
+            tk.USE_DEVICE_LBFGSB = True
+    assert rel_l2(outs[0], outs[1]) < 1e-8
