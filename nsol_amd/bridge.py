@@ -30,7 +30,9 @@ class BridgedCallable(object):
                 if is_device_tensor(out):
                     self.on_device = True
                     return out.contiguous().view(-1)
-            except Exception:
+            except (TypeError, AttributeError, ValueError, RuntimeError):
+                # a NumPy-only callable choking on a device tensor; a genuine
+                # error re-surfaces from the host call below
                 pass
             self.on_device = False
             return self._host_call(t, *args)

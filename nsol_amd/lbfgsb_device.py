@@ -132,69 +132,6 @@ class DeviceBackend(object):
         self._x = x
         return d, tbk, iw, st
 
-    def breakpoint_stream(self, tbk, d, ws_list, wy_list):
-        x = self._x
-        dev = tbk.device
-        n = tbk.numel()
-        cap = min(self.CAPACITY, n)
-        idx = torch.empty(cap, dtype=torch.int64, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        sel = _fn("select", tbk)
-        gat = _fn("gather", tbk)
-        srt = _fn("sort_candidates", tbk)
-        cntw = _fn("count_window", tbk)
-        lib = _lib.load()
-        f32 = tbk.dtype == torch.float32
-
-        def gather(src, count):
-            out = torch.empty(count, dtype=src.dtype, device=dev)
-            self._check(gat(_p(src), _p(idx), count, _p(out), stream_ptr()),
-                        "gather")
-            return out.cpu().numpy().astype(np.float64)
-
-        def fetch(t_done, i_done, t_hi):
-            """Sorted batch (t, index, d, x, Y rows, S rows) of the breakpoints
-            after (t_done, i_done) up to t_hi, or None."""
-            # widen the window slightly: the host walk applies the exact test
-            lim = t_hi * (1.0 + (1e-6 if f32 else 1e-12)) + 1e-300
-            # size the window with the (atomic-free) counting pass, then
-            # compact once
-            wsb, res = self._bufs(tbk)
-            while True:
-                self._check(cntw(_p(tbk), n, float(t_done), int(i_done),
-                                 float(lim), _p(res), _p(wsb), stream_ptr()),
-                            "count_window")
-                count = int(round(float(res[0].item())))
-                if count <= cap:
-                    break
-                # too many candidates: halve the window above t_done
-                base = max(t_done, 0.0)
-                lim = base + 0.5 * (lim - base)
-            if count == 0:
-                return None
-            self._check(sel(_p(tbk), n, float(t_done), int(i_done),
-                            float(lim), _p(idx), cap, _p(cnt), stream_ptr()),
-                        "select")
-            assert int(cnt.item()) == count
-            # order the candidates by (t, index) on the device, then gather
-            need = int(lib.nsol_lb_sort_tmp_bytes(count, 4 if f32 else 8))
-            if self._tmp is None or self._tmp.numel() < need or \
-                    self._tmp.device != dev:
-                self._tmp = torch.empty(need, dtype=torch.uint8, device=dev)
-            self._check(srt(_p(tbk), _p(idx), count, _p(self._tmp),
-                            self._tmp.numel(), stream_ptr()),
-                        "sort_candidates")
-            t = gather(tbk, count)
-            ii = idx[:count].cpu().numpy()
-            dv = gather(d, count)
-            xv = gather(x, count)
-            wyv = np.stack([gather(w, count) for w in wy_list], 1) \
-                if wy_list else np.zeros((count, 0))
-            wsv = np.stack([gather(w, count) for w in ws_list], 1) \
-                if ws_list else np.zeros((count, 0))
-            return (t, ii, dv, xv, wyv, wsv)
-        return fetch
-
     def breakpoint_walker(self, tbk, d, ws_list, wy_list, theta, lo, hi,
                           f2_org, mmat):
         """Device walk of the crossed breakpoints: window -> compaction ->
