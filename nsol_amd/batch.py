@@ -38,6 +38,8 @@ def solve_batch(solve_one, n_items, group=None, dst=0):
             raise RuntimeError("rank %d owns no volume: use world_size <= "
                                "n_items" % rank)
         send = local[r] if have else torch.zeros_like(ref)
+        if send.is_cuda and dist.get_backend(group) == "gloo":
+            send = send.cpu()      # rehearsal without RCCL: stage through host
         if rank == dst:
             bucket = [torch.empty_like(send) for _ in range(world)]
             dist.gather(send, gather_list=bucket, dst=dst, group=group)
