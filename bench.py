@@ -197,6 +197,30 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
         del bucket
 
+    # for reference: the one-iteration-per-pass kernel on the same state
+    single = None
+    if world == 1 and args.steps >= 2:
+        _lib.set_param("pd2_enable", 0)
+        try:
+            k1 = 40
+            sg1, ta1, th1 = step_schedule("ALG2", 16.0, lmbda, k1)
+            f0, f1 = ev.create(), ev.create()
+            ops.pd_run(xbar[0], xbar[1], x_alt, bt, p[0], p[1], shape, w,
+                       lmbda, sg1[:4], ta1[:4], th1[:4], False, 0.05, flags)
+            ev.record(f0, stream)
+            ops.pd_run(xbar[0], xbar[1], x_alt, bt, p[0], p[1], shape, w,
+                       lmbda, sg1, ta1, th1, False, 0.05, flags)
+            ev.record(f1, stream)
+            torch.cuda.synchronize()
+            ms1 = ev.elapsed_ms(f0, f1) / k1
+            single = {"kernel": "k_pd_fused (one iteration per launch)",
+                      "avg_launch_ms": ms1, "iterations_per_s": 1e3 / ms1,
+                      "achieved": BYTES_PER_VOXEL * nvox / (ms1 * 1e-3) / 1e9,
+                      "frac": BYTES_PER_VOXEL * nvox / (ms1 * 1e-3) / 1e9 /
+                      HBM_PEAK_GBPS}
+        finally:
+            _lib.set_param("pd2_enable", 1)
+
     finite = bool(torch.isfinite(x).all().item())
 
     if rank == 0:
@@ -230,7 +254,8 @@ def main():
                 "avg_launch_ms": kernel_ms,
                 # what the memory system actually carries (PMC, per launch)
                 "traffic_rate_GBps": (measured_traffic(n) / (kernel_ms * 1e-3)
-                                      / 1e9) if measured_traffic(n) else None},
+                                      / 1e9) if measured_traffic(n) else None,
+                "single_pass_reference": single},
         }
         if world == 1 and not args.no_cpu_baseline:
             sn = args.cpu_sample
