@@ -237,6 +237,27 @@ int nsol_pd_fused2_iter_f64(const double *xbar_in, double *xbar_out,
                             const double *sigma_2, const double *hden_2,
                             const double *tau_2, const double *tl_2,
                             const double *theta_2, int flags, void *stream);
+/* K = 2 or 3 iterations in a single pass over memory on 2-D tiled footprints
+ * (temporal blocking of depth K; 11 words per voxel for all K).  sigma_k ...
+ * theta_k are HOST arrays of k doubles (iterations n .. n+k-1).  Same aliasing
+ * rules and -2 convention as nsol_pd_fused2_iter_*; results are bit-identical
+ * to k calls of nsol_pd_fused_iter_*. */
+int nsol_pd_fusedk_iter_f32(const float *xbar_in, float *xbar_out,
+                            const float *x_in, float *x_out, const float *bt,
+                            const float *p_in, float *p_out, int ndim,
+                            int64_t nz, int64_t ny, int64_t nx, double wx,
+                            double wy, double wz, int k, const double *sigma_k,
+                            const double *hden_k, const double *tau_k,
+                            const double *tl_k, const double *theta_k,
+                            int flags, void *stream);
+int nsol_pd_fusedk_iter_f64(const double *xbar_in, double *xbar_out,
+                            const double *x_in, double *x_out,
+                            const double *bt, const double *p_in,
+                            double *p_out, int ndim, int64_t nz, int64_t ny,
+                            int64_t nx, double wx, double wy, double wz, int k,
+                            const double *sigma_k, const double *hden_k,
+                            const double *tau_k, const double *tl_k,
+                            const double *theta_k, int flags, void *stream);
 /* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;

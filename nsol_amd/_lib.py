@@ -75,6 +75,8 @@ def load():
     lib.nsol_hip_set_param_conv.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_hip_set_param_pd2.restype = c_int
     lib.nsol_hip_set_param_pd2.argtypes = [ctypes.c_char_p, c_int]
+    lib.nsol_hip_set_param_pdk.restype = c_int
+    lib.nsol_hip_set_param_pdk.argtypes = [ctypes.c_char_p, c_int]
     if lib.nsol_hip_abi_version() != 1:
         raise NsolHipError("libnsol_hip.so ABI version mismatch")
     _lib = lib
@@ -90,7 +92,12 @@ def check(rc, what):
 
 def set_param(name, value):
     lib = load()
-    fn = lib.nsol_hip_set_param_pd2 if name.startswith("pd2_") \
-        else (lib.nsol_hip_set_param_conv if name.startswith("corr_")
-              else lib.nsol_hip_set_param)
+    if name.startswith("pd2_"):
+        fn = lib.nsol_hip_set_param_pd2
+    elif name.startswith("pdk_"):
+        fn = lib.nsol_hip_set_param_pdk
+    elif name.startswith("corr_"):
+        fn = lib.nsol_hip_set_param_conv
+    else:
+        fn = lib.nsol_hip_set_param
     check(fn(name.encode(), int(value)), "set_param")

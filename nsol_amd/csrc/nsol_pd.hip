@@ -484,6 +484,25 @@ inline int fused2_call(const double *a, double *b, const double *c, double *d,
                                  s, h, t, tl, th, flags, st);
 }
 
+inline int fusedk_call(const float *a, float *b, const float *c, float *d,
+                       const float *e, const float *f, float *g, int ndim,
+                       int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                       double wz, int k, const double *s, const double *h,
+                       const double *t, const double *tl, const double *th,
+                       int flags, void *st) {
+  return nsol_pd_fusedk_iter_f32(a, b, c, d, e, f, g, ndim, nz, ny, nx, wx, wy, wz,
+                                 k, s, h, t, tl, th, flags, st);
+}
+inline int fusedk_call(const double *a, double *b, const double *c, double *d,
+                       const double *e, const double *f, double *g, int ndim,
+                       int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                       double wz, int k, const double *s, const double *h,
+                       const double *t, const double *tl, const double *th,
+                       int flags, void *st) {
+  return nsol_pd_fusedk_iter_f64(a, b, c, d, e, f, g, ndim, nz, ny, nx, wx, wy, wz,
+                                 k, s, h, t, tl, th, flags, st);
+}
+
 template <typename T>
 int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
              int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
@@ -502,21 +521,35 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
     const T *pin = (n == 0 && p_is_zero) ? nullptr : pp[slot];
     int rc = -2;
     if (xoth && n + 1 < iterations && !g_tune.force_two_pass) {
-      double h2[2], tl2[2];
-      for (int i = 0; i < 2; ++i) {
-        h2[i] = huber ? 1.0 + sig[n + i] * gamma_huber : 1.0;
-        tl2[i] = tau[n + i] * lambda;
+      // deepest temporal blocking first: 3 iterations per pass (tiled
+      // footprints), then 2 (tiled or full-row footprints), then 1
+      double h3[3], tl3[3];
+      const int left = iterations - n < 3 ? iterations - n : 3;
+      for (int i = 0; i < left; ++i) {
+        h3[i] = huber ? 1.0 + sig[n + i] * gamma_huber : 1.0;
+        tl3[i] = tau[n + i] * lambda;
       }
-      rc = fused2_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
-                       ndim, nz, ny, nx, wx, wy, wz, sig + n, h2, tau + n, tl2,
-                       theta + n, flags, stream);
-      if (rc == 0) {
-        n += 2;
+      int done = 0;
+      for (int k = left; k >= 2 && !done; --k) {
+        rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
+                         ndim, nz, ny, nx, wx, wy, wz, k, sig + n, h3, tau + n, tl3,
+                         theta + n, flags, stream);
+        if (rc == 0) done = k;
+        else if (rc != -2) return rc;
+      }
+      if (!done) {
+        rc = fused2_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
+                         ndim, nz, ny, nx, wx, wy, wz, sig + n, h3, tau + n, tl3,
+                         theta + n, flags, stream);
+        if (rc == 0) done = 2;
+        else if (rc != -2) return rc;
+      }
+      if (done) {
+        n += done;
         slot ^= 1;
         T *t = xcur; xcur = xoth; xoth = t;
         continue;
       }
-      if (rc != -2) return rc;
     }
     const double hden = huber ? 1.0 + sig[n] * gamma_huber : 1.0;
     if (g_tune.force_two_pass) {

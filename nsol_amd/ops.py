@@ -300,6 +300,27 @@ def pd_fused2_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
     return True
 
 
+def pd_fusedk_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
+                   sigma, hden, tau, tl, theta, flags):
+    """len(sigma) = 2 or 3 iterations in one pass on tiled footprints; returns
+    False if the kernel does not apply (nothing was launched)."""
+    ndim, nz, ny, nx = dims3(shape)
+    arr = [np.ascontiguousarray(a, dtype=np.float64)
+           for a in (sigma, hden, tau, tl, theta)]
+    k = int(arr[0].size)
+    if any(a.size != k for a in arr):
+        raise ValueError("step-size arrays must have equal length")
+    rc = _fn("pd_fusedk_iter", x_in)(
+        _p(xbar_in), _p(xbar_out), _p(x_in), _p(x_out), _p(bt), _p(p_in),
+        _p(p_out), ndim, nz, ny, nx, w[0], w[1], w[2], k, arr[0].ctypes.data,
+        arr[1].ctypes.data, arr[2].ctypes.data, arr[3].ctypes.data,
+        arr[4].ctypes.data, int(flags), stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_pd_fusedk_iter")
+    return True
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
            p_is_zero, gamma_huber, flags, x_alt=None):
     """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that

@@ -677,7 +677,7 @@ def test_x_scale_invariance(nsol, golden):
 
 # ------------------------------------------- two iterations per pass (TB2)
 def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
-                two_pass=0):
+                two_pass=0, pdk=None):
     import torch
     from nsol_amd import ops, _lib
     from nsol_amd.primal_dual_solver import step_schedule
@@ -692,6 +692,10 @@ def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
     _lib.set_param("pd2_enable", enable2)
     _lib.set_param("pd2_zchunk", zchunk2)
     _lib.set_param("pd_two_pass", two_pass)
+    pdk_defaults = dict(pdk_enable=0, pdk_kmax=3, pdk_nw=16, pdk_zchunk=0,
+                        pdk_ntx=0)
+    for k, v in dict(pdk_defaults, **(pdk or {})).items():
+        _lib.set_param(k, v)
     try:
         slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape,
                           (1.0, 0.5, 2.0), 20.0, sig, ta, th, True, 0.05,
@@ -701,6 +705,8 @@ def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
         _lib.set_param("pd2_enable", 1)
         _lib.set_param("pd2_zchunk", 0)
         _lib.set_param("pd_two_pass", 0)
+        for k, v in pdk_defaults.items():
+            _lib.set_param(k, v)
     return x, xb[slot], p[slot], bt
 
 
@@ -722,6 +728,32 @@ def test_two_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters):
         got = _run_pd_raw(shape, dtype, iters, flags, enable2=1, zchunk2=zc)
         for a, b in zip(ref[:3], got[:3]):
             assert torch.equal(a, b), (shape, zc)
+
+
+@pytest.mark.parametrize("shape,dtype", [
+    ((20, 30, 256), np.float32), ((17, 9, 512), np.float32),
+    ((9, 70, 264), np.float32), ((33, 20, 768), np.float32),
+    ((8, 8, 1280), np.float32), ((21, 13, 132), np.float64),
+    ((10, 37, 256), np.float64), ((12, 11, 600), np.float64),
+    ((16, 40, 32), np.float32), ((11, 100, 64), np.float64)])
+@pytest.mark.parametrize("iters", [3, 8])
+@pytest.mark.parametrize("nw", [16, 12])
+def test_k_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters, nw):
+    """Depth-3 / depth-2 temporal blocking on tiled footprints (k_pd_fusedk):
+    forced x tilings (1..3 tiles), z-chunk seams, 3+3+2 and 3 iterations, all
+    flag combinations, both workgroup sizes."""
+    import torch
+    from nsol_amd import ops
+    for flags in (ops.PD_REG_HUBER | ops.PD_DATA_L1,
+                  ops.PD_REG_TV | ops.PD_DATA_L2):
+        ref = _run_pd_raw(shape, dtype, iters, flags, enable2=0)
+        for cfg in (dict(), dict(pdk_zchunk=5), dict(pdk_ntx=1),
+                    dict(pdk_ntx=2, pdk_zchunk=4), dict(pdk_ntx=3),
+                    dict(pdk_kmax=2), dict(pdk_kmax=2, pdk_ntx=2, pdk_zchunk=3)):
+            cfg = dict(cfg, pdk_enable=1, pdk_nw=nw)
+            got = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg)
+            for a, b in zip(ref[:3], got[:3]):
+                assert torch.equal(a, b), (shape, cfg, flags)
 
 
 @pytest.mark.parametrize("shape", [(200, 333, 640), (97, 1030, 512),
