@@ -5,8 +5,9 @@ per GPU.
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is ONE primal-dual iteration = one launch of the single-pass fused
-kernel over the whole volume (inputs already resident in HBM).  N > 1: launched
+A step is ONE primal-dual iteration over the whole volume (inputs already
+resident in HBM); three consecutive iterations share one pass over memory
+(k_pd_fusedk, temporal blocking of depth 3).  N > 1: launched
 by torch.distributed.run, one rank per GPU, each rank owns its own volume (weak
 scaling, no per-iteration collective); after the timed region the results are
 gathered once on rank 0 over RCCL (reported as gather_ms, not part of `value`).
@@ -151,6 +152,15 @@ def main():
                          p_is_zero, 0.05, flags, x_alt=x_alt)
         state["slot"] = a ^ end
 
+    # Plan pass (untimed, like creating an FFT plan): the first launch of the
+    # depth-3 kernel on a new shape times a handful of footprint shapes and keeps
+    # the fastest for the life of the process.  The state is reset afterwards.
+    run(0, min(5, total), True)
+    torch.cuda.synchronize()
+    x.copy_(bt)
+    xbar[0].copy_(bt)
+    state["slot"] = 0
+
     if args.warmup > 0:
         run(0, args.warmup, True)
     torch.cuda.synchronize()
@@ -158,23 +168,36 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
+    # The timed region is ONE enqueue of args.steps iterations; an event after
+    # the last full group of three separates the launches of the dominant
+    # kernel (k_pd_fusedk, three iterations per launch) from the one or two
+    # trailing iterations (k_pd_fused2 / k_pd_fused).
     ev = HipEvents()
-    e0, e1 = ev.create(), ev.create()
+    e0, em, e1 = ev.create(), ev.create(), ev.create()
     stream = torch.cuda.current_stream().cuda_stream
+    triples = args.steps // 3
     t0 = time.perf_counter()
     ev.record(e0, stream)
-    run(args.warmup, args.steps, args.warmup == 0)
+    if triples:
+        run(args.warmup, 3 * triples, args.warmup == 0)
+    ev.record(em, stream)
+    if args.steps > 3 * triples:
+        run(args.warmup + 3 * triples, args.steps - 3 * triples,
+            args.warmup == 0 and triples == 0)
     ev.record(e1, stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # one launch of k_pd_fused2 advances TWO iterations (an odd trailing
-    # iteration is one launch of k_pd_fused)
-    launches = (args.steps + 1) // 2
-    total_ms = ev.elapsed_ms(e0, e1)
-    kernel_ms = total_ms / launches                    # avg launch duration
+    if triples:
+        launches = triples
+        iters_per_launch = 3
+        kernel_ms = ev.elapsed_ms(e0, em) / launches        # avg launch duration
+    else:
+        launches = 1
+        iters_per_launch = args.steps
+        kernel_ms = ev.elapsed_ms(e0, e1)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64,
                         device="cpu" if on_host else dev)
@@ -201,6 +224,7 @@ def main():
     single = None
     if world == 1 and args.steps >= 2:
         _lib.set_param("pd2_enable", 0)
+        _lib.set_param("pdk_enable", 0)
         try:
             k1 = 40
             sg1, ta1, th1 = step_schedule("ALG2", 16.0, lmbda, k1)
@@ -220,14 +244,15 @@ def main():
                       HBM_PEAK_GBPS}
         finally:
             _lib.set_param("pd2_enable", 1)
+            _lib.set_param("pdk_enable", 1)
 
     finite = bool(torch.isfinite(x).all().item())
 
     if rank == 0:
         value = world * args.steps / tmax
         # algorithmic bytes: 44 B per voxel per ITERATION; a launch
-        # processes args.steps / launches iterations
-        bytes_per_launch = BYTES_PER_VOXEL * nvox * args.steps / launches
+        # of the dominant kernel processes iters_per_launch iterations
+        bytes_per_launch = BYTES_PER_VOXEL * nvox * iters_per_launch
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "primal-dual iters/sec on %d^3 fp32 TV-%s" %
@@ -243,14 +268,16 @@ def main():
                             "alpha=%g, one volume per GPU" %
                             (n, kind, args.data, alpha),
                 "volumes": world, "voxels_per_volume": nvox,
-                "kernel": "k_pd_fused2 (two iterations per pass)",
+                "kernel": "k_pd_fusedk (three iterations per pass; trailing "
+                          "iterations: k_pd_fused2 / k_pd_fused)",
                 "gather_ms": gather_ms, "result_finite": finite},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": measured_traffic(n),
                 "bytes_per_launch": bytes_per_launch,
-                "iterations_per_launch": args.steps / launches,
+                "iterations_per_launch": iters_per_launch,
+                "launches": launches,
                 "avg_launch_ms": kernel_ms,
                 # what the memory system actually carries (PMC, per launch)
                 "traffic_rate_GBps": (measured_traffic(n) / (kernel_ms * 1e-3)

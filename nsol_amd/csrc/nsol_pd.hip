@@ -530,16 +530,23 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
         tl3[i] = tau[n + i] * lambda;
       }
       int done = 0;
-      for (int k = left; k >= 2 && !done; --k) {
+      if (left >= 3) {
         rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
-                         ndim, nz, ny, nx, wx, wy, wz, k, sig + n, h3, tau + n, tl3,
+                         ndim, nz, ny, nx, wx, wy, wz, 3, sig + n, h3, tau + n, tl3,
                          theta + n, flags, stream);
-        if (rc == 0) done = k;
+        if (rc == 0) done = 3;
         else if (rc != -2) return rc;
       }
       if (!done) {
         rc = fused2_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
                          ndim, nz, ny, nx, wx, wy, wz, sig + n, h3, tau + n, tl3,
+                         theta + n, flags, stream);
+        if (rc == 0) done = 2;
+        else if (rc != -2) return rc;
+      }
+      if (!done) {   // e.g. rows too short for the full-row footprints
+        rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
+                         ndim, nz, ny, nx, wx, wy, wz, 2, sig + n, h3, tau + n, tl3,
                          theta + n, flags, stream);
         if (rc == 0) done = 2;
         else if (rc != -2) return rc;

@@ -27,7 +27,15 @@
 //               entries and forms p_x^(k), p_y^(k) and the in-plane K^T.
 // The arithmetic per voxel is that of K launches of k_pd_fused in the same
 // order, so results are bit-identical.
+#include <stdio.h>
 #include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <type_traits>
+#include <vector>
 
 #include "nsol_common.hpp"
 #include "nsol_pd_common.hpp"
@@ -49,6 +57,59 @@ struct Tiling {
   int ntx, nty;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// Raw buffer addressing: a 32-bit byte offset per lane plus a scalar offset,
+// and the hardware range check drops accesses whose offset is >= num_records
+// (loads return 0).  Lanes outside the volume carry kInvalid as their offset,
+// so the loop body needs neither exec-mask branches nor zero-initialised
+// destination registers -- which is what lets the prefetch stay in flight.
+constexpr uint32_t kInvalid = 0xC0000000u;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+template <typename T, int V>
+__device__ __forceinline__ void bld(rsrc_t r, uint32_t vo, uint32_t so, T (&v)[V]) {
+  static_assert(sizeof(T) * V == 16, "one 16-byte vector per lane");
+  typedef typename Pack<T, V>::type P;
+  const P t = __builtin_bit_cast(P, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+#pragma unroll
+  for (int k = 0; k < V; ++k) v[k] = t[k];
+}
+template <typename T> __device__ __forceinline__ T bld1(rsrc_t r, uint32_t vo, uint32_t so);
+template <> __device__ __forceinline__ float bld1<float>(rsrc_t r, uint32_t vo, uint32_t so) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+}
+template <> __device__ __forceinline__ double bld1<double>(rsrc_t r, uint32_t vo, uint32_t so) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
+}
+// The whole offset goes into the VGPR and the scalar offset is the constant 0.
+// A 16-byte buffer store reads its data registers over two passes; when the
+// scalar offset is a REGISTER the compiler (ROCm 7.2) assumes there is no hazard
+// and lets the next VALU instruction overwrite them -- on gfx950 that corrupted
+// the stored vector in the lanes of the later passes.  With a constant scalar
+// offset the hazard recogniser inserts the wait state; the s_nop makes it
+// independent of that rule.
+template <typename T, int V>
+__device__ __forceinline__ void bst(rsrc_t r, uint32_t vo, const T (&v)[V]) {
+  typedef typename Pack<T, V>::type P;
+  P t;
+#pragma unroll
+  for (int k = 0; k < V; ++k) t[k] = v[k];
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r, vo, 0, 0);
+  asm volatile("s_nop 1");
+}
+
+// LDS rows are padded by one (zero) row above and below the footprint
+template <int NT, int K>
+struct LdsShape {
+  static constexpr int LXM = NT / (2 * K);          // widest row (lanes)
+  static constexpr int N = NT + 2 * LXM;            // vectors per array
+};
+
 template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1>
 __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out,
@@ -59,8 +120,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   constexpr int NT = NW * 64;
   constexpr int H = K - 1;
   constexpr int HX = ((H + VEC - 1) / VEC) * VEC;
-  __shared__ __attribute__((aligned(16))) T s_xb[2][K - 1][NT * VEC];
-  __shared__ __attribute__((aligned(16))) T s_py[2][K - 1][NT * VEC];
+  constexpr int LN = LdsShape<NT, K>::N;
+  __shared__ __attribute__((aligned(16))) T s_xb[2][K - 1][LN * VEC];
+  __shared__ __attribute__((aligned(16))) T s_py[2][K - 1][LN * VEC];
   __shared__ T s_px[2][K - 1][NW];   // last p_x^(k-1) of each wave's lane 63
 
   const int tid = threadIdx.x;
@@ -111,30 +173,63 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   const int64_t zbeg = (int64_t)zc * zchunk;
   int64_t zend = zbeg + zchunk;
   if (zend > G.nz) zend = G.nz;
-
-  const T *pin_x = p_in, *pin_y = p_in + G.n, *pin_z = p_in + 2 * G.n;
-  T *pout_x = p_out, *pout_y = p_out + G.n, *pout_z = p_out + 2 * G.n;
-
-  // stage 1 halos (old data, global memory)
-  const bool row_end = (lx == lxb - 1) || lane == 63;
-  const bool row_beg = (lx == 0) || lane == 0;
-  const bool g_right = rin && row_end && (x0 + VEC < G.nx);
-  const bool g_left = rin && row_beg && x0 > 0;
-  const bool g_up = rin && y > 0;
-  const bool g_down = rin && (y + 1 < G.ny);
-  // stages >= 2: neighbours inside the footprint (LDS); beyond it: zero (either
-  // the zero padding of K / K^T at the volume edge, or a voxel whose result is
-  // recomputed by the neighbouring footprint and never stored from here)
-  const bool n_l = active && lx > 0;
-  const bool n_r = active && lx < lxb - 1;
-  const bool n_u = active && row > 0;
-  const bool n_d = active && row + 1 < Q.rows;
-  const bool v_l = rin && n_l && x0 > 0;   // the left / upper voxel is in the volume
-  const bool v_u = rin && n_u && y > 0;
-
   const int64_t s_first = zbeg > H ? zbeg - H : 0;
   const int64_t s_last = zend + K - 2;
-  int64_t off = s_first * G.sz + y * G.sy + x0;
+  const int64_t s_hi = s_last < G.nz - 1 ? s_last : G.nz - 1;   // last step with a stage 1
+
+  // ---- buffer resources over the planes [pz0, pe) this workgroup touches
+  const int64_t pz0 = s_first > 0 ? s_first - 1 : 0;
+  int64_t pe = s_last + 2;
+  if (pe > G.nz) pe = G.nz;
+  const uint32_t szb = (uint32_t)(G.sz * (int64_t)sizeof(T));
+  const uint32_t syb = (uint32_t)(G.sy * (int64_t)sizeof(T));
+  const uint32_t span = (uint32_t)(pe - pz0) * szb;       // < 2^30 (host-checked)
+  const int64_t boff = pz0 * G.sz;
+  const uint32_t pspan = S.has_p ? span : 0u;             // p = 0: every load returns 0
+  const rsrc_t r_xb = make_rsrc(xbar_in + boff, span);
+  const rsrc_t r_x = make_rsrc(x_in + boff, span);
+  const rsrc_t r_bt = make_rsrc(bt + boff, span);
+  const rsrc_t r_px = make_rsrc(p_in + boff, pspan);
+  const rsrc_t r_py = make_rsrc(p_in + G.n + boff, pspan);
+  const rsrc_t r_pz = make_rsrc(p_in + 2 * G.n + boff, pspan);
+  const rsrc_t w_xb = make_rsrc(xbar_out + boff, span);
+  const rsrc_t w_x = make_rsrc(x_out + boff, span);
+  const rsrc_t w_px = make_rsrc(p_out + boff, span);
+  const rsrc_t w_py = make_rsrc(p_out + G.n + boff, span);
+  const rsrc_t w_pz = make_rsrc(p_out + 2 * G.n + boff, span);
+
+  // per-lane byte offsets inside a plane (loop invariant); the plane is selected
+  // by the scalar offset.  Stage-1 halos: old data from global memory (L1/L2).
+  const bool row_end = (lx == lxb - 1) || lane == 63;
+  const bool row_beg = (lx == 0) || lane == 0;
+  const uint32_t o0 = (uint32_t)((y * G.sy + x0) * (int64_t)sizeof(T));
+  const uint32_t v_own = rin ? o0 : kInvalid;
+  const uint32_t v_up = (rin && y > 0) ? o0 - syb : kInvalid;
+  const uint32_t v_down = (rin && y + 1 < G.ny) ? o0 + syb : kInvalid;
+  const uint32_t v_right = (rin && row_end && x0 + VEC < G.nx) ? o0 + 16u : kInvalid;
+  const uint32_t v_left = (rin && row_beg && x0 > 0) ? o0 - (uint32_t)sizeof(T) : kInvalid;
+  const uint32_t v_st = rvalid ? o0 : kInvalid;
+  // stages >= 2: neighbours inside the footprint come from LDS; beyond it the
+  // value is zero (the zero padding of K / K^T at the volume edge) or belongs
+  // to a voxel whose result is recomputed by the next footprint and not stored
+  const bool n_r = active && lx < lxb - 1;
+  const bool v_l = rin && lx > 0 && x0 > 0;      // the left / upper voxel is in the volume
+  const bool v_u = rin && row > 0 && y > 0;
+  const bool g_l = rin && row_beg && x0 > 0;
+  const bool g_u = rin && y > 0;
+  const int li = (tid + lxb) * VEC;              // LDS slot of this lane (row + 1)
+
+  // zero rows above and below the footprint, once
+  for (int i = tid; i < 2 * (K - 1) * 2 * lxb * VEC; i += NT) {
+    const int e = i % (lxb * VEC);
+    int r = i / (lxb * VEC);
+    const int side = r & 1; r >>= 1;
+    const int kk = r % (K - 1);
+    const int b = r / (K - 1);
+    const int at = side ? (Q.rows + 1) * lxb * VEC + e : e;
+    s_xb[b][kk][at] = T(0);
+    s_py[b][kk][at] = T(0);
+  }
 
   T xc[VEC];              // xbar[s]
   T pz[K][VEC];           // pz[k-1]: p^(k)_z on the plane stage k finished last
@@ -144,71 +239,58 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   T c_kt[K][VEC];         //               in-plane part of K^T p^(k) there
   T c_px[K][VEC];         // [k-1], k>=3: p_x^(k-1) on plane s-(k-1)+1 (from IP_{k-1})
   T c_py[K][VEC];
-  zero(xc);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     zero(pz[k]); zero(c_xb[k]); zero(c_x[k]); zero(c_bt[k]); zero(c_kt[k]);
     zero(c_px[k]); zero(c_py[k]);
   }
-  if (rin) ldv<T, VEC>(xbar_in + off, xc);
-  if (s_first > 0 && rin) {
+  uint32_t adv = (uint32_t)(s_first - pz0) * szb;   // scalar offset of plane s
+  bld<T, VEC>(r_xb, v_own, adv, xc);
+  {
+    // p'_z of the plane below the first one (zero at the bottom of the volume)
     T xm[VEC], pm[VEC];
-    zero(pm);
-    ldv<T, VEC>(xbar_in + off - G.sz, xm);
-    if (S.has_p) ldv<T, VEC>(pin_z + off - G.sz, pm);
+    const uint32_t vb = s_first > 0 ? v_own : kInvalid;
+    const uint32_t ab = s_first > 0 ? adv - szb : 0u;
+    bld<T, VEC>(r_xb, vb, ab, xm);
+    bld<T, VEC>(r_pz, vb, ab, pm);
+    const T sg = s_first > 0 ? S.sigma[0] : T(0);
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      pz[0][j] = dual_update_s<HUBER>(pm[j], xc[j], xm[j], G.wz, S.sigma[0], S.hden[0]);
+      pz[0][j] = dual_update_s<HUBER>(pm[j], xc[j], xm[j], G.wz, sg, S.hden[0]);
   }
 
-  // Software pipeline: the global loads of plane s+1 are issued right after the
-  // stage-1 arithmetic of plane s, so they are in flight while the later stages
-  // (and the barrier) run -- the waves of a workgroup move in lockstep, so
-  // nothing else would hide the latency.
+  // Software pipeline: the loads of plane s+1 are issued right after the stage-1
+  // arithmetic of plane s and stay in flight while the later stages (and the
+  // barrier) run -- the waves of a workgroup move in lockstep, so nothing else
+  // would hide the latency.
   T xn[VEC], xv[VEC], btn[VEC], pxo[VEC], pyo[VEC], pzo[VEC];
   T xdown[VEC], xup[VEC], pyup[VEC];
-  T xright = T(0), xleft = T(0), pxleft = T(0);
-  zero(xn); zero(xv); zero(btn); zero(pxo); zero(pyo); zero(pzo);
-  zero(xdown); zero(xup); zero(pyup);
-  auto issue_loads = [&](int64_t sp, int64_t o) {
-    if (rin) {
-      if (sp + 1 < G.nz) ldv<T, VEC>(xbar_in + o + G.sz, xn);
-      else zero(xn);
-      ldv<T, VEC>(x_in + o, xv);
-      ldv<T, VEC>(bt + o, btn);
-      if (S.has_p) {
-        ldv<T, VEC>(pin_x + o, pxo);
-        ldv<T, VEC>(pin_y + o, pyo);
-        ldv<T, VEC>(pin_z + o, pzo);
-      }
-    }
-    if (g_right) xright = xbar_in[o + VEC];
-    if (g_left) {
-      xleft = xbar_in[o - 1];
-      if (S.has_p) pxleft = pin_x[o - 1];
-    }
-    if (g_down) ldv<T, VEC>(xbar_in + o + G.sy, xdown);
-    if (g_up) {
-      ldv<T, VEC>(xbar_in + o - G.sy, xup);
-      if (S.has_p) ldv<T, VEC>(pin_y + o - G.sy, pyup);
-    }
+  T xright, xleft, pxleft;
+  auto issue_loads = [&](int64_t sp, uint32_t a) {
+    // sp: plane; a: its scalar offset.  The plane above the volume is zero.
+    bld<T, VEC>(r_xb, (sp + 1 < G.nz) ? v_own : kInvalid, a + szb, xn);
+    bld<T, VEC>(r_x, v_own, a, xv);
+    bld<T, VEC>(r_bt, v_own, a, btn);
+    bld<T, VEC>(r_px, v_own, a, pxo);
+    bld<T, VEC>(r_py, v_own, a, pyo);
+    bld<T, VEC>(r_pz, v_own, a, pzo);
+    xright = bld1<T>(r_xb, v_right, a);
+    xleft = bld1<T>(r_xb, v_left, a);
+    pxleft = bld1<T>(r_px, v_left, a);
+    bld<T, VEC>(r_xb, v_down, a, xdown);
+    bld<T, VEC>(r_xb, v_up, a, xup);
+    bld<T, VEC>(r_py, v_up, a, pyup);
   };
-  if (s_first < G.nz) issue_loads(s_first, off);
+  issue_loads(s_first, adv);
 
-  for (int64_t s = s_first; s <= s_last; ++s, off += G.sz) {
+  // one plane step; HAVE1 = false in the drain steps above the volume's last plane
+  auto step = [&](auto have1_tag, int64_t s) {
+    constexpr bool HAVE1 = decltype(have1_tag)::value;
     // fr_*[k-1]: results of stage k produced in this step
     T fr_xb[K][VEC], fr_x[K][VEC], fr_bt[K][VEC], pzn[K][VEC];
     T f_px[VEC], f_py[VEC];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      zero(fr_xb[k]); zero(fr_x[k]); zero(fr_bt[k]); zero(pzn[k]);
-    }
-    zero(f_px); zero(f_py);
-
-    if (s < G.nz) {
+    if constexpr (HAVE1) {
       // ================= stage 1: iteration n+1 on plane s ===================
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) fr_bt[0][j] = btn[j];
       T nb = __shfl_down(xc[0], 1, kWave);
       if (row_end) nb = xright;
 #pragma unroll
@@ -220,55 +302,61 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       }
       T pxl = __shfl_up(f_px[VEC - 1], 1, kWave);
       if (row_beg)
-        pxl = g_left ? dual_update_s<HUBER>(pxleft, xc[0], xleft, G.wx, S.sigma[0],
-                                            S.hden[0])
-                     : T(0);
+        pxl = g_l ? dual_update_s<HUBER>(pxleft, xc[0], xleft, G.wx, S.sigma[0],
+                                         S.hden[0])
+                  : T(0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T pu = g_up ? dual_update_s<HUBER>(pyup[j], xc[j], xup[j], G.wy,
-                                                 S.sigma[0], S.hden[0])
-                          : T(0);
+        const T pu = g_u ? dual_update_s<HUBER>(pyup[j], xc[j], xup[j], G.wy,
+                                                S.sigma[0], S.hden[0])
+                         : T(0);
         const T pl = (j > 0) ? f_px[(j + VEC - 1) % VEC] : pxl;
         T kt = f_px[j] * (-G.wx) + pl * G.wx;
         kt += f_py[j] * (-G.wy) + pu * G.wy;
         kt += pzn[0][j] * (-G.wz) + pz[0][j] * G.wz;
         const T u = xv[j] - tau_m[0] * kt;
-        const T xnew = prox_data_s<L1>(u, fr_bt[0][j], S.tl[0], S.optl[0]);
+        const T xnew = prox_data_s<L1>(u, btn[j], S.tl[0], S.optl[0]);
         fr_x[0][j] = xnew;
         fr_xb[0][j] = xnew + S.theta[0] * (xnew - xv[j]);
+        fr_bt[0][j] = btn[j];
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) xc[j] = xn[j];
-      if (s + 1 < G.nz && s + 1 <= s_last) issue_loads(s + 1, off + G.sz);
+      // prefetch plane s+1 (the step after the last plane re-reads it: unused)
+      const bool more = s + 1 <= s_hi;
+      issue_loads(more ? s + 1 : s, more ? adv + szb : adv);
+    } else {
+      zero(fr_xb[0]); zero(fr_x[0]); zero(fr_bt[0]); zero(pzn[0]);
+      zero(f_px); zero(f_py);
     }
 
     // ================= F_k: finish iteration n+k on plane s-(k-1) ===========
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
       const int64_t f = s - (k - 1);
-      if (f >= s_first) {
-        // beyond the last plane everything is zero padding (only k < K gets there)
-        const T tk = (f < G.nz) ? tau_m[k - 1] : T(0);
-        T pkz[VEC];
+      // below the volume and above it everything is zero padding
+      const bool inr = f >= 0 && f < G.nz;
+      const T sk = inr ? sig_m[k - 1] : T(0);
+      const T tk = inr ? tau_m[k - 1] : T(0);
+      T pkz[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          pkz[j] = dual_update_s<HUBER>(pz[k - 2][j], fr_xb[k - 2][j], c_xb[k - 1][j],
-                                        G.wz, sig_m[k - 1], S.hden[k - 1]);
-          T kt = c_kt[k - 1][j];
-          kt += pkz[j] * (-G.wz) + pz[k - 1][j] * G.wz;
-          const T u = c_x[k - 1][j] - tk * kt;
-          const T xk = prox_data_s<L1>(u, c_bt[k - 1][j], S.tl[k - 1], S.optl[k - 1]);
-          fr_x[k - 1][j] = xk;
-          fr_xb[k - 1][j] = xk + S.theta[k - 1] * (xk - c_x[k - 1][j]);
-          fr_bt[k - 1][j] = c_bt[k - 1][j];
-          pzn[k - 1][j] = pkz[j];
-        }
-        if (k == K && f >= zbeg && f < zend && rvalid) {
-          const int64_t o = off - (int64_t)(K - 1) * G.sz;
-          stv<T, VEC>(pout_z + o, pkz);
-          stv<T, VEC>(x_out + o, fr_x[K - 1]);
-          stv<T, VEC>(xbar_out + o, fr_xb[K - 1]);
-        }
+      for (int j = 0; j < VEC; ++j) {
+        pkz[j] = dual_update_s<HUBER>(pz[k - 2][j], fr_xb[k - 2][j], c_xb[k - 1][j],
+                                      G.wz, sk, S.hden[k - 1]);
+        T kt = c_kt[k - 1][j];
+        kt += pkz[j] * (-G.wz) + pz[k - 1][j] * G.wz;
+        const T u = c_x[k - 1][j] - tk * kt;
+        const T xk = prox_data_s<L1>(u, c_bt[k - 1][j], S.tl[k - 1], S.optl[k - 1]);
+        fr_x[k - 1][j] = xk;
+        fr_xb[k - 1][j] = xk + S.theta[k - 1] * (xk - c_x[k - 1][j]);
+        fr_bt[k - 1][j] = c_bt[k - 1][j];
+        pzn[k - 1][j] = pkz[j];
+      }
+      if (k == K && f >= zbeg && f < zend) {      // uniform
+        const uint32_t vo = v_st + (adv - (uint32_t)(K - 1) * szb);
+        bst<T, VEC>(w_pz, vo, pkz);
+        bst<T, VEC>(w_x, vo, fr_x[K - 1]);
+        bst<T, VEC>(w_xb, vo, fr_xb[K - 1]);
       }
     }
 
@@ -276,12 +364,12 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const int buf = (int)(s & 1);
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
-      stv<T, VEC>(&s_xb[buf][k - 2][tid * VEC], fr_xb[k - 2]);
+      stv<T, VEC>(&s_xb[buf][k - 2][li], fr_xb[k - 2]);
       if (k == 2) {
-        stv<T, VEC>(&s_py[buf][0][tid * VEC], f_py);
+        stv<T, VEC>(&s_py[buf][0][li], f_py);
         if (lane == 63) s_px[buf][0][tid >> 6] = f_px[VEC - 1];
       } else {
-        stv<T, VEC>(&s_py[buf][k - 2][tid * VEC], c_py[k - 1]);
+        stv<T, VEC>(&s_py[buf][k - 2][li], c_py[k - 1]);
         if (lane == 63) s_px[buf][k - 2][tid >> 6] = c_px[k - 1][VEC - 1];
       }
     }
@@ -290,19 +378,14 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
       T below[VEC], above[VEC], above_py[VEC];
-      zero(below); zero(above); zero(above_py);
-      T right = T(0), left_xb = T(0), left_px = T(0);
-      if (n_d) ldv<T, VEC>(&s_xb[buf][k - 2][(tid + lxb) * VEC], below);
-      if (n_u) {
-        ldv<T, VEC>(&s_xb[buf][k - 2][(tid - lxb) * VEC], above);
-        ldv<T, VEC>(&s_py[buf][k - 2][(tid - lxb) * VEC], above_py);
-      }
-      if (n_r) right = s_xb[buf][k - 2][(tid + 1) * VEC];
-      left_px = __shfl_up((k == 2) ? f_px[VEC - 1] : c_px[k - 1][VEC - 1], 1, kWave);
-      if (n_l) {
-        left_xb = s_xb[buf][k - 2][tid * VEC - 1];
-        if (lane == 0) left_px = s_px[buf][k - 2][(tid >> 6) - 1];
-      }
+      ldv<T, VEC>(&s_xb[buf][k - 2][li + lxb * VEC], below);
+      ldv<T, VEC>(&s_xb[buf][k - 2][li - lxb * VEC], above);
+      ldv<T, VEC>(&s_py[buf][k - 2][li - lxb * VEC], above_py);
+      T right = s_xb[buf][k - 2][li + VEC];
+      if (!n_r) right = T(0);
+      const T left_xb = s_xb[buf][k - 2][li - 1];
+      T left_px = __shfl_up((k == 2) ? f_px[VEC - 1] : c_px[k - 1][VEC - 1], 1, kWave);
+      if (lane == 0) left_px = s_px[buf][k - 2][tid > 0 ? (tid >> 6) - 1 : 0];
       const T pl0 = v_l ? dual_update_s<HUBER>(left_px, fr_xb[k - 2][0], left_xb, G.wx,
                                                S.sigma[k - 1], S.hden[k - 1])
                         : T(0);
@@ -331,10 +414,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       }
       if (k == K) {
         const int64_t a = s - (K - 2);
-        if (a >= zbeg && a < zend && rvalid) {
-          const int64_t o = off - (int64_t)(K - 2) * G.sz;
-          stv<T, VEC>(pout_x + o, pkx);
-          stv<T, VEC>(pout_y + o, pky);
+        if (a >= zbeg && a < zend) {              // uniform
+          const uint32_t vo = v_st + (adv - (uint32_t)(K - 2) * szb);
+          bst<T, VEC>(w_px, vo, pkx);
+          bst<T, VEC>(w_py, vo, pky);
         }
       }
     }
@@ -358,16 +441,25 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) pz[k][j] = pzn[k][j];
-  }
+    adv += szb;
+  };
+
+  __syncthreads();   // LDS padding rows are zero before anyone reads them
+  int64_t s = s_first;
+  for (; s <= s_hi; ++s) step(std::true_type{}, s);
+  for (; s <= s_last; ++s) step(std::false_type{}, s);
 }
 
 struct Tuning {
-  int enable = 0;
+  int enable = 1;
   int kmax = 3;
-  int nw = 16;
-  int zchunk = 0;
-  int ntx = 0;      // 0 = choose
+  int nw = 0;         // 0 = choose (12 or 8 waves for K = 3; 16 / 12 for K = 2)
+  int zchunk = 0;     // 0 = choose
+  int ntx = 0;        // 0 = choose
   int xcd_map = 1;
+  int verbose = 0;
+  int autotune = 1;   // time the best few model candidates once per problem shape
+  int tune_min_mvox = 16;   // ... for volumes of at least this many Mi voxels
 };
 Tuning g_tunek;
 
@@ -384,45 +476,47 @@ inline int cu_count() {
   return n;
 }
 
-// Footprint shape with the largest share of lanes that produce stored output.
-inline bool choose_tiling(int64_t nx, int64_t ny, int nt, int vec, int h, int hx,
-                          int force_ntx, Tiling *out) {
-  double best = 0.0;
-  bool found = false;
-  for (int ntx = 1; ntx <= 64; ++ntx) {
-    if (force_ntx > 0 && ntx != force_ntx) continue;
-    Tiling q;
-    if (ntx == 1) {
-      q.xv = 0;
-      q.lxb = (int)(nx / vec);
-    } else {
-      int64_t xv = (nx + ntx - 1) / ntx;
-      xv = (xv + vec - 1) / vec * vec;
-      if (xv * (ntx - 1) >= nx) continue;   // fewer tiles would do
-      q.xv = (int)xv;
-      q.lxb = (int)(xv / vec) + 2 * (hx / vec);
-    }
-    if (q.lxb < 1 || q.lxb > nt) continue;
-    q.rows = nt / q.lxb;
-    if (q.rows - 2 * h < 1) continue;
-    q.ntx = ntx;
-    q.nty = (int)((ny + (q.rows - 2 * h) - 1) / (q.rows - 2 * h));
-    const double eff = (double)nx * (double)ny /
-                       ((double)q.ntx * q.nty * (double)nt * vec);
-    if (eff > best) { best = eff; *out = q; found = true; }
+struct Config {
+  int nw = 0;
+  Tiling q{};
+  int64_t zchunk = 0;
+  double cost = 0.0;      // modelled bytes through L2 -> fabric per launch
+};
+
+// Footprint of `nt` lanes cut into ntx columns of tiles.
+inline bool make_tiling(int64_t nx, int64_t ny, int nt, int vec, int h, int hx,
+                        int lxm, int ntx, Tiling *out) {
+  Tiling q;
+  if (ntx == 1) {
+    q.xv = 0;
+    q.lxb = (int)(nx / vec);
+  } else {
+    int64_t xv = (nx + ntx - 1) / ntx;
+    xv = (xv + vec - 1) / vec * vec;
+    if (xv * (ntx - 1) >= nx) return false;   // fewer tiles would do
+    q.xv = (int)xv;
+    q.lxb = (int)(xv / vec) + 2 * (hx / vec);
   }
-  return found;
+  if (q.lxb < 1 || q.lxb > lxm) return false;
+  q.rows = nt / q.lxb;
+  if (q.rows - 2 * h < 1) return false;
+  q.ntx = ntx;
+  q.nty = (int)((ny + (q.rows - 2 * h) - 1) / (q.rows - 2 * h));
+  *out = q;
+  return true;
 }
 
 // z-chunk length: trade the 2(K-1) extra planes per chunk against filling the
-// last round of workgroups (one workgroup per CU).
-inline int64_t pick_zchunk(int64_t nz, int64_t tiles, int extra) {
+// last round of workgroups (one workgroup per CU).  Returns the efficiency.
+inline double pick_zchunk(int64_t nz, int64_t tiles, int extra, int64_t max_chunk,
+                          int64_t *chunk_out) {
   const double slots = (double)cu_count();
   double best = -1.0;
-  int64_t best_chunk = nz;
+  int64_t best_chunk = nz < max_chunk ? nz : max_chunk;
   for (int64_t nzc = 1; nzc <= nz; ++nzc) {
     const int64_t chunk = (nz + nzc - 1) / nzc;
     if (chunk < 8 && nzc > 1) break;
+    if (chunk > max_chunk) continue;
     if ((nz + chunk - 1) / chunk != nzc) continue;
     const double blocks = (double)tiles * nzc;
     const double rounds = (double)(int64_t)((blocks + slots - 1) / slots);
@@ -430,7 +524,36 @@ inline int64_t pick_zchunk(int64_t nz, int64_t tiles, int extra) {
     const double eff = fill * (double)chunk / (double)(chunk + extra);
     if (eff > best) { best = eff; best_chunk = chunk; }
   }
-  return best_chunk;
+  *chunk_out = best_chunk;
+  return best > 0.0 ? best : 1.0;
+}
+
+// Bytes one launch pulls through L2 if no overlap is shared between footprints:
+// whole 128-byte lines per footprint row (the x halo costs a line on each side,
+// which is what makes narrow tiles expensive), six input arrays, plus the five
+// output arrays once.
+inline double model_cost(const Tiling &q, int64_t nx, int64_t ny, int64_t nz,
+                         int vec, int esize, int h, int hx, double zeff) {
+  double lines = 0.0;
+  for (int tx = 0; tx < q.ntx; ++tx) {
+    int64_t lo = q.xv ? (int64_t)tx * q.xv - hx : 0;
+    int64_t hi = lo + (int64_t)q.lxb * vec;
+    if (lo < 0) lo = 0;
+    if (hi > nx) hi = nx;
+    if (hi <= lo) continue;
+    lines += (double)((hi * esize - 1) / 128 - (lo * esize) / 128 + 1);
+  }
+  double rows = 0.0;
+  const int64_t tyv = q.rows - 2 * h;
+  for (int ty = 0; ty < q.nty; ++ty) {
+    int64_t lo = (int64_t)ty * tyv - h, hi = lo + q.rows;
+    if (lo < 0) lo = 0;
+    if (hi > ny) hi = ny;
+    if (hi > lo) rows += (double)(hi - lo);
+  }
+  const double reads = lines * 128.0 * rows * (double)nz * 6.0;
+  const double writes = 5.0 * (double)nx * ny * nz * esize;
+  return (reads + writes) / zeff;
 }
 
 template <typename T>
@@ -439,18 +562,12 @@ inline bool al16(const T *a) {
 }
 
 template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1>
-int launch_f(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
-             const T *p_in, T *p_out, const Geom<T> &G, const StageScalars<T, K> &S,
-             hipStream_t st) {
-  constexpr int H = K - 1;
-  constexpr int HX = ((H + VEC - 1) / VEC) * VEC;
-  Tiling Q;
-  if (!choose_tiling(G.nx, G.ny, NW * 64, VEC, H, HX, g_tunek.ntx, &Q)) return -2;
+int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
+             const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
+             const StageScalars<T, K> &S, hipStream_t st) {
+  const Tiling &Q = c.q;
   const int64_t tiles = (int64_t)Q.ntx * Q.nty;
-  int64_t zchunk = g_tunek.zchunk;
-  if (zchunk <= 0) zchunk = pick_zchunk(G.nz, tiles, 2 * H);
-  if (zchunk > G.nz) zchunk = G.nz;
-  const int64_t nzc = (G.nz + zchunk - 1) / zchunk;
+  const int64_t nzc = (G.nz + c.zchunk - 1) / c.zchunk;
   int64_t blocks = tiles * nzc;
   int64_t slab = 0;
   if (g_tunek.xcd_map && tiles >= 16) {
@@ -458,18 +575,23 @@ int launch_f(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     blocks = 8 * slab * nzc;
   }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
+  if (g_tunek.verbose)
+    fprintf(stderr, "k_pd_fusedk K=%d waves=%d: lxb=%d rows=%d xv=%d tiles=%dx%d "
+            "zchunk=%lld blocks=%lld slab=%lld model=%.3f GB\n", K, NW, Q.lxb, Q.rows,
+            Q.xv, Q.ntx, Q.nty, (long long)c.zchunk, (long long)blocks,
+            (long long)slab, c.cost * 1e-9);
   hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1>),
                      dim3((unsigned)blocks), dim3(NW * 64), 0, st, xbar_in, xbar_out,
-                     x_in, x_out, bt, p_in, p_out, G, S, Q, (int)zchunk, (int)slab);
+                     x_in, x_out, bt, p_in, p_out, G, S, Q, (int)c.zchunk, (int)slab);
   return launch_status();
 }
 
 template <typename T, int VEC, int NW, int K, int WPE>
-int launch_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
-             const T *p_in, T *p_out, const Geom<T> &G, const StageScalars<T, K> &S,
-             int flags, hipStream_t st) {
+int launch_k(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
+             const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
+             const StageScalars<T, K> &S, int flags, hipStream_t st) {
 #define NSOL_F(HB, L)                                                           \
-  launch_f<T, VEC, NW, K, WPE, HB, L>(xbar_in, xbar_out, x_in, x_out, bt, p_in,  \
+  launch_f<T, VEC, NW, K, WPE, HB, L>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in, \
                                       p_out, G, S, st)
   const bool huber = (flags & NSOL_PD_REG_HUBER) != 0;
   const bool l1 = (flags & NSOL_PD_DATA_L1) != 0;
@@ -478,26 +600,166 @@ int launch_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
 #undef NSOL_F
 }
 
+// workgroup sizes compiled per depth (16 waves: neither the registers nor the
+// LDS of K = 3 fit)
+template <int K> struct Waves;
+template <> struct Waves<2> { static constexpr int n = 3; static constexpr int v[3] = {16, 12, 8}; };
+template <> struct Waves<3> { static constexpr int n = 2; static constexpr int v[2] = {12, 8}; };
+
+template <typename T, int K>
+int launch_cfg(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in,
+               T *x_out, const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
+               const StageScalars<T, K> &S, int flags, hipStream_t st) {
+  constexpr int VW = 16 / sizeof(T);
+#define NSOL_W(NWV, WPE)                                                          \
+  launch_k<T, VW, NWV, K, WPE>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, \
+                               G, S, flags, st)
+  if (c.nw == 8) return NSOL_W(8, 2);
+  if (c.nw == 12) return NSOL_W(12, 3);
+  if constexpr (K == 2) {
+    if (c.nw == 16) return NSOL_W(16, 4);
+  }
+#undef NSOL_W
+  return NSOL_EINVAL;
+}
+
+template <int NT, int K> constexpr int lxm_of() { return LdsShape<NT, K>::LXM; }
+
+// candidate configurations for a shape, cheapest (by model) first
+template <typename T, int K>
+std::vector<Config> candidates(const Geom<T> &G) {
+  constexpr int VW = 16 / sizeof(T);
+  constexpr int H = K - 1;
+  constexpr int HX = ((H + VW - 1) / VW) * VW;
+  std::vector<Config> out;
+  const int64_t plane_bytes = G.sz * (int64_t)sizeof(T);
+  // 32-bit buffer offsets: the planes one workgroup touches span < 2^30 bytes
+  const int64_t max_planes = ((int64_t)1 << 30) / plane_bytes - 1;
+  const int64_t max_chunk = max_planes - 2 * K - 1;
+  if (max_chunk < 8) return out;
+  for (int wi = 0; wi < Waves<K>::n; ++wi) {
+    const int nw = Waves<K>::v[wi];
+    if (g_tunek.nw > 0 && g_tunek.nw != nw) continue;
+    const int nt = nw * 64;
+    const int lxm = nt / (2 * K);
+    for (int ntx = 1; ntx <= 64; ++ntx) {
+      if (g_tunek.ntx > 0 && ntx != g_tunek.ntx) continue;
+      Config c;
+      c.nw = nw;
+      if (!make_tiling(G.nx, G.ny, nt, VW, H, HX, lxm, ntx, &c.q)) continue;
+      const int64_t tiles = (int64_t)c.q.ntx * c.q.nty;
+      double zeff;
+      if (g_tunek.zchunk > 0) {
+        c.zchunk = g_tunek.zchunk < max_chunk ? g_tunek.zchunk : max_chunk;
+        if (c.zchunk > G.nz) c.zchunk = G.nz;
+        zeff = (double)c.zchunk / (double)(c.zchunk + 2 * H);
+      } else {
+        zeff = pick_zchunk(G.nz, tiles, 2 * H, max_chunk, &c.zchunk);
+      }
+      c.cost = model_cost(c.q, G.nx, G.ny, G.nz, VW, (int)sizeof(T), H, HX, zeff);
+      // fewer waves hide less latency: mild penalty so that ties go to more waves
+      c.cost *= 1.0 + 0.02 * (16 - nw) / 4.0;
+      out.push_back(c);
+    }
+  }
+  std::sort(out.begin(), out.end(),
+            [](const Config &a, const Config &b) { return a.cost < b.cost; });
+  return out;
+}
+
+struct PlanKey {
+  int esize, k;
+  int64_t nz, ny, nx;
+  bool operator<(const PlanKey &o) const {
+    return std::tie(esize, k, nz, ny, nx) < std::tie(o.esize, o.k, o.nz, o.ny, o.nx);
+  }
+};
+std::map<PlanKey, Config> g_plans;
+std::mutex g_plans_mutex;
+
+// Configuration for this shape.  Large volumes: the first call times the best few
+// model candidates on the caller's own buffers (every trial launch writes the
+// same, final values) and keeps the fastest for the life of the process.
+template <typename T, int K>
+int plan_for(const Geom<T> &G, Config *cfg, const T *xbar_in, T *xbar_out,
+             const T *x_in, T *x_out, const T *bt, const T *p_in, T *p_out,
+             const StageScalars<T, K> &S, int flags, hipStream_t st) {
+  const bool forced = g_tunek.nw > 0 || g_tunek.ntx > 0 || g_tunek.zchunk > 0;
+  const PlanKey key{(int)sizeof(T), K, G.nz, G.ny, G.nx};
+  std::lock_guard<std::mutex> lock(g_plans_mutex);
+  if (!forced) {
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) { *cfg = it->second; return 0; }
+  }
+  std::vector<Config> cand = candidates<T, K>(G);
+  if (cand.empty()) return -2;
+  Config best = cand[0];
+  const bool big = G.n >= ((int64_t)g_tunek.tune_min_mvox << 20);
+  if (!forced && g_tunek.autotune && big && cand.size() > 1) {
+    // best three tilings per workgroup size, each with the model's z-chunk and
+    // two shorter ones (more workgroups in flight)
+    std::vector<Config> trial;
+    int per_nw[17] = {0};
+    for (const Config &c : cand) {
+      if (per_nw[c.nw]++ >= 3) continue;
+      trial.push_back(c);
+      for (int64_t zc : {(int64_t)24, (int64_t)64}) {
+        if (zc >= c.zchunk || zc > G.nz) continue;
+        Config d = c;
+        d.zchunk = zc;
+        trial.push_back(d);
+      }
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+      return (int)hipGetLastError();
+    float best_ms = -1.f;
+    for (const Config &c : trial) {
+      float ms_min = -1.f;
+      for (int rep = 0; rep < 3; ++rep) {        // rep 0 warms up
+        hipEventRecord(e0, st);
+        int rc = launch_cfg<T, K>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out,
+                                  G, S, flags, st);
+        if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
+        hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) {
+          hipEventDestroy(e0); hipEventDestroy(e1);
+          return (int)hipGetLastError();
+        }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && (ms_min < 0.f || ms < ms_min)) ms_min = ms;
+      }
+      if (g_tunek.verbose)
+        fprintf(stderr, "k_pd_fusedk tune K=%d waves=%d ntx=%d zchunk=%lld: %.3f ms\n",
+                K, c.nw, c.q.ntx, (long long)c.zchunk, ms_min);
+      if (best_ms < 0.f || ms_min < best_ms) { best_ms = ms_min; best = c; }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+  }
+  if (!forced) g_plans[key] = best;
+  *cfg = best;
+  return 0;
+}
+
 template <typename T, int K>
 int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt,
              const T *p_in, T *p_out, const Geom<T> &G, const double *sigma,
              const double *hden, const double *tau, const double *tl,
              const double *theta, int flags, hipStream_t st) {
-  constexpr int VW = 16 / sizeof(T);
   StageScalars<T, K> S;
   for (int i = 0; i < K; ++i) {
     S.sigma[i] = (T)sigma[i]; S.hden[i] = (T)hden[i]; S.tau[i] = (T)tau[i];
     S.tl[i] = (T)tl[i]; S.optl[i] = prox_den<T>(tl[i]); S.theta[i] = (T)theta[i];
   }
   S.has_p = p_in != nullptr ? 1 : 0;
-  if (g_tunek.nw == 8)
-    return launch_k<T, VW, 8, K, 2>(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out,
-                                    G, S, flags, st);
-  if (g_tunek.nw == 12)
-    return launch_k<T, VW, 12, K, 3>(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out,
-                                     G, S, flags, st);
-  return launch_k<T, VW, 16, K, 4>(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G,
-                                   S, flags, st);
+  Config cfg;
+  int rc = plan_for<T, K>(G, &cfg, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, S,
+                          flags, st);
+  if (rc) return rc;
+  return launch_cfg<T, K>(cfg, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S,
+                          flags, st);
 }
 
 // returns -2 if the kernel does not apply to this problem
@@ -539,6 +801,13 @@ int nsol_hip_set_param_pdk(const char *name, int value) {
   else if (!strcmp(name, "pdk_zchunk")) nsol_pdk::g_tunek.zchunk = value;
   else if (!strcmp(name, "pdk_ntx")) nsol_pdk::g_tunek.ntx = value;
   else if (!strcmp(name, "pdk_xcd_map")) nsol_pdk::g_tunek.xcd_map = value;
+  else if (!strcmp(name, "pdk_verbose")) nsol_pdk::g_tunek.verbose = value;
+  else if (!strcmp(name, "pdk_autotune")) nsol_pdk::g_tunek.autotune = value;
+  else if (!strcmp(name, "pdk_tune_min_mvox")) nsol_pdk::g_tunek.tune_min_mvox = value;
+  else if (!strcmp(name, "pdk_forget")) {
+    std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
+    nsol_pdk::g_plans.clear();
+  }
   else return NSOL_EINVAL;
   return 0;
 }

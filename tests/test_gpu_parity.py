@@ -692,9 +692,11 @@ def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
     _lib.set_param("pd2_enable", enable2)
     _lib.set_param("pd2_zchunk", zchunk2)
     _lib.set_param("pd_two_pass", two_pass)
-    pdk_defaults = dict(pdk_enable=0, pdk_kmax=3, pdk_nw=16, pdk_zchunk=0,
+    pdk_defaults = dict(pdk_enable=1, pdk_kmax=3, pdk_nw=0, pdk_zchunk=0,
                         pdk_ntx=0)
-    for k, v in dict(pdk_defaults, **(pdk or {})).items():
+    # pdk=None: the depth-3 kernel stays out of the way (the callers compare
+    # the one-iteration kernel with k_pd_fused2)
+    for k, v in dict(pdk_defaults, **(pdk or {"pdk_enable": 0})).items():
         _lib.set_param(k, v)
     try:
         slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape,
@@ -735,9 +737,10 @@ def test_two_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters):
     ((9, 70, 264), np.float32), ((33, 20, 768), np.float32),
     ((8, 8, 1280), np.float32), ((21, 13, 132), np.float64),
     ((10, 37, 256), np.float64), ((12, 11, 600), np.float64),
-    ((16, 40, 32), np.float32), ((11, 100, 64), np.float64)])
+    ((16, 40, 32), np.float32), ((11, 100, 64), np.float64),
+    ((64, 64, 64), np.float32), ((16, 16, 128), np.float32)])
 @pytest.mark.parametrize("iters", [3, 8])
-@pytest.mark.parametrize("nw", [16, 12])
+@pytest.mark.parametrize("nw", [12, 8])
 def test_k_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters, nw):
     """Depth-3 / depth-2 temporal blocking on tiled footprints (k_pd_fusedk):
     forced x tilings (1..3 tiles), z-chunk seams, 3+3+2 and 3 iterations, all
@@ -745,12 +748,15 @@ def test_k_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters, nw):
     import torch
     from nsol_amd import ops
     for flags in (ops.PD_REG_HUBER | ops.PD_DATA_L1,
-                  ops.PD_REG_TV | ops.PD_DATA_L2):
+                  ops.PD_REG_TV | ops.PD_DATA_L2,
+                  ops.PD_REG_TV | ops.PD_DATA_L1,
+                  ops.PD_REG_HUBER | ops.PD_DATA_L2):
         ref = _run_pd_raw(shape, dtype, iters, flags, enable2=0)
         for cfg in (dict(), dict(pdk_zchunk=5), dict(pdk_ntx=1),
                     dict(pdk_ntx=2, pdk_zchunk=4), dict(pdk_ntx=3),
-                    dict(pdk_kmax=2), dict(pdk_kmax=2, pdk_ntx=2, pdk_zchunk=3)):
-            cfg = dict(cfg, pdk_enable=1, pdk_nw=nw)
+                    dict(pdk_kmax=2), dict(pdk_kmax=2, pdk_ntx=2, pdk_zchunk=3),
+                    dict(pdk_kmax=2, pdk_nw=16), dict(pdk_nw=0)):
+            cfg = dict(dict(pdk_enable=1, pdk_nw=nw), **cfg)
             got = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg)
             for a, b in zip(ref[:3], got[:3]):
                 assert torch.equal(a, b), (shape, cfg, flags)
@@ -760,12 +766,26 @@ def test_k_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters, nw):
                                    (130, 260, 1536), (64, 64, 2048)])
 def test_two_iterations_per_pass_large_shapes(nsol, shape):
     """HBM-sized, non-cubic volumes incl. several x-tiles (nx > 512) and a
-    ragged last y-tile: still bit-identical to the one-iteration kernel."""
+    ragged last y-tile: still bit-identical to the one-iteration kernel.  The
+    depth-3 kernel runs with its first-call autotuner here (3 + 1 and 3 + 2
+    iterations)."""
     import torch
     from nsol_amd import ops
     flags = ops.PD_REG_TV | ops.PD_DATA_L2
     ref = _run_pd_raw(shape, np.float32, 4, flags, enable2=0)
     got = _run_pd_raw(shape, np.float32, 4, flags, enable2=1)
+    for a, b in zip(ref[:3], got[:3]):
+        assert torch.equal(a, b), shape
+    got = _run_pd_raw(shape, np.float32, 4, flags, enable2=0,
+                      pdk=dict(pdk_enable=1))
+    for a, b in zip(ref[:3], got[:3]):
+        assert torch.equal(a, b), shape
+    del got, ref
+    torch.cuda.empty_cache()
+    flags = ops.PD_REG_HUBER | ops.PD_DATA_L1
+    ref = _run_pd_raw(shape, np.float32, 5, flags, enable2=0)
+    got = _run_pd_raw(shape, np.float32, 5, flags, enable2=1,
+                      pdk=dict(pdk_enable=1))
     for a, b in zip(ref[:3], got[:3]):
         assert torch.equal(a, b), shape
 
@@ -808,6 +828,12 @@ def test_full_size_512_properties(nsol):
     flags = _ops.PD_REG_HUBER | _ops.PD_DATA_L2
     a = _run_pd_raw(shape, np.float32, 5, flags, enable2=1)      # 2 + 2 + 1
     b = _run_pd_raw(shape, np.float32, 5, flags, enable2=0)      # 5 x 1
+    for u, v in zip(a[:3], b[:3]):
+        assert torch.equal(u, v)
+    del a
+    torch.cuda.empty_cache()
+    a = _run_pd_raw(shape, np.float32, 5, flags, enable2=1,
+                    pdk=dict(pdk_enable=1))                      # 3 + 2 (default)
     for u, v in zip(a[:3], b[:3]):
         assert torch.equal(u, v)
     del a
