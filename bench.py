@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--data", default="L2", choices=["L2", "L1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose-tuning", action="store_true",
+                    help="print the online tuner's decision (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only to rehearse N > 1 on a box with fewer "
@@ -118,6 +120,8 @@ def main():
     from nsol_amd.primal_dual_solver import step_schedule
     from nsol_amd.synthetic import synth_volume
     _lib.load()
+    if args.verbose_tuning:
+        _lib.set_param("pdk_verbose", 2)
 
     n = args.size
     shape = (n, n, n)
@@ -152,11 +156,15 @@ def main():
                          p_is_zero, 0.05, flags, x_alt=x_alt)
         state["slot"] = a ^ end
 
-    # Plan pass (untimed, like creating an FFT plan): the first launch of the
-    # depth-3 kernel on a new shape times a handful of footprint shapes and keeps
-    # the fastest for the life of the process.  The state is reset afterwards.
-    run(0, min(5, total), True)
-    torch.cuda.synchronize()
+    # Plan pass (untimed, like creating an FFT plan): the depth-3 kernel tunes
+    # its footprint shape online during the first few dozen launches on a new
+    # problem shape.  Run until it has settled, then reset the state.
+    for _ in range(8):
+        run(0, min(60, total), True)
+        torch.cuda.synchronize()
+        state["slot"] = 0
+        if ops.pd_fusedk_tuned(x, shape) != 0:
+            break
     x.copy_(bt)
     xbar[0].copy_(bt)
     state["slot"] = 0

@@ -258,6 +258,13 @@ int nsol_pd_fusedk_iter_f64(const double *xbar_in, double *xbar_out,
                             const double *sigma_k, const double *hden_k,
                             const double *tau_k, const double *tl_k,
                             const double *theta_k, int flags, void *stream);
+/* Footprint shape and z-chunk of nsol_pd_fusedk_iter_* are tuned online for
+ * volumes of >= 16 Mi voxels: the first few dozen launches of a new problem
+ * shape each try one candidate (they are real launches of the run, timed with
+ * events that are read back without synchronising), then the fastest is kept
+ * for the life of the process.  Returns 1 once a shape has settled, 0 while it
+ * is still exploring, -1 if the shape has not been seen. */
+int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx);
 /* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;

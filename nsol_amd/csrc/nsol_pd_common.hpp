@@ -70,6 +70,22 @@ __device__ __forceinline__ T dual_update_s(T p_old, T hi, T lo, T w, T sigma,
   return dual_clamp(q);
 }
 
+// UNIT: all inverse spacings are exactly 1.  x*1 and x*(-1) are exact, so
+// hi*1 + lo*(-1) == hi - lo and p*(-1) + pl*1 == pl - p bit for bit: the
+// multiplications can be dropped without changing a single result.
+template <bool HUBER, bool UNIT, typename T>
+__device__ __forceinline__ T dual_update_u(T p_old, T hi, T lo, T w, T sigma, T hden) {
+  const T g = UNIT ? hi - lo : hi * w + lo * (-w);
+  T q = p_old + sigma * g;
+  if constexpr (HUBER) q = q / hden;
+  return dual_clamp(q);
+}
+// one axis of K^T p: p*(-w) + p_prev*w
+template <bool UNIT, typename T>
+__device__ __forceinline__ T adj_term(T p, T p_prev, T w) {
+  return UNIT ? p_prev - p : p * (-w) + p_prev * w;
+}
+
 template <bool L1, typename T>
 __device__ __forceinline__ T prox_data_s(T u, T bt, T tl, T one_plus_tl) {
   if constexpr (L1) return prox_ell1(u, bt, tl);

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -110,7 +111,14 @@ struct LdsShape {
   static constexpr int N = NT + 2 * LXM;            // vectors per array
 };
 
-template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1>
+template <typename T, int V>
+struct PlaneLoads {          // registers one prefetched plane lands in
+  T xn[V], xv[V], btn[V], pxo[V], pyo[V], pzo[V], xdown[V], xup[V], pyup[V];
+  T xright, xleft, pxleft;
+};
+
+template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1, bool PF2,
+          bool UNIT>
 __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out,
     const T *__restrict__ x_in, T *__restrict__ x_out,
@@ -256,75 +264,77 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const T sg = s_first > 0 ? S.sigma[0] : T(0);
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      pz[0][j] = dual_update_s<HUBER>(pm[j], xc[j], xm[j], G.wz, sg, S.hden[0]);
+      pz[0][j] = dual_update_u<HUBER, UNIT>(pm[j], xc[j], xm[j], G.wz, sg, S.hden[0]);
   }
 
   // Software pipeline: the loads of plane s+1 are issued right after the stage-1
   // arithmetic of plane s and stay in flight while the later stages (and the
   // barrier) run -- the waves of a workgroup move in lockstep, so nothing else
   // would hide the latency.
-  T xn[VEC], xv[VEC], btn[VEC], pxo[VEC], pyo[VEC], pzo[VEC];
-  T xdown[VEC], xup[VEC], pyup[VEC];
-  T xright, xleft, pxleft;
-  auto issue_loads = [&](int64_t sp, uint32_t a) {
+  // PF2: two register sets, so the loads of plane s+1 are issued BEFORE the
+  // stage-1 arithmetic of plane s (a full step of latency hiding; +36 VGPRs).
+  typedef PlaneLoads<T, VEC> Loads;
+  Loads LA, LB;
+  auto issue_loads = [&](Loads &L, int64_t sp, uint32_t a) {
     // sp: plane; a: its scalar offset.  The plane above the volume is zero.
-    bld<T, VEC>(r_xb, (sp + 1 < G.nz) ? v_own : kInvalid, a + szb, xn);
-    bld<T, VEC>(r_x, v_own, a, xv);
-    bld<T, VEC>(r_bt, v_own, a, btn);
-    bld<T, VEC>(r_px, v_own, a, pxo);
-    bld<T, VEC>(r_py, v_own, a, pyo);
-    bld<T, VEC>(r_pz, v_own, a, pzo);
-    xright = bld1<T>(r_xb, v_right, a);
-    xleft = bld1<T>(r_xb, v_left, a);
-    pxleft = bld1<T>(r_px, v_left, a);
-    bld<T, VEC>(r_xb, v_down, a, xdown);
-    bld<T, VEC>(r_xb, v_up, a, xup);
-    bld<T, VEC>(r_py, v_up, a, pyup);
+    bld<T, VEC>(r_xb, (sp + 1 < G.nz) ? v_own : kInvalid, a + szb, L.xn);
+    bld<T, VEC>(r_x, v_own, a, L.xv);
+    bld<T, VEC>(r_bt, v_own, a, L.btn);
+    bld<T, VEC>(r_px, v_own, a, L.pxo);
+    bld<T, VEC>(r_py, v_own, a, L.pyo);
+    bld<T, VEC>(r_pz, v_own, a, L.pzo);
+    L.xright = bld1<T>(r_xb, v_right, a);
+    L.xleft = bld1<T>(r_xb, v_left, a);
+    L.pxleft = bld1<T>(r_px, v_left, a);
+    bld<T, VEC>(r_xb, v_down, a, L.xdown);
+    bld<T, VEC>(r_xb, v_up, a, L.xup);
+    bld<T, VEC>(r_py, v_up, a, L.pyup);
   };
-  issue_loads(s_first, adv);
+  issue_loads(LA, s_first, adv);
 
   // one plane step; HAVE1 = false in the drain steps above the volume's last plane
-  auto step = [&](auto have1_tag, int64_t s) {
+  auto step = [&](auto have1_tag, int64_t s, Loads &L, Loads &LN) {
     constexpr bool HAVE1 = decltype(have1_tag)::value;
     // fr_*[k-1]: results of stage k produced in this step
     T fr_xb[K][VEC], fr_x[K][VEC], fr_bt[K][VEC], pzn[K][VEC];
     T f_px[VEC], f_py[VEC];
     if constexpr (HAVE1) {
+      // prefetch plane s+1 (after the last plane: re-reads it, unused)
+      const bool more = s + 1 <= s_hi;
+      if constexpr (PF2) issue_loads(LN, more ? s + 1 : s, more ? adv + szb : adv);
       // ================= stage 1: iteration n+1 on plane s ===================
       T nb = __shfl_down(xc[0], 1, kWave);
-      if (row_end) nb = xright;
+      if (row_end) nb = L.xright;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const T hx = (j + 1 < VEC) ? xc[(j + 1) % VEC] : nb;
-        f_px[j] = dual_update_s<HUBER>(pxo[j], hx, xc[j], G.wx, sig_m[0], S.hden[0]);
-        f_py[j] = dual_update_s<HUBER>(pyo[j], xdown[j], xc[j], G.wy, sig_m[0], S.hden[0]);
-        pzn[0][j] = dual_update_s<HUBER>(pzo[j], xn[j], xc[j], G.wz, sig_m[0], S.hden[0]);
+        f_px[j] = dual_update_u<HUBER, UNIT>(L.pxo[j], hx, xc[j], G.wx, sig_m[0], S.hden[0]);
+        f_py[j] = dual_update_u<HUBER, UNIT>(L.pyo[j], L.xdown[j], xc[j], G.wy, sig_m[0], S.hden[0]);
+        pzn[0][j] = dual_update_u<HUBER, UNIT>(L.pzo[j], L.xn[j], xc[j], G.wz, sig_m[0], S.hden[0]);
       }
       T pxl = __shfl_up(f_px[VEC - 1], 1, kWave);
       if (row_beg)
-        pxl = g_l ? dual_update_s<HUBER>(pxleft, xc[0], xleft, G.wx, S.sigma[0],
+        pxl = g_l ? dual_update_u<HUBER, UNIT>(L.pxleft, xc[0], L.xleft, G.wx, S.sigma[0],
                                          S.hden[0])
                   : T(0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T pu = g_u ? dual_update_s<HUBER>(pyup[j], xc[j], xup[j], G.wy,
+        const T pu = g_u ? dual_update_u<HUBER, UNIT>(L.pyup[j], xc[j], L.xup[j], G.wy,
                                                 S.sigma[0], S.hden[0])
                          : T(0);
         const T pl = (j > 0) ? f_px[(j + VEC - 1) % VEC] : pxl;
-        T kt = f_px[j] * (-G.wx) + pl * G.wx;
-        kt += f_py[j] * (-G.wy) + pu * G.wy;
-        kt += pzn[0][j] * (-G.wz) + pz[0][j] * G.wz;
-        const T u = xv[j] - tau_m[0] * kt;
-        const T xnew = prox_data_s<L1>(u, btn[j], S.tl[0], S.optl[0]);
+        T kt = adj_term<UNIT>(f_px[j], pl, G.wx);
+        kt += adj_term<UNIT>(f_py[j], pu, G.wy);
+        kt += adj_term<UNIT>(pzn[0][j], pz[0][j], G.wz);
+        const T u = L.xv[j] - tau_m[0] * kt;
+        const T xnew = prox_data_s<L1>(u, L.btn[j], S.tl[0], S.optl[0]);
         fr_x[0][j] = xnew;
-        fr_xb[0][j] = xnew + S.theta[0] * (xnew - xv[j]);
-        fr_bt[0][j] = btn[j];
+        fr_xb[0][j] = xnew + S.theta[0] * (xnew - L.xv[j]);
+        fr_bt[0][j] = L.btn[j];
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) xc[j] = xn[j];
-      // prefetch plane s+1 (the step after the last plane re-reads it: unused)
-      const bool more = s + 1 <= s_hi;
-      issue_loads(more ? s + 1 : s, more ? adv + szb : adv);
+      for (int j = 0; j < VEC; ++j) xc[j] = L.xn[j];
+      if constexpr (!PF2) issue_loads(L, more ? s + 1 : s, more ? adv + szb : adv);
     } else {
       zero(fr_xb[0]); zero(fr_x[0]); zero(fr_bt[0]); zero(pzn[0]);
       zero(f_px); zero(f_py);
@@ -341,10 +351,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       T pkz[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        pkz[j] = dual_update_s<HUBER>(pz[k - 2][j], fr_xb[k - 2][j], c_xb[k - 1][j],
+        pkz[j] = dual_update_u<HUBER, UNIT>(pz[k - 2][j], fr_xb[k - 2][j], c_xb[k - 1][j],
                                       G.wz, sk, S.hden[k - 1]);
         T kt = c_kt[k - 1][j];
-        kt += pkz[j] * (-G.wz) + pz[k - 1][j] * G.wz;
+        kt += adj_term<UNIT>(pkz[j], pz[k - 1][j], G.wz);
         const T u = c_x[k - 1][j] - tk * kt;
         const T xk = prox_data_s<L1>(u, c_bt[k - 1][j], S.tl[k - 1], S.optl[k - 1]);
         fr_x[k - 1][j] = xk;
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       const T left_xb = s_xb[buf][k - 2][li - 1];
       T left_px = __shfl_up((k == 2) ? f_px[VEC - 1] : c_px[k - 1][VEC - 1], 1, kWave);
       if (lane == 0) left_px = s_px[buf][k - 2][tid > 0 ? (tid >> 6) - 1 : 0];
-      const T pl0 = v_l ? dual_update_s<HUBER>(left_px, fr_xb[k - 2][0], left_xb, G.wx,
+      const T pl0 = v_l ? dual_update_u<HUBER, UNIT>(left_px, fr_xb[k - 2][0], left_xb, G.wx,
                                                S.sigma[k - 1], S.hden[k - 1])
                         : T(0);
       T pkx[VEC], pky[VEC];
@@ -395,19 +405,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         const T px_old = (k == 2) ? f_px[j] : c_px[k - 1][j];
         const T py_old = (k == 2) ? f_py[j] : c_py[k - 1][j];
         const T hx = (j + 1 < VEC) ? fr_xb[k - 2][(j + 1) % VEC] : right;
-        pkx[j] = dual_update_s<HUBER>(px_old, hx, fr_xb[k - 2][j], G.wx, sig_m[k - 1],
+        pkx[j] = dual_update_u<HUBER, UNIT>(px_old, hx, fr_xb[k - 2][j], G.wx, sig_m[k - 1],
                                       S.hden[k - 1]);
-        pky[j] = dual_update_s<HUBER>(py_old, below[j], fr_xb[k - 2][j], G.wy,
+        pky[j] = dual_update_u<HUBER, UNIT>(py_old, below[j], fr_xb[k - 2][j], G.wy,
                                       sig_m[k - 1], S.hden[k - 1]);
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T pu = v_u ? dual_update_s<HUBER>(above_py[j], fr_xb[k - 2][j], above[j],
+        const T pu = v_u ? dual_update_u<HUBER, UNIT>(above_py[j], fr_xb[k - 2][j], above[j],
                                                 G.wy, S.sigma[k - 1], S.hden[k - 1])
                          : T(0);
         const T pl = (j > 0) ? pkx[(j + VEC - 1) % VEC] : pl0;
-        T kt = pkx[j] * (-G.wx) + pl * G.wx;
-        kt += pky[j] * (-G.wy) + pu * G.wy;
+        T kt = adj_term<UNIT>(pkx[j], pl, G.wx);
+        kt += adj_term<UNIT>(pky[j], pu, G.wy);
         n_kt[k - 1][j] = kt;
         n_px[k - 1][j] = pkx[j];
         n_py[k - 1][j] = pky[j];
@@ -446,8 +456,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
 
   __syncthreads();   // LDS padding rows are zero before anyone reads them
   int64_t s = s_first;
-  for (; s <= s_hi; ++s) step(std::true_type{}, s);
-  for (; s <= s_last; ++s) step(std::false_type{}, s);
+  if constexpr (PF2) {
+    for (; s + 1 <= s_hi; s += 2) {
+      step(std::true_type{}, s, LA, LB);
+      step(std::true_type{}, s + 1, LB, LA);
+    }
+    if (s <= s_hi) { step(std::true_type{}, s, LA, LB); ++s; }
+  } else {
+    for (; s <= s_hi; ++s) step(std::true_type{}, s, LA, LA);
+  }
+  for (; s <= s_last; ++s) step(std::false_type{}, s, LA, LA);
 }
 
 struct Tuning {
@@ -460,6 +478,7 @@ struct Tuning {
   int verbose = 0;
   int autotune = 1;   // time the best few model candidates once per problem shape
   int tune_min_mvox = 16;   // ... for volumes of at least this many Mi voxels
+  int pf2 = -1;       // -1 = where the registers allow; 0 / 1 force
 };
 Tuning g_tunek;
 
@@ -478,6 +497,7 @@ inline int cu_count() {
 
 struct Config {
   int nw = 0;
+  int pf2 = 0;       // 1 = two prefetch register sets
   Tiling q{};
   int64_t zchunk = 0;
   double cost = 0.0;      // modelled bytes through L2 -> fabric per launch
@@ -561,7 +581,8 @@ inline bool al16(const T *a) {
   return (reinterpret_cast<uintptr_t>(a) & 15u) == 0;
 }
 
-template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1>
+template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1, bool PF2,
+          bool UNIT>
 int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
              const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
              const StageScalars<T, K> &S, hipStream_t st) {
@@ -575,24 +596,27 @@ int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x
     blocks = 8 * slab * nzc;
   }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
-  if (g_tunek.verbose)
-    fprintf(stderr, "k_pd_fusedk K=%d waves=%d: lxb=%d rows=%d xv=%d tiles=%dx%d "
-            "zchunk=%lld blocks=%lld slab=%lld model=%.3f GB\n", K, NW, Q.lxb, Q.rows,
+  if (g_tunek.verbose == 1)
+    fprintf(stderr, "k_pd_fusedk K=%d waves=%d pf2=%d: lxb=%d rows=%d xv=%d tiles=%dx%d "
+            "zchunk=%lld blocks=%lld slab=%lld model=%.3f GB\n", K, NW, (int)PF2, Q.lxb, Q.rows,
             Q.xv, Q.ntx, Q.nty, (long long)c.zchunk, (long long)blocks,
             (long long)slab, c.cost * 1e-9);
-  hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1>),
+  hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1, PF2, UNIT>),
                      dim3((unsigned)blocks), dim3(NW * 64), 0, st, xbar_in, xbar_out,
                      x_in, x_out, bt, p_in, p_out, G, S, Q, (int)c.zchunk, (int)slab);
   return launch_status();
 }
 
-template <typename T, int VEC, int NW, int K, int WPE>
+template <typename T, int VEC, int NW, int K, int WPE, bool PF2>
 int launch_k(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
              const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
              const StageScalars<T, K> &S, int flags, hipStream_t st) {
 #define NSOL_F(HB, L)                                                           \
-  launch_f<T, VEC, NW, K, WPE, HB, L>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in, \
-                                      p_out, G, S, st)
+  (unit ? launch_f<T, VEC, NW, K, WPE, HB, L, PF2, true>(                       \
+              c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S, st)     \
+        : launch_f<T, VEC, NW, K, WPE, HB, L, PF2, false>(                      \
+              c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S, st))
+  const bool unit = G.wx == T(1) && G.wy == T(1) && G.wz == T(1);
   const bool huber = (flags & NSOL_PD_REG_HUBER) != 0;
   const bool l1 = (flags & NSOL_PD_DATA_L1) != 0;
   if (huber) return l1 ? NSOL_F(true, true) : NSOL_F(true, false);
@@ -611,13 +635,16 @@ int launch_cfg(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in,
                T *x_out, const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
                const StageScalars<T, K> &S, int flags, hipStream_t st) {
   constexpr int VW = 16 / sizeof(T);
-#define NSOL_W(NWV, WPE)                                                          \
-  launch_k<T, VW, NWV, K, WPE>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, \
-                               G, S, flags, st)
-  if (c.nw == 8) return NSOL_W(8, 2);
-  if (c.nw == 12) return NSOL_W(12, 3);
+#define NSOL_W(NWV, WPE, PF)                                                      \
+  launch_k<T, VW, NWV, K, WPE, PF>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in,     \
+                                   p_out, G, S, flags, st)
+  // two prefetch register sets where the register file has room for them
+  if (c.nw == 8) return c.pf2 ? NSOL_W(8, 2, true) : NSOL_W(8, 2, false);
   if constexpr (K == 2) {
-    if (c.nw == 16) return NSOL_W(16, 4);
+    if (c.nw == 12) return NSOL_W(12, 3, false);
+    if (c.nw == 16) return NSOL_W(16, 4, false);
+  } else {
+    if (c.nw == 12) return NSOL_W(12, 3, false);
   }
 #undef NSOL_W
   return NSOL_EINVAL;
@@ -646,6 +673,8 @@ std::vector<Config> candidates(const Geom<T> &G) {
       if (g_tunek.ntx > 0 && ntx != g_tunek.ntx) continue;
       Config c;
       c.nw = nw;
+      c.pf2 = (nw == 8) ? 1 : 0;
+      if (g_tunek.pf2 == 0) c.pf2 = 0;
       if (!make_tiling(G.nx, G.ny, nt, VW, H, HX, lxm, ntx, &c.q)) continue;
       const int64_t tiles = (int64_t)c.q.ntx * c.q.nty;
       double zeff;
@@ -674,73 +703,70 @@ struct PlanKey {
     return std::tie(esize, k, nz, ny, nx) < std::tie(o.esize, o.k, o.nz, o.ny, o.nx);
   }
 };
-std::map<PlanKey, Config> g_plans;
+// Online autotuner.  A plan holds the model's best few configurations; while a
+// plan is exploring, every REAL launch of the run uses the next candidate and
+// is bracketed by two events that are read back later with hipEventQuery -- no
+// trial launches, no host synchronisation.  After `kRounds` samples per
+// candidate (candidates >12 % behind after the first round are dropped) the
+// fastest one is kept for the life of the process.
+struct Sample { hipEvent_t e0, e1; int cand; };
+struct Plan {
+  std::vector<Config> cand;
+  std::vector<float> best_ms;
+  std::vector<int> issued, done;
+  std::vector<char> dropped;
+  std::deque<Sample> pending;
+  int chosen = -1;
+};
+constexpr int kRounds = 2;
+std::map<PlanKey, Plan> g_plans;
 std::mutex g_plans_mutex;
 
-// Configuration for this shape.  Large volumes: the first call times the best few
-// model candidates on the caller's own buffers (every trial launch writes the
-// same, final values) and keeps the fastest for the life of the process.
-template <typename T, int K>
-int plan_for(const Geom<T> &G, Config *cfg, const T *xbar_in, T *xbar_out,
-             const T *x_in, T *x_out, const T *bt, const T *p_in, T *p_out,
-             const StageScalars<T, K> &S, int flags, hipStream_t st) {
-  const bool forced = g_tunek.nw > 0 || g_tunek.ntx > 0 || g_tunek.zchunk > 0;
-  const PlanKey key{(int)sizeof(T), K, G.nz, G.ny, G.nx};
-  std::lock_guard<std::mutex> lock(g_plans_mutex);
-  if (!forced) {
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) { *cfg = it->second; return 0; }
-  }
-  std::vector<Config> cand = candidates<T, K>(G);
-  if (cand.empty()) return -2;
-  Config best = cand[0];
-  const bool big = G.n >= ((int64_t)g_tunek.tune_min_mvox << 20);
-  if (!forced && g_tunek.autotune && big && cand.size() > 1) {
-    // best three tilings per workgroup size, each with the model's z-chunk and
-    // two shorter ones (more workgroups in flight)
-    std::vector<Config> trial;
-    int per_nw[17] = {0};
-    for (const Config &c : cand) {
-      if (per_nw[c.nw]++ >= 3) continue;
-      trial.push_back(c);
-      for (int64_t zc : {(int64_t)24, (int64_t)64}) {
-        if (zc >= c.zchunk || zc > G.nz) continue;
-        Config d = c;
-        d.zchunk = zc;
-        trial.push_back(d);
-      }
+inline void plan_poll(Plan &P, int K) {
+  while (!P.pending.empty()) {
+    Sample sm = P.pending.front();
+    hipError_t q = hipEventQuery(sm.e1);
+    if (q == hipErrorNotReady) break;
+    float ms = 0.f;
+    if (q == hipSuccess && hipEventElapsedTime(&ms, sm.e0, sm.e1) == hipSuccess) {
+      if (P.best_ms[sm.cand] < 0.f || ms < P.best_ms[sm.cand]) P.best_ms[sm.cand] = ms;
+      P.done[sm.cand]++;
+    } else {
+      (void)hipGetLastError();
+      P.issued[sm.cand]--;              // lost sample: take it again
     }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-      return (int)hipGetLastError();
-    float best_ms = -1.f;
-    for (const Config &c : trial) {
-      float ms_min = -1.f;
-      for (int rep = 0; rep < 3; ++rep) {        // rep 0 warms up
-        hipEventRecord(e0, st);
-        int rc = launch_cfg<T, K>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out,
-                                  G, S, flags, st);
-        if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
-        hipEventRecord(e1, st);
-        if (hipEventSynchronize(e1) != hipSuccess) {
-          hipEventDestroy(e0); hipEventDestroy(e1);
-          return (int)hipGetLastError();
-        }
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (rep > 0 && (ms_min < 0.f || ms < ms_min)) ms_min = ms;
-      }
-      if (g_tunek.verbose)
-        fprintf(stderr, "k_pd_fusedk tune K=%d waves=%d ntx=%d zchunk=%lld: %.3f ms\n",
-                K, c.nw, c.q.ntx, (long long)c.zchunk, ms_min);
-      if (best_ms < 0.f || ms_min < best_ms) { best_ms = ms_min; best = c; }
-    }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(sm.e0);
+    (void)hipEventDestroy(sm.e1);
+    P.pending.pop_front();
   }
-  if (!forced) g_plans[key] = best;
-  *cfg = best;
-  return 0;
+  if (P.chosen >= 0) return;
+  const int n = (int)P.cand.size();
+  // drop the stragglers once everybody has one sample
+  bool round1 = true;
+  float best = -1.f;
+  for (int i = 0; i < n; ++i) {
+    if (P.dropped[i]) continue;
+    if (P.done[i] < 1) round1 = false;
+    else if (best < 0.f || P.best_ms[i] < best) best = P.best_ms[i];
+  }
+  if (round1)
+    for (int i = 0; i < n; ++i)
+      if (!P.dropped[i] && P.best_ms[i] > 1.12f * best) P.dropped[i] = 1;
+  bool all = true;
+  for (int i = 0; i < n; ++i)
+    if (!P.dropped[i] && P.done[i] < kRounds) all = false;
+  if (all) {
+    int arg = 0;
+    for (int i = 0; i < n; ++i)
+      if (!P.dropped[i] && (P.dropped[arg] || P.best_ms[i] < P.best_ms[arg])) arg = i;
+    P.chosen = arg;
+    if (g_tunek.verbose) {
+      for (int i = 0; i < n; ++i)
+        fprintf(stderr, "k_pd_fusedk tune K=%d waves=%d ntx=%d zchunk=%lld: %.3f ms%s\n",
+                K, P.cand[i].nw, P.cand[i].q.ntx, (long long)P.cand[i].zchunk,
+                P.best_ms[i], i == arg ? "  <- kept" : (P.dropped[i] ? "  (dropped)" : ""));
+    }
+  }
 }
 
 template <typename T, int K>
@@ -754,12 +780,85 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     S.tl[i] = (T)tl[i]; S.optl[i] = prox_den<T>(tl[i]); S.theta[i] = (T)theta[i];
   }
   S.has_p = p_in != nullptr ? 1 : 0;
-  Config cfg;
-  int rc = plan_for<T, K>(G, &cfg, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, S,
-                          flags, st);
-  if (rc) return rc;
-  return launch_cfg<T, K>(cfg, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S,
-                          flags, st);
+#define NSOL_GO(cfg)                                                              \
+  launch_cfg<T, K>(cfg, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S, flags, st)
+  const bool forced = g_tunek.nw > 0 || g_tunek.ntx > 0 || g_tunek.zchunk > 0;
+  if (forced) {                     // experiments and tests: no plan, no tuning
+    std::vector<Config> cand = candidates<T, K>(G);
+    if (cand.empty()) return -2;
+    return NSOL_GO(cand[0]);
+  }
+  const PlanKey key{(int)sizeof(T), K, G.nz, G.ny, G.nx};
+  std::lock_guard<std::mutex> lock(g_plans_mutex);
+  auto it = g_plans.find(key);
+  if (it == g_plans.end()) {
+    Plan P;
+    std::vector<Config> cand = candidates<T, K>(G);
+    if (cand.empty()) return -2;
+    const bool big = G.n >= ((int64_t)g_tunek.tune_min_mvox << 20);
+    if (g_tunek.autotune && big && cand.size() > 1) {
+      // the model's best five tilings per workgroup size, each also with a
+      // shorter z-chunk (more workgroups in flight)
+      int per_nw[17] = {0};
+      for (const Config &c : cand) {
+        if (per_nw[c.nw]++ >= 5) continue;
+        P.cand.push_back(c);
+        const int64_t zc = c.zchunk > 96 ? 64 : 24;
+        if (zc < c.zchunk && zc <= G.nz) {
+          Config d = c;
+          d.zchunk = zc;
+          P.cand.push_back(d);
+        }
+      }
+    } else {
+      P.cand.push_back(cand[0]);
+      P.chosen = 0;
+    }
+    const size_t n = P.cand.size();
+    P.best_ms.assign(n, -1.f);
+    P.issued.assign(n, 0);
+    P.done.assign(n, 0);
+    P.dropped.assign(n, 0);
+    it = g_plans.emplace(key, std::move(P)).first;
+  }
+  Plan &P = it->second;
+  plan_poll(P, K);
+  if (P.chosen >= 0) return NSOL_GO(P.cand[P.chosen]);
+  // exploring: next candidate that still needs a sample (the first launch of a
+  // run reads no dual variable, so it is cheaper than all others: not a sample)
+  int pick = -1;
+  for (int r = 1; r <= kRounds && pick < 0 && S.has_p; ++r)
+    for (int i = 0; i < (int)P.cand.size() && pick < 0; ++i)
+      if (!P.dropped[i] && P.issued[i] < r) pick = i;
+  if (pick < 0) {
+    // every sample is in flight: run the best one known so far meanwhile
+    pick = 0;
+    for (int i = 0; i < (int)P.cand.size(); ++i)
+      if (!P.dropped[i] && P.best_ms[i] >= 0.f &&
+          (P.best_ms[pick] < 0.f || P.best_ms[i] < P.best_ms[pick]))
+        pick = i;
+    return NSOL_GO(P.cand[pick]);
+  }
+  Sample sm;
+  sm.cand = pick;
+  if (hipEventCreate(&sm.e0) != hipSuccess) { (void)hipGetLastError(); return NSOL_GO(P.cand[pick]); }
+  if (hipEventCreate(&sm.e1) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipEventDestroy(sm.e0);
+    return NSOL_GO(P.cand[pick]);
+  }
+  (void)hipEventRecord(sm.e0, st);
+  const int rc = NSOL_GO(P.cand[pick]);
+  (void)hipEventRecord(sm.e1, st);
+  if (rc == 0) {
+    P.issued[pick]++;
+    P.pending.push_back(sm);
+  } else {
+    (void)hipEventDestroy(sm.e0);
+    (void)hipEventDestroy(sm.e1);
+  }
+  return rc;
+#undef NSOL_GO
 }
 
 // returns -2 if the kernel does not apply to this problem
@@ -803,13 +902,27 @@ int nsol_hip_set_param_pdk(const char *name, int value) {
   else if (!strcmp(name, "pdk_xcd_map")) nsol_pdk::g_tunek.xcd_map = value;
   else if (!strcmp(name, "pdk_verbose")) nsol_pdk::g_tunek.verbose = value;
   else if (!strcmp(name, "pdk_autotune")) nsol_pdk::g_tunek.autotune = value;
+  else if (!strcmp(name, "pdk_pf2")) nsol_pdk::g_tunek.pf2 = value;
   else if (!strcmp(name, "pdk_tune_min_mvox")) nsol_pdk::g_tunek.tune_min_mvox = value;
   else if (!strcmp(name, "pdk_forget")) {
     std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
+    for (auto &kv : nsol_pdk::g_plans)
+      for (auto &sm : kv.second.pending) {
+        (void)hipEventDestroy(sm.e0);
+        (void)hipEventDestroy(sm.e1);
+      }
     nsol_pdk::g_plans.clear();
   }
   else return NSOL_EINVAL;
   return 0;
+}
+
+int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx) {
+  std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
+  auto it = nsol_pdk::g_plans.find(nsol_pdk::PlanKey{elem_size, k, nz, ny, nx});
+  if (it == nsol_pdk::g_plans.end()) return -1;
+  nsol_pdk::plan_poll(it->second, k);
+  return it->second.chosen >= 0 ? 1 : 0;
 }
 
 int nsol_pd_fusedk_iter_f32(const float *xbar_in, float *xbar_out, const float *x_in,

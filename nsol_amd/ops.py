@@ -321,6 +321,14 @@ def pd_fusedk_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
     return True
 
 
+def pd_fusedk_tuned(x, shape, k=3):
+    """1 once the online tuner of the k-iterations-per-pass kernel has settled
+    for this shape / dtype, 0 while exploring, -1 if the shape is unknown."""
+    ndim, nz, ny, nx = dims3(shape)
+    return int(_lib.load().nsol_pd_fusedk_tuned(int(x.element_size()), int(k),
+                                                nz, ny, nx))
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
            p_is_zero, gamma_huber, flags, x_alt=None):
     """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that

@@ -677,7 +677,7 @@ def test_x_scale_invariance(nsol, golden):
 
 # ------------------------------------------- two iterations per pass (TB2)
 def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
-                two_pass=0, pdk=None):
+                two_pass=0, pdk=None, w=(1.0, 0.5, 2.0)):
     import torch
     from nsol_amd import ops, _lib
     from nsol_amd.primal_dual_solver import step_schedule
@@ -700,7 +700,7 @@ def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
         _lib.set_param(k, v)
     try:
         slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape,
-                          (1.0, 0.5, 2.0), 20.0, sig, ta, th, True, 0.05,
+                          w, 20.0, sig, ta, th, True, 0.05,
                           flags, x_alt=torch.empty_like(x))
         torch.cuda.synchronize()
     finally:
@@ -751,13 +751,23 @@ def test_k_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters, nw):
                   ops.PD_REG_TV | ops.PD_DATA_L2,
                   ops.PD_REG_TV | ops.PD_DATA_L1,
                   ops.PD_REG_HUBER | ops.PD_DATA_L2):
-        ref = _run_pd_raw(shape, dtype, iters, flags, enable2=0)
+        # unit spacing takes the multiplication-free specialisation
+        w = (1.0, 1.0, 1.0) if flags & ops.PD_REG_HUBER else (1.0, 0.5, 2.0)
+        for cfg in (dict(), dict(pdk_ntx=2, pdk_zchunk=4)):
+            cfg = dict(dict(pdk_enable=1, pdk_nw=nw), **cfg)
+            a = _run_pd_raw(shape, dtype, iters, flags, enable2=0, w=w[::-1])
+            b = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg,
+                            w=w[::-1])
+            for u, v in zip(a[:3], b[:3]):
+                assert torch.equal(u, v), (shape, cfg, flags, "w swapped")
+        ref = _run_pd_raw(shape, dtype, iters, flags, enable2=0, w=w)
         for cfg in (dict(), dict(pdk_zchunk=5), dict(pdk_ntx=1),
                     dict(pdk_ntx=2, pdk_zchunk=4), dict(pdk_ntx=3),
                     dict(pdk_kmax=2), dict(pdk_kmax=2, pdk_ntx=2, pdk_zchunk=3),
                     dict(pdk_kmax=2, pdk_nw=16), dict(pdk_nw=0)):
             cfg = dict(dict(pdk_enable=1, pdk_nw=nw), **cfg)
-            got = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg)
+            got = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg,
+                              w=w)
             for a, b in zip(ref[:3], got[:3]):
                 assert torch.equal(a, b), (shape, cfg, flags)
 
