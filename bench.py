@@ -55,15 +55,21 @@ class HipEvents(object):
         return float(ms.value)
 
 
-def measured_traffic(n):
+def measured_traffic(n, plan=None):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3
     PMC passes (profiles/latest_pmc.json, written by tools/summarize_profiles.py);
-    None when no profile of this problem size is on record."""
+    None when no profile of this problem size -- and, if the profile names the
+    kernel configuration it was taken with, of this configuration -- is on
+    record."""
     path = os.path.join(ROOT, "profiles", "latest_pmc.json")
     try:
         rec = json.load(open(path))
-        if int(rec.get("size", 0)) == n:
-            return float(rec["traffic_bytes_per_launch"])
+        if int(rec.get("size", 0)) != n:
+            return None
+        cfg = rec.get("kernel_config")
+        if cfg and plan and tuple(cfg) != tuple(plan[:3]):
+            return None
+        return float(rec["traffic_bytes_per_launch"])
     except Exception:
         pass
     return None
@@ -91,6 +97,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--data", default="L2", choices=["L2", "L1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pdk", default="",
+                    help="waves:ntx:zchunk -- pin the depth-3 kernel's "
+                         "configuration instead of tuning (profiling passes)")
     ap.add_argument("--verbose-tuning", action="store_true",
                     help="print the online tuner's decision (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=256)
@@ -122,6 +131,12 @@ def main():
     _lib.load()
     if args.verbose_tuning:
         _lib.set_param("pdk_verbose", 2)
+    pinned = None
+    if args.pdk:
+        pinned = tuple(int(t) for t in args.pdk.split(":"))
+        _lib.set_param("pdk_nw", pinned[0])
+        _lib.set_param("pdk_ntx", pinned[1])
+        _lib.set_param("pdk_zchunk", pinned[2])
 
     n = args.size
     shape = (n, n, n)
@@ -163,8 +178,9 @@ def main():
         run(0, min(60, total), True)
         torch.cuda.synchronize()
         state["slot"] = 0
-        if ops.pd_fusedk_tuned(x, shape) != 0:
+        if pinned or ops.pd_fusedk_tuned(x, shape) != 0:
             break
+    plan = pinned or ops.pd_fusedk_plan(x, shape)
     x.copy_(bt)
     xbar[0].copy_(bt)
     state["slot"] = 0
@@ -278,18 +294,22 @@ def main():
                 "volumes": world, "voxels_per_volume": nvox,
                 "kernel": "k_pd_fusedk (three iterations per pass; trailing "
                           "iterations: k_pd_fused2 / k_pd_fused)",
+                "kernel_config": None if plan is None else {
+                    "waves": plan[0], "tiles_x": plan[1], "zchunk": plan[2],
+                    "pinned": bool(pinned)},
                 "gather_ms": gather_ms, "result_finite": finite},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(n),
+                "traffic": measured_traffic(n, plan),
                 "bytes_per_launch": bytes_per_launch,
                 "iterations_per_launch": iters_per_launch,
                 "launches": launches,
                 "avg_launch_ms": kernel_ms,
                 # what the memory system actually carries (PMC, per launch)
-                "traffic_rate_GBps": (measured_traffic(n) / (kernel_ms * 1e-3)
-                                      / 1e9) if measured_traffic(n) else None,
+                "traffic_rate_GBps": (measured_traffic(n, plan) /
+                                      (kernel_ms * 1e-3) / 1e9)
+                if measured_traffic(n, plan) else None,
                 "single_pass_reference": single},
         }
         if world == 1 and not args.no_cpu_baseline:

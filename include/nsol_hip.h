@@ -265,6 +265,10 @@ int nsol_pd_fusedk_iter_f64(const double *xbar_in, double *xbar_out,
  * for the life of the process.  Returns 1 once a shape has settled, 0 while it
  * is still exploring, -1 if the shape has not been seen. */
 int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx);
+/* The settled configuration (waves per workgroup, tiles along x, z-chunk);
+ * NSOL_EINVAL while the shape is unknown or still exploring. */
+int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,
+                        int *waves, int *ntx, int64_t *zchunk);
 /* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;

@@ -925,6 +925,18 @@ int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t n
   return it->second.chosen >= 0 ? 1 : 0;
 }
 
+int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,
+                        int *waves, int *ntx, int64_t *zchunk) {
+  std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
+  auto it = nsol_pdk::g_plans.find(nsol_pdk::PlanKey{elem_size, k, nz, ny, nx});
+  if (it == nsol_pdk::g_plans.end() || it->second.chosen < 0) return NSOL_EINVAL;
+  const nsol_pdk::Config &c = it->second.cand[it->second.chosen];
+  if (waves) *waves = c.nw;
+  if (ntx) *ntx = c.q.ntx;
+  if (zchunk) *zchunk = c.zchunk;
+  return 0;
+}
+
 int nsol_pd_fusedk_iter_f32(const float *xbar_in, float *xbar_out, const float *x_in,
                             float *x_out, const float *bt, const float *p_in,
                             float *p_out, int ndim, int64_t nz, int64_t ny,

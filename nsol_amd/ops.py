@@ -329,6 +329,17 @@ def pd_fusedk_tuned(x, shape, k=3):
                                                 nz, ny, nx))
 
 
+def pd_fusedk_plan(x, shape, k=3):
+    """(waves, tiles along x, z-chunk) the online tuner settled on, or None."""
+    import ctypes
+    ndim, nz, ny, nx = dims3(shape)
+    wv, nt, zc = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+    rc = _lib.load().nsol_pd_fusedk_plan(
+        int(x.element_size()), int(k), nz, ny, nx, ctypes.byref(wv),
+        ctypes.byref(nt), ctypes.byref(zc))
+    return None if rc else (int(wv.value), int(nt.value), int(zc.value))
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
            p_is_zero, gamma_huber, flags, x_alt=None):
     """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that

@@ -41,6 +41,11 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--skip-first", type=int, default=1,
                     help="dispatches of --kernel to drop (p = 0 first launch)")
+    ap.add_argument("--config", default="",
+                    help="waves:ntx:zchunk the PMC passes were pinned to")
+    ap.add_argument("--last", type=int, default=0,
+                    help="use only the last N dispatches of --kernel (steady "
+                         "state after the online tuner has settled)")
     args = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -49,6 +54,8 @@ def main():
                            recursive=True):
             shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % args.tag))
     summary = {"kernel": args.kernel, "size": args.size, "tag": args.tag}
+    if args.config:
+        summary["kernel_config"] = [int(t) for t in args.config.split(":")]
     if args.stats:
         # steady state of the dominant instantiation: the first-call autotuner
         # launches other footprint shapes of the same kernel, so the average of
@@ -64,11 +71,12 @@ def main():
         if durs:
             name = max(durs, key=lambda k: len(durs[k]))
             d = [x[1] for x in sorted(durs[name])]
-            tail = d[len(d) // 2:]
+            tail = d[-args.last:] if args.last > 0 else d[len(d) // 2:]
             summary["dominant_instantiation"] = name[:80]
             summary["dispatches"] = len(d)
             summary["avg_ns_all"] = sum(d) / len(d)
-            summary["avg_ns_last_half"] = sum(tail) / len(tail)
+            summary["avg_ns_steady"] = sum(tail) / len(tail)
+            summary["steady_dispatches"] = len(tail)
     rows = []
     for name, d in (("FETCH_SIZE", args.fetch), ("WRITE_SIZE", args.write)):
         if not d:
@@ -78,7 +86,9 @@ def main():
         dominant = max(match, key=lambda k: len(acc[k]))[0] if match else None
         for (kern, ctr), vals in sorted(acc.items()):
             use = vals
-            if kern == dominant and len(vals) > args.skip_first:
+            if kern == dominant and args.last > 0:
+                use = vals[-args.last:]
+            elif kern == dominant and len(vals) > args.skip_first:
                 use = vals[args.skip_first:]
             mean = sum(use) / len(use)
             rows.append((kern[:100], ctr, len(use), mean))
