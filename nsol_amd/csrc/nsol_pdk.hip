@@ -178,21 +178,24 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     tau_m[k] = rin ? S.tau[k] : T(0);
   }
 
-  const int64_t zbeg = (int64_t)zc * zchunk;
-  int64_t zend = zbeg + zchunk;
-  if (zend > G.nz) zend = G.nz;
-  const int64_t s_first = zbeg > H ? zbeg - H : 0;
-  const int64_t s_last = zend + K - 2;
-  const int64_t s_hi = s_last < G.nz - 1 ? s_last : G.nz - 1;   // last step with a stage 1
+  // plane indices fit in 32 bits (the host checks nz < 2^30): scalar registers
+  // are the scarce resource here (11 buffer descriptors)
+  const int nzi = (int)G.nz;
+  const int zbeg = zc * zchunk;
+  int zend = zbeg + zchunk;
+  if (zend > nzi) zend = nzi;
+  const int s_first = zbeg > H ? zbeg - H : 0;
+  const int s_last = zend + K - 2;
+  const int s_hi = s_last < nzi - 1 ? s_last : nzi - 1;   // last step with a stage 1
 
   // ---- buffer resources over the planes [pz0, pe) this workgroup touches
-  const int64_t pz0 = s_first > 0 ? s_first - 1 : 0;
-  int64_t pe = s_last + 2;
-  if (pe > G.nz) pe = G.nz;
+  const int pz0 = s_first > 0 ? s_first - 1 : 0;
+  int pe = s_last + 2;
+  if (pe > nzi) pe = nzi;
   const uint32_t szb = (uint32_t)(G.sz * (int64_t)sizeof(T));
   const uint32_t syb = (uint32_t)(G.sy * (int64_t)sizeof(T));
   const uint32_t span = (uint32_t)(pe - pz0) * szb;       // < 2^30 (host-checked)
-  const int64_t boff = pz0 * G.sz;
+  const int64_t boff = (int64_t)pz0 * G.sz;
   const uint32_t pspan = S.has_p ? span : 0u;             // p = 0: every load returns 0
   const rsrc_t r_xb = make_rsrc(xbar_in + boff, span);
   const rsrc_t r_x = make_rsrc(x_in + boff, span);
@@ -226,6 +229,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   const bool g_l = rin && row_beg && x0 > 0;
   const bool g_u = rin && y > 0;
   const int li = (tid + lxb) * VEC;              // LDS slot of this lane (row + 1)
+  // step size of the recomputed dual of the voxel above: zero where there is none
+  // (its inputs are zero there -- out-of-range load, zero LDS row, or a lane outside
+  // the volume -- so the result is exactly zero without a select per value)
+  T sig_u[K];
+  sig_u[0] = g_u ? S.sigma[0] : T(0);
+#pragma unroll
+  for (int k = 1; k < K; ++k) sig_u[k] = v_u ? S.sigma[k] : T(0);
 
   // zero rows above and below the footprint, once
   for (int i = tid; i < 2 * (K - 1) * 2 * lxb * VEC; i += NT) {
@@ -275,9 +285,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   // stage-1 arithmetic of plane s (a full step of latency hiding; +36 VGPRs).
   typedef PlaneLoads<T, VEC> Loads;
   Loads LA, LB;
-  auto issue_loads = [&](Loads &L, int64_t sp, uint32_t a) {
+  auto issue_loads = [&](Loads &L, int sp, uint32_t a) {
     // sp: plane; a: its scalar offset.  The plane above the volume is zero.
-    bld<T, VEC>(r_xb, (sp + 1 < G.nz) ? v_own : kInvalid, a + szb, L.xn);
+    bld<T, VEC>(r_xb, (sp + 1 < nzi) ? v_own : kInvalid, a + szb, L.xn);
     bld<T, VEC>(r_x, v_own, a, L.xv);
     bld<T, VEC>(r_bt, v_own, a, L.btn);
     bld<T, VEC>(r_px, v_own, a, L.pxo);
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   issue_loads(LA, s_first, adv);
 
   // one plane step; HAVE1 = false in the drain steps above the volume's last plane
-  auto step = [&](auto have1_tag, int64_t s, Loads &L, Loads &LN) {
+  auto step = [&](auto have1_tag, int s, Loads &L, Loads &LN) {
     constexpr bool HAVE1 = decltype(have1_tag)::value;
     // fr_*[k-1]: results of stage k produced in this step
     T fr_xb[K][VEC], fr_x[K][VEC], fr_bt[K][VEC], pzn[K][VEC];
@@ -319,9 +329,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
                   : T(0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T pu = g_u ? dual_update_u<HUBER, UNIT>(L.pyup[j], xc[j], L.xup[j], G.wy,
-                                                S.sigma[0], S.hden[0])
-                         : T(0);
+        // the upper neighbour's new dual; without one, pyup = xup = 0 (offset
+        // out of range) and sig_u = 0 make it exactly zero
+        const T pu = dual_update_u<HUBER, UNIT>(L.pyup[j], xc[j], L.xup[j], G.wy,
+                                                sig_u[0], S.hden[0]);
         const T pl = (j > 0) ? f_px[(j + VEC - 1) % VEC] : pxl;
         T kt = adj_term<UNIT>(f_px[j], pl, G.wx);
         kt += adj_term<UNIT>(f_py[j], pu, G.wy);
@@ -343,9 +354,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     // ================= F_k: finish iteration n+k on plane s-(k-1) ===========
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
-      const int64_t f = s - (k - 1);
+      const int f = s - (k - 1);
       // below the volume and above it everything is zero padding
-      const bool inr = f >= 0 && f < G.nz;
+      const bool inr = f >= 0 && f < nzi;
       const T sk = inr ? sig_m[k - 1] : T(0);
       const T tk = inr ? tau_m[k - 1] : T(0);
       T pkz[VEC];
@@ -412,9 +423,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T pu = v_u ? dual_update_u<HUBER, UNIT>(above_py[j], fr_xb[k - 2][j], above[j],
-                                                G.wy, S.sigma[k - 1], S.hden[k - 1])
-                         : T(0);
+        const T pu = dual_update_u<HUBER, UNIT>(above_py[j], fr_xb[k - 2][j], above[j],
+                                                G.wy, sig_u[k - 1], S.hden[k - 1]);
         const T pl = (j > 0) ? pkx[(j + VEC - 1) % VEC] : pl0;
         T kt = adj_term<UNIT>(pkx[j], pl, G.wx);
         kt += adj_term<UNIT>(pky[j], pu, G.wy);
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         n_py[k - 1][j] = pky[j];
       }
       if (k == K) {
-        const int64_t a = s - (K - 2);
+        const int a = s - (K - 2);
         if (a >= zbeg && a < zend) {              // uniform
           const uint32_t vo = v_st + (adv - (uint32_t)(K - 2) * szb);
           bst<T, VEC>(w_px, vo, pkx);
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   };
 
   __syncthreads();   // LDS padding rows are zero before anyone reads them
-  int64_t s = s_first;
+  int s = s_first;
   if constexpr (PF2) {
     for (; s + 1 <= s_hi; s += 2) {
       step(std::true_type{}, s, LA, LB);
@@ -797,11 +807,12 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     if (cand.empty()) return -2;
     const bool big = G.n >= ((int64_t)g_tunek.tune_min_mvox << 20);
     if (g_tunek.autotune && big && cand.size() > 1) {
-      // the model's best five tilings per workgroup size, each also with a
-      // shorter z-chunk (more workgroups in flight)
+      // per workgroup size: the tilings with up to 8 tiles along x plus the
+      // model's best five, each also with a shorter z-chunk (more workgroups in
+      // flight).  The model ranks; the measurement decides.
       int per_nw[17] = {0};
       for (const Config &c : cand) {
-        if (per_nw[c.nw]++ >= 5) continue;
+        if (per_nw[c.nw]++ >= 5 && c.q.ntx > 8) continue;
         P.cand.push_back(c);
         const int64_t zc = c.zchunk > 96 ? 64 : 24;
         if (zc < c.zchunk && zc <= G.nz) {
@@ -875,7 +886,7 @@ int fusedk_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T 
     return NSOL_EINVAL;
   constexpr int VW = 16 / sizeof(T);
   if (!g_tunek.enable || k > g_tunek.kmax || ndim != 3 || nx % VW != 0 ||
-      nx / VW < 8 || ny < 8 || nz < 8 || !al16(xbar_in) || !al16(xbar_out) ||
+      nx / VW < 8 || ny < 8 || nz < 8 || nz >= ((int64_t)1 << 30) || !al16(xbar_in) || !al16(xbar_out) ||
       !al16(x_in) || !al16(x_out) || !al16(bt) || !al16(p_out) ||
       (p_in && !al16(p_in)) || (nz * ny * nx) % VW != 0)
     return -2;
