@@ -43,6 +43,12 @@
 
 using namespace nsol;
 
+// Timing experiments only (wrong results): -DPDK_ABLATE=1 no global loads,
+// 2 no global stores, 4 no barrier; bits combine.
+#ifndef PDK_ABLATE
+#define PDK_ABLATE 0
+#endif
+
 namespace nsol_pdk {
 
 template <typename T, int K>
@@ -76,6 +82,10 @@ template <typename T, int V>
 __device__ __forceinline__ void bld(rsrc_t r, uint32_t vo, uint32_t so, T (&v)[V]) {
   static_assert(sizeof(T) * V == 16, "one 16-byte vector per lane");
   typedef typename Pack<T, V>::type P;
+#if PDK_ABLATE & 1
+  for (int k = 0; k < V; ++k) v[k] = T(1e-3) * (T)((vo + so + k) & 255u);
+  return;
+#endif
   const P t = __builtin_bit_cast(P, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
 #pragma unroll
   for (int k = 0; k < V; ++k) v[k] = t[k];
@@ -100,8 +110,46 @@ __device__ __forceinline__ void bst(rsrc_t r, uint32_t vo, const T (&v)[V]) {
   P t;
 #pragma unroll
   for (int k = 0; k < V; ++k) t[k] = v[k];
+#if PDK_ABLATE & 2
+  if (t[0] != T(123.456)) return;
+#endif
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r, vo, 0, 0);
   asm volatile("s_nop 1");
+}
+
+// Element-wise dual update of a whole vector, out[j] = clamp((p_old[j] + sigma *
+// (hi[j] - lo[j]) * w) / hden), with the float arithmetic issued as packed pairs
+// (v_pk_add_f32 / v_pk_mul_f32).  There is no packed subtract and the compiler
+// turns a + (-b) back into a scalar v_sub, hence the one-line asm with the
+// negation in the operand modifiers; all values are exactly those of
+// dual_update_u.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <bool HUBER, bool UNIT, typename T, int V>
+__device__ __forceinline__ void dual_vec(T (&out)[V], const T (&p_old)[V],
+                                         const T (&hi)[V], const T (&lo)[V], T w,
+                                         T sigma, T hden) {
+  if constexpr (sizeof(T) == 4 && V % 2 == 0) {
+#pragma unroll
+    for (int h = 0; h < V / 2; ++h) {
+      const f32x2 a = {hi[2 * h], hi[2 * h + 1]};
+      const f32x2 b = {lo[2 * h], lo[2 * h + 1]};
+      const f32x2 p = {p_old[2 * h], p_old[2 * h + 1]};
+      const f32x2 g = UNIT ? pk_sub(a, b) : a * w + b * (-w);
+      f32x2 q = p + sigma * g;
+      if constexpr (HUBER) q = q / hden;
+      out[2 * h] = dual_clamp(q[0]);
+      out[2 * h + 1] = dual_clamp(q[1]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      out[j] = dual_update_u<HUBER, UNIT>(p_old[j], hi[j], lo[j], w, sigma, hden);
+  }
 }
 
 // LDS rows are padded by one (zero) row above and below the footprint
@@ -249,21 +297,28 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     s_py[b][kk][at] = T(0);
   }
 
-  T xc[VEC];              // xbar[s]
-  T pz[K][VEC];           // pz[k-1]: p^(k)_z on the plane stage k finished last
-  T c_xb[K][VEC];         // [k-1], k>=2: xbar^(k-1) on plane s-(k-1)
-  T c_x[K][VEC];          //               x^(k-1) there
-  T c_bt[K][VEC];         //               bt there
-  T c_kt[K][VEC];         //               in-plane part of K^T p^(k) there
-  T c_px[K][VEC];         // [k-1], k>=3: p_x^(k-1) on plane s-(k-1)+1 (from IP_{k-1})
-  T c_py[K][VEC];
+  // State carried from one plane step to the next.  The 8-wave variants keep two
+  // copies: a step reads one and writes the other (main loop unrolled by two), so
+  // "carrying" is a renaming of registers instead of ~40 v_mov per step; with 12
+  // or 16 waves that spills, and one copy is updated in place.
+  struct Carry {
+    T xc[VEC];              // xbar[s]
+    T pz[K][VEC];           // pz[k-1]: p^(k)_z on the plane stage k finished last
+    T c_xb[K][VEC];         // [k-1], k>=2: xbar^(k-1) on plane s-(k-1)
+    T c_x[K][VEC];          //               x^(k-1) there
+    T c_bt[K][VEC];         //               bt there
+    T c_kt[K][VEC];         //               in-plane part of K^T p^(k) there
+    T c_px[K][VEC];         // [k-1], k>=3: p_x^(k-1) on plane s-(k-1)+1 (from IP_{k-1})
+    T c_py[K][VEC];
+  };
+  Carry CA, CB;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    zero(pz[k]); zero(c_xb[k]); zero(c_x[k]); zero(c_bt[k]); zero(c_kt[k]);
-    zero(c_px[k]); zero(c_py[k]);
+    zero(CA.pz[k]); zero(CA.c_xb[k]); zero(CA.c_x[k]); zero(CA.c_bt[k]);
+    zero(CA.c_kt[k]); zero(CA.c_px[k]); zero(CA.c_py[k]);
   }
   uint32_t adv = (uint32_t)(s_first - pz0) * szb;   // scalar offset of plane s
-  bld<T, VEC>(r_xb, v_own, adv, xc);
+  bld<T, VEC>(r_xb, v_own, adv, CA.xc);
   {
     // p'_z of the plane below the first one (zero at the bottom of the volume)
     T xm[VEC], pm[VEC];
@@ -274,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const T sg = s_first > 0 ? S.sigma[0] : T(0);
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      pz[0][j] = dual_update_u<HUBER, UNIT>(pm[j], xc[j], xm[j], G.wz, sg, S.hden[0]);
+      CA.pz[0][j] = dual_update_u<HUBER, UNIT>(pm[j], CA.xc[j], xm[j], G.wz, sg, S.hden[0]);
   }
 
   // Software pipeline: the loads of plane s+1 are issued right after the stage-1
@@ -303,7 +358,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   issue_loads(LA, s_first, adv);
 
   // one plane step; HAVE1 = false in the drain steps above the volume's last plane
-  auto step = [&](auto have1_tag, int s, Loads &L, Loads &LN) {
+  auto step = [&](auto have1_tag, int s, Loads &L, Loads &LN, const Carry &P,
+                  Carry &N) {
     constexpr bool HAVE1 = decltype(have1_tag)::value;
     // fr_*[k-1]: results of stage k produced in this step
     T fr_xb[K][VEC], fr_x[K][VEC], fr_bt[K][VEC], pzn[K][VEC];
@@ -313,30 +369,31 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       const bool more = s + 1 <= s_hi;
       if constexpr (PF2) issue_loads(LN, more ? s + 1 : s, more ? adv + szb : adv);
       // ================= stage 1: iteration n+1 on plane s ===================
-      T nb = __shfl_down(xc[0], 1, kWave);
+      T nb = __shfl_down(P.xc[0], 1, kWave);
       if (row_end) nb = L.xright;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T hx = (j + 1 < VEC) ? xc[(j + 1) % VEC] : nb;
-        f_px[j] = dual_update_u<HUBER, UNIT>(L.pxo[j], hx, xc[j], G.wx, sig_m[0], S.hden[0]);
-        f_py[j] = dual_update_u<HUBER, UNIT>(L.pyo[j], L.xdown[j], xc[j], G.wy, sig_m[0], S.hden[0]);
-        pzn[0][j] = dual_update_u<HUBER, UNIT>(L.pzo[j], L.xn[j], xc[j], G.wz, sig_m[0], S.hden[0]);
+        const T hx = (j + 1 < VEC) ? P.xc[(j + 1) % VEC] : nb;
+        f_px[j] = dual_update_u<HUBER, UNIT>(L.pxo[j], hx, P.xc[j], G.wx, sig_m[0], S.hden[0]);
       }
+      dual_vec<HUBER, UNIT>(f_py, L.pyo, L.xdown, P.xc, G.wy, sig_m[0], S.hden[0]);
+      dual_vec<HUBER, UNIT>(pzn[0], L.pzo, L.xn, P.xc, G.wz, sig_m[0], S.hden[0]);
       T pxl = __shfl_up(f_px[VEC - 1], 1, kWave);
       if (row_beg)
-        pxl = g_l ? dual_update_u<HUBER, UNIT>(L.pxleft, xc[0], L.xleft, G.wx, S.sigma[0],
+        pxl = g_l ? dual_update_u<HUBER, UNIT>(L.pxleft, P.xc[0], L.xleft, G.wx, S.sigma[0],
                                          S.hden[0])
                   : T(0);
+      // the upper neighbour's new dual; without one, pyup = xup = 0 (offset out
+      // of range) and sig_u = 0 make it exactly zero
+      T puv[VEC];
+      dual_vec<HUBER, UNIT>(puv, L.pyup, P.xc, L.xup, G.wy, sig_u[0], S.hden[0]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        // the upper neighbour's new dual; without one, pyup = xup = 0 (offset
-        // out of range) and sig_u = 0 make it exactly zero
-        const T pu = dual_update_u<HUBER, UNIT>(L.pyup[j], xc[j], L.xup[j], G.wy,
-                                                sig_u[0], S.hden[0]);
+        const T pu = puv[j];
         const T pl = (j > 0) ? f_px[(j + VEC - 1) % VEC] : pxl;
         T kt = adj_term<UNIT>(f_px[j], pl, G.wx);
         kt += adj_term<UNIT>(f_py[j], pu, G.wy);
-        kt += adj_term<UNIT>(pzn[0][j], pz[0][j], G.wz);
+        kt += adj_term<UNIT>(pzn[0][j], P.pz[0][j], G.wz);
         const T u = L.xv[j] - tau_m[0] * kt;
         const T xnew = prox_data_s<L1>(u, L.btn[j], S.tl[0], S.optl[0]);
         fr_x[0][j] = xnew;
@@ -344,11 +401,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         fr_bt[0][j] = L.btn[j];
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) xc[j] = L.xn[j];
+      for (int j = 0; j < VEC; ++j) N.xc[j] = L.xn[j];
       if constexpr (!PF2) issue_loads(L, more ? s + 1 : s, more ? adv + szb : adv);
     } else {
       zero(fr_xb[0]); zero(fr_x[0]); zero(fr_bt[0]); zero(pzn[0]);
       zero(f_px); zero(f_py);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) N.xc[j] = P.xc[j];
     }
 
     // ================= F_k: finish iteration n+k on plane s-(k-1) ===========
@@ -360,17 +419,17 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       const T sk = inr ? sig_m[k - 1] : T(0);
       const T tk = inr ? tau_m[k - 1] : T(0);
       T pkz[VEC];
+      dual_vec<HUBER, UNIT>(pkz, P.pz[k - 2], fr_xb[k - 2], P.c_xb[k - 1], G.wz, sk,
+                            S.hden[k - 1]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        pkz[j] = dual_update_u<HUBER, UNIT>(pz[k - 2][j], fr_xb[k - 2][j], c_xb[k - 1][j],
-                                      G.wz, sk, S.hden[k - 1]);
-        T kt = c_kt[k - 1][j];
-        kt += adj_term<UNIT>(pkz[j], pz[k - 1][j], G.wz);
-        const T u = c_x[k - 1][j] - tk * kt;
-        const T xk = prox_data_s<L1>(u, c_bt[k - 1][j], S.tl[k - 1], S.optl[k - 1]);
+        T kt = P.c_kt[k - 1][j];
+        kt += adj_term<UNIT>(pkz[j], P.pz[k - 1][j], G.wz);
+        const T u = P.c_x[k - 1][j] - tk * kt;
+        const T xk = prox_data_s<L1>(u, P.c_bt[k - 1][j], S.tl[k - 1], S.optl[k - 1]);
         fr_x[k - 1][j] = xk;
-        fr_xb[k - 1][j] = xk + S.theta[k - 1] * (xk - c_x[k - 1][j]);
-        fr_bt[k - 1][j] = c_bt[k - 1][j];
+        fr_xb[k - 1][j] = xk + S.theta[k - 1] * (xk - P.c_x[k - 1][j]);
+        fr_bt[k - 1][j] = P.c_bt[k - 1][j];
         pzn[k - 1][j] = pkz[j];
       }
       if (k == K && f >= zbeg && f < zend) {      // uniform
@@ -390,11 +449,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         stv<T, VEC>(&s_py[buf][0][li], f_py);
         if (lane == 63) s_px[buf][0][tid >> 6] = f_px[VEC - 1];
       } else {
-        stv<T, VEC>(&s_py[buf][k - 2][li], c_py[k - 1]);
-        if (lane == 63) s_px[buf][k - 2][tid >> 6] = c_px[k - 1][VEC - 1];
+        stv<T, VEC>(&s_py[buf][k - 2][li], P.c_py[k - 1]);
+        if (lane == 63) s_px[buf][k - 2][tid >> 6] = P.c_px[k - 1][VEC - 1];
       }
     }
+#if !(PDK_ABLATE & 4)
     __syncthreads();
+#endif
     T n_kt[K][VEC], n_px[K][VEC], n_py[K][VEC];
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
@@ -405,26 +466,30 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       T right = s_xb[buf][k - 2][li + VEC];
       if (!n_r) right = T(0);
       const T left_xb = s_xb[buf][k - 2][li - 1];
-      T left_px = __shfl_up((k == 2) ? f_px[VEC - 1] : c_px[k - 1][VEC - 1], 1, kWave);
+      T left_px = __shfl_up((k == 2) ? f_px[VEC - 1] : P.c_px[k - 1][VEC - 1], 1, kWave);
       if (lane == 0) left_px = s_px[buf][k - 2][tid > 0 ? (tid >> 6) - 1 : 0];
       const T pl0 = v_l ? dual_update_u<HUBER, UNIT>(left_px, fr_xb[k - 2][0], left_xb, G.wx,
                                                S.sigma[k - 1], S.hden[k - 1])
                         : T(0);
-      T pkx[VEC], pky[VEC];
+      T pkx[VEC], pky[VEC], puv[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T px_old = (k == 2) ? f_px[j] : c_px[k - 1][j];
-        const T py_old = (k == 2) ? f_py[j] : c_py[k - 1][j];
+        const T px_old = (k == 2) ? f_px[j] : P.c_px[k - 1][j];
         const T hx = (j + 1 < VEC) ? fr_xb[k - 2][(j + 1) % VEC] : right;
         pkx[j] = dual_update_u<HUBER, UNIT>(px_old, hx, fr_xb[k - 2][j], G.wx, sig_m[k - 1],
                                       S.hden[k - 1]);
-        pky[j] = dual_update_u<HUBER, UNIT>(py_old, below[j], fr_xb[k - 2][j], G.wy,
-                                      sig_m[k - 1], S.hden[k - 1]);
       }
+      if (k == 2)
+        dual_vec<HUBER, UNIT>(pky, f_py, below, fr_xb[k - 2], G.wy, sig_m[k - 1],
+                              S.hden[k - 1]);
+      else
+        dual_vec<HUBER, UNIT>(pky, P.c_py[k - 1], below, fr_xb[k - 2], G.wy, sig_m[k - 1],
+                              S.hden[k - 1]);
+      dual_vec<HUBER, UNIT>(puv, above_py, fr_xb[k - 2], above, G.wy, sig_u[k - 1],
+                            S.hden[k - 1]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const T pu = dual_update_u<HUBER, UNIT>(above_py[j], fr_xb[k - 2][j], above[j],
-                                                G.wy, sig_u[k - 1], S.hden[k - 1]);
+        const T pu = puv[j];
         const T pl = (j > 0) ? pkx[(j + VEC - 1) % VEC] : pl0;
         T kt = adj_term<UNIT>(pkx[j], pl, G.wx);
         kt += adj_term<UNIT>(pky[j], pu, G.wy);
@@ -442,40 +507,47 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       }
     }
 
-    // ================= carry ===============================================
+    // ================= next state ==========================================
 #pragma unroll
     for (int k = K; k >= 2; --k) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        c_xb[k - 1][j] = fr_xb[k - 2][j];
-        c_x[k - 1][j] = fr_x[k - 2][j];
-        c_bt[k - 1][j] = fr_bt[k - 2][j];
-        c_kt[k - 1][j] = n_kt[k - 1][j];
+        N.c_xb[k - 1][j] = fr_xb[k - 2][j];
+        N.c_x[k - 1][j] = fr_x[k - 2][j];
+        N.c_bt[k - 1][j] = fr_bt[k - 2][j];
+        N.c_kt[k - 1][j] = n_kt[k - 1][j];
         if (k < K) {
-          c_px[k][j] = n_px[k - 1][j];
-          c_py[k][j] = n_py[k - 1][j];
+          N.c_px[k][j] = n_px[k - 1][j];
+          N.c_py[k][j] = n_py[k - 1][j];
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) pz[k][j] = pzn[k][j];
+      for (int j = 0; j < VEC; ++j) N.pz[k][j] = pzn[k][j];
     adv += szb;
   };
 
   __syncthreads();   // LDS padding rows are zero before anyone reads them
   int s = s_first;
   if constexpr (PF2) {
+    // 8 waves: registers to spare -> two load sets and two state sets
     for (; s + 1 <= s_hi; s += 2) {
-      step(std::true_type{}, s, LA, LB);
-      step(std::true_type{}, s + 1, LB, LA);
+      step(std::true_type{}, s, LA, LB, CA, CB);
+      step(std::true_type{}, s + 1, LB, LA, CB, CA);
     }
-    if (s <= s_hi) { step(std::true_type{}, s, LA, LB); ++s; }
+    if (s <= s_hi) {
+      step(std::true_type{}, s, LA, LB, CA, CB);
+      CA = CB;
+      ++s;
+    }
   } else {
-    for (; s <= s_hi; ++s) step(std::true_type{}, s, LA, LA);
+    // one set of each, updated in place (a step writes its state last)
+    for (; s <= s_hi; ++s) step(std::true_type{}, s, LA, LA, CA, CA);
   }
-  for (; s <= s_last; ++s) step(std::false_type{}, s, LA, LA);
+  for (; s <= s_last; ++s)       // at most K-1 drain steps
+    step(std::false_type{}, s, LA, LA, CA, CA);
 }
 
 struct Tuning {
