@@ -105,6 +105,19 @@ int nsol_corr_axis_f32(const float *x, float *out, int axis, int64_t nz,
 int nsol_corr_axis_f64(const double *x, double *out, int axis, int64_t nz,
                        int64_t ny, int64_t nx, const double *taps_host,
                        int ntaps, int centre, int mode, void *stream);
+/* Separable periodic ("wrap") 3-D correlation in one pass over memory: the
+ * Gaussian blur A = A^T of linear_operators.py:82-86 on a volume, 8 bytes per
+ * voxel instead of 24 for three nsol_corr_axis_* passes.  taps_* are HOST arrays
+ * of `ntaps` doubles (odd, centre in the middle, the same count on every axis).
+ * Passes run x, y, z.  Returns -2 (nothing launched) when the kernel does not
+ * apply (even / long tap counts, nx not a multiple of 16 bytes, unaligned
+ * pointers): use the per-axis passes then. */
+int nsol_corr3_wrap_f32(const float *x, float *out, int64_t nz, int64_t ny,
+                        int64_t nx, const double *taps_z, const double *taps_y,
+                        const double *taps_x, int ntaps, void *stream);
+int nsol_corr3_wrap_f64(const double *x, double *out, int64_t nz, int64_t ny,
+                        int64_t nx, const double *taps_z, const double *taps_y,
+                        const double *taps_x, int ntaps, void *stream);
 /* dense N-D correlation with DEVICE taps [kz][ky][kx] and centre (cz,cy,cx):
  *   out[i] = sum_t taps[t] * x[i + t - c].  Replaces linear_operators.py:60-68
  * (scipy.ndimage.convolve with an arbitrary kernel; the host flips the kernel

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
   }
 }
 
+int g_blur3_lxb = 16;   // lanes per row of the one-pass blur's tile (experiment knob)
 int g_corr_ra = 8;   // outputs per lane along a strided axis (experiment knob)
 int g_corr_xv = 1;   // output vectors per lane in the x pass (experiment knob)
 
@@ -282,6 +283,204 @@ int try_launch_wrap(const T *x, T *out, int axis, int64_t nz, int64_t ny,
 #undef NSOL_NT_CASE
 }
 
+// ---------------------------------------------------------------------------
+// Separable periodic 3-D correlation in ONE pass over memory (the Gaussian blur
+// A = A^T of linear_operators.py:82-86 on a volume): reads x once, writes the
+// result once (8 B per voxel instead of 24 for three 1-D passes).
+//
+// A workgroup owns a tile of TY rows x LXB*VEC voxels and marches along z:
+//   x pass  every lane filters its own row segment straight from global memory
+//           (the taps' neighbours are L1 hits, as in k_corr_x_wrap) -- for the
+//           tile's rows and, in a second round, for the 2R halo rows -- and
+//           writes the filtered vectors to LDS (double buffered, one barrier);
+//   y pass  a lane reads the NT vectors of its column from LDS;
+//   z pass  the xy-filtered values of the last NT planes live in registers (a
+//           shifting window); once it is full every new plane yields one
+//           output plane R planes behind.
+// Order of the passes: x, y, z, each accumulating t = 0..NT-1 like ndimage.
+// (The three-kernel path runs z, y, x; both are rank-1 evaluations of the same
+// dense kernel and differ from it, and from each other, by rounding only.)
+// ---------------------------------------------------------------------------
+template <typename T, int VEC, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
+    const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
+    Taps<T> tz, Taps<T> ty, Taps<T> tx, int lxb, int tyr, int ntx, int nty,
+    int zchunk) {
+  typedef typename VecOf<T, VEC>::type V;
+  constexpr int R = NT / 2;
+  constexpr int NBH = (R + VEC - 1) / VEC;   // vectors on each side in x
+  constexpr int NB = 2 * NBH + 1;
+  constexpr int NT_THREADS = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int frows = tyr + 2 * R;               // footprint rows
+  const int rowlen = lxb * VEC;
+  const int tid = threadIdx.x;
+  const int row = tid / lxb;
+  const int lx = tid - row * lxb;
+  const bool active = row < tyr;
+  int bid = blockIdx.x;
+  const int bx = bid % ntx; bid /= ntx;
+  const int by = bid % nty;
+  const int bz = bid / nty;
+  const int64_t nxv = nx / VEC;
+  const int64_t xv = (int64_t)bx * lxb + lx;           // own vector along x
+  const int64_t y0 = (int64_t)by * tyr;
+  const bool xin = xv < nxv;
+  const bool owner = active && xin && (y0 + row < ny);
+  // wrapped vector offsets of the x window (loop invariant)
+  int64_t xoff[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    int64_t j = (xv + b - NBH) % nxv;
+    if (j < 0) j += nxv;
+    xoff[b] = j * VEC;
+  }
+  // rows this lane filters along x: footprint row `row` (always) and footprint
+  // row tyr + row (the halo round, lanes with row < 2R)
+  const bool second = active && row < 2 * R;
+  int64_t yoff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int64_t yy = (y0 - R + row + (int64_t)q * tyr) % ny;
+    if (yy < 0) yy += ny;
+    yoff[q] = yy * nx;
+  }
+  const int64_t zbeg = (int64_t)bz * zchunk;
+  int64_t zend = zbeg + zchunk;
+  if (zend > nz) zend = nz;
+  int64_t zw = (zbeg - R) % nz;
+  if (zw < 0) zw += nz;
+  V ring[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) ring[t] = V(T(0));
+  const int64_t nsteps = (zend - zbeg) + 2 * R;
+  // one plane: x pass -> LDS -> y pass; returns the xy-filtered vector of this lane
+  auto plane_xy = [&](int64_t st) {
+    T *buf = smem + (size_t)(st & 1) * frows * rowlen;
+    const T *plane = x + zw * ny * nx;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 0 ? active : second) {
+        T win[NB * VEC];
+        const T *rp = plane + yoff[q];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const V v = *reinterpret_cast<const V *>(rp + xoff[b]);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) win[b * VEC + k] = v[k];
+        }
+        V res;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          T acc = tx.w[0] * win[NBH * VEC + k - R];
+#pragma unroll
+          for (int t = 1; t < NT; ++t) acc += tx.w[t] * win[NBH * VEC + k - R + t];
+          res[k] = acc;
+        }
+        *reinterpret_cast<V *>(buf + (size_t)(row + q * tyr) * rowlen + lx * VEC) = res;
+      }
+    }
+    __syncthreads();
+    V v = V(T(0));
+    if (active) {
+      const T *col = buf + (size_t)row * rowlen + lx * VEC;
+      v = ty.w[0] * *reinterpret_cast<const V *>(col);
+#pragma unroll
+      for (int t = 1; t < NT; ++t)
+        v += ty.w[t] * *reinterpret_cast<const V *>(col + (size_t)t * rowlen);
+    }
+    if (++zw == nz) zw = 0;
+    return v;
+  };
+  // z pass: the window is a ring with compile-time slots (the step loop is
+  // unrolled NT times), so nothing is shifted
+  for (int64_t base = 0; base < nsteps; base += NT) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int64_t st = base + u;
+      if (st < nsteps) {                       // uniform
+        ring[u] = plane_xy(st);
+        if (st >= 2 * R && owner) {
+          V acc = tz.w[0] * ring[(u + 1) % NT];
+#pragma unroll
+          for (int t = 1; t < NT; ++t) acc += tz.w[t] * ring[(u + 1 + t) % NT];
+          const int64_t z = zbeg + (st - 2 * R);
+          *reinterpret_cast<V *>(out + (z * ny + (y0 + row)) * nx + xv * VEC) = acc;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int VEC, int NT>
+int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
+                 const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
+                 hipStream_t st) {
+  constexpr int NW = 16;
+  constexpr int R = NT / 2;
+  const int64_t nxv = nx / VEC;
+  // lanes per row: a power of two up to 32 that covers the row in few tiles
+  int lxb = g_blur3_lxb;
+  while (lxb > 8 && lxb / 2 >= nxv) lxb /= 2;
+  const int tyr = (NW * 64) / lxb;
+  if (tyr < 2 * R) return -2;
+  const int64_t ntx = (nxv + lxb - 1) / lxb;
+  const int64_t nty = (ny + tyr - 1) / tyr;
+  // z chunks: enough workgroups for the chip, each long enough to amortise the
+  // 2R extra planes
+  int64_t zchunk = nz;
+  const int64_t want = 2 * 256;
+  while (ntx * nty * ((nz + zchunk - 1) / zchunk) < want && zchunk > 8 * R)
+    zchunk = (zchunk + 1) / 2;
+  const int64_t nzc = (nz + zchunk - 1) / zchunk;
+  const int64_t blocks = ntx * nty * nzc;
+  if (blocks > 0x7fffffff) return -2;
+  const size_t lds = 2 * (size_t)(tyr + 2 * R) * lxb * VEC * sizeof(T);
+  if (lds > 150 * 1024) return -2;
+  auto kern = k_blur3_wrap<T, VEC, NT, NW>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, st, x, out, nz,
+                     ny, nx, tz, ty, tx, lxb, tyr, (int)ntx, (int)nty, (int)zchunk);
+  return launch_status();
+}
+
+// returns -2 when the fused kernel does not apply
+template <typename T>
+int corr3_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
+               const double *tz_host, const double *ty_host, const double *tx_host,
+               int ntaps, void *stream) {
+  if (!x || !out || x == out || !tz_host || !ty_host || !tx_host || nz < 1 ||
+      ny < 1 || nx < 1 || ntaps < 1)
+    return NSOL_EINVAL;
+  constexpr int VEC = 16 / sizeof(T);
+  // longer windows spill (the z window alone is ntaps vectors per lane)
+  constexpr int kMaxFused = sizeof(T) == 4 ? 17 : 15;
+  if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > kMaxFused || nx % VEC != 0 ||
+      (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+    return -2;
+  Taps<T> tz, ty, tx;
+  for (int t = 0; t < kMaxTaps; ++t) {
+    tz.w[t] = t < ntaps ? (T)tz_host[t] : T(0);
+    ty.w[t] = t < ntaps ? (T)ty_host[t] : T(0);
+    tx.w[t] = t < ntaps ? (T)tx_host[t] : T(0);
+  }
+  hipStream_t st = as_stream(stream);
+#define NSOL_B3_CASE(N) \
+  case N: return launch_blur3<T, VEC, N>(x, out, nz, ny, nx, tz, ty, tx, st);
+  switch (ntaps) {
+    NSOL_B3_CASE(3) NSOL_B3_CASE(5) NSOL_B3_CASE(7) NSOL_B3_CASE(9)
+    NSOL_B3_CASE(11) NSOL_B3_CASE(13) NSOL_B3_CASE(15) NSOL_B3_CASE(17)
+    default: return -2;
+  }
+#undef NSOL_B3_CASE
+}
+
 template <typename T>
 int corr_axis_impl(const T *x, T *out, int axis, int64_t nz, int64_t ny,
                    int64_t nx, const double *taps_host, int ntaps, int centre,
@@ -324,6 +523,7 @@ int nsol_hip_set_param_conv(const char *name, int value) {
   if (!name) return NSOL_EINVAL;
   if (!strcmp(name, "corr_ra")) g_corr_ra = value;
   else if (!strcmp(name, "corr_xv")) g_corr_xv = value;
+  else if (!strcmp(name, "corr_blur3_lxb")) g_blur3_lxb = value;
   else return NSOL_EINVAL;
   return 0;
 }
@@ -338,6 +538,16 @@ int nsol_corr_axis_f64(const double *x, double *out, int axis, int64_t nz,
                        int ntaps, int centre, int mode, void *stream) {
   return corr_axis_impl<double>(x, out, axis, nz, ny, nx, taps_host, ntaps,
                                 centre, mode, stream);
+}
+int nsol_corr3_wrap_f32(const float *x, float *out, int64_t nz, int64_t ny,
+                        int64_t nx, const double *taps_z, const double *taps_y,
+                        const double *taps_x, int ntaps, void *stream) {
+  return corr3_impl<float>(x, out, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, stream);
+}
+int nsol_corr3_wrap_f64(const double *x, double *out, int64_t nz, int64_t ny,
+                        int64_t nx, const double *taps_z, const double *taps_y,
+                        const double *taps_x, int ntaps, void *stream) {
+  return corr3_impl<double>(x, out, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, stream);
 }
 int nsol_corr_dense_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const float *taps, int kz, int ky, int kx,

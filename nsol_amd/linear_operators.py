@@ -151,6 +151,10 @@ def _rank1_factors(kernel, tol=1e-13):
     return facs
 
 
+# one-pass 3-D blur (nsol_corr3_wrap_*); False = always three 1-D passes
+USE_FUSED_BLUR3 = True
+
+
 class ConvolutionOperator(DeviceOperator):
     """x -> scipy.ndimage.convolve(x, kernel, mode) on the GPU
     (linear_operators.py:60-68).  Separable kernels (every Gaussian with a
@@ -181,6 +185,16 @@ class ConvolutionOperator(DeviceOperator):
     def separable(self):
         return self._passes is not None
 
+    def _fusable3(self):
+        """Three periodic passes with the same odd tap count, centred: one
+        launch of nsol_corr3_wrap_* instead of three of nsol_corr_axis_*."""
+        p = self._passes
+        return (self.dimension == 3 and self.mode == "wrap" and len(p) == 3
+                and [a for a, _, _ in p] == [0, 1, 2]
+                and len({t.size for _, t, _ in p}) == 1
+                and p[0][1].size % 2 == 1
+                and all(c == t.size // 2 for _, t, c in p))
+
     def _apply(self, x, in_shape):
         if len(in_shape) != self.dimension:
             raise RuntimeError("%dD convolution applied to %d axes" %
@@ -188,6 +202,11 @@ class ConvolutionOperator(DeviceOperator):
         if self._passes is not None:
             if not self._passes:
                 return x.clone()
+            if USE_FUSED_BLUR3 and self._fusable3():
+                res = ops.corr3_wrap(x, in_shape, self._passes[0][1],
+                                     self._passes[1][1], self._passes[2][1])
+                if res is not None:
+                    return res
             cur = x
             for axis3, taps, centre in self._passes:
                 cur = ops.corr_axis(cur, in_shape, axis3, taps, centre,

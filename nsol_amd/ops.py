@@ -97,6 +97,26 @@ def corr_axis(x, shape, axis3, taps, centre, mode, out=None):
     return out
 
 
+def corr3_wrap(x, shape, taps_z, taps_y, taps_x, out=None):
+    """Separable periodic 3-D correlation in one pass (passes x, y, z); returns
+    None when the fused kernel does not apply (nothing was launched)."""
+    _chk(x)
+    _, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(t, dtype=np.float64)
+                  for t in (taps_z, taps_y, taps_x))
+    if not (tz.size == ty.size == tx.size):
+        return None
+    if out is None:
+        out = empty_like(x)
+    rc = _fn("corr3_wrap", x)(_p(x), _p(out), nz, ny, nx, tz.ctypes.data,
+                              ty.ctypes.data, tx.ctypes.data, int(tz.size),
+                              stream_ptr())
+    if rc == -2:
+        return None
+    _lib.check(rc, "nsol_corr3_wrap")
+    return out
+
+
 def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
     _chk(x)
     _chk(taps_dev)

@@ -71,6 +71,33 @@ def test_blur_matches_reference_goldens(nsol, golden):
         assert rel_l2(A_adj(g[xin].astype(np.float32)), g[ref]) < 1e-6, ref
 
 
+@pytest.mark.parametrize("shape,sigma2,dtype", [
+    ((20, 37, 64), 2.0, np.float64), ((9, 5, 16), 4.0, np.float64),
+    ((33, 70, 132), 1.0, np.float32), ((64, 64, 64), 4.0, np.float32),
+    ((40, 48, 512), 4.0, np.float32), ((7, 100, 24), 0.5, np.float64)])
+def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
+    """nsol_corr3_wrap_* (x, y, z passes fused, periodic) against the three
+    nsol_corr_axis_* launches and against the oracle's dense convolution:
+    ragged tiles, volumes smaller than the halo, z-chunk seams."""
+    import nsol_amd.linear_operators as LO
+    from oracle import nsol_oracle as orc
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(shape).astype(dtype)
+    A, _ = _lo(3).get_gaussian_blurring_operators(np.diag([sigma2] * 3))
+    assert A._fusable3()
+    LO.USE_FUSED_BLUR3 = False
+    try:
+        three = A(x)
+    finally:
+        LO.USE_FUSED_BLUR3 = True
+    one = A(x)
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    assert rel_l2(one, three) < tol
+    if np.prod(shape) <= 64 ** 3:
+        ref = orc.gaussian_blur(x.astype(np.float64), np.diag([sigma2] * 3))
+        assert rel_l2(one, ref) < (1e-12 if dtype == np.float64 else 2e-6)
+
+
 @pytest.mark.parametrize("mode", ["wrap", "constant", "nearest", "reflect",
                                   "mirror"])
 def test_user_kernel_convolution(nsol, golden, mode):
