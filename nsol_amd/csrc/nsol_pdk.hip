@@ -561,6 +561,9 @@ struct Tuning {
   int autotune = 1;   // time the best few model candidates once per problem shape
   int tune_min_mvox = 16;   // ... for volumes of at least this many Mi voxels
   int pf2 = -1;       // -1 = where the registers allow; 0 / 1 force
+  int min_kvox = 1024;  // smaller volumes (Ki voxels) stay with the one-iteration kernel:
+                        // cache resident, they want many short workgroups (crossover
+                        // measured between 96^3 and 128^3, tools/crossover_pd.py)
 };
 Tuning g_tunek;
 
@@ -958,6 +961,7 @@ int fusedk_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T 
     return NSOL_EINVAL;
   constexpr int VW = 16 / sizeof(T);
   if (!g_tunek.enable || k > g_tunek.kmax || ndim != 3 || nx % VW != 0 ||
+      nz * ny * nx < ((int64_t)g_tunek.min_kvox << 10) ||
       nx / VW < 8 || ny < 8 || nz < 8 || nz >= ((int64_t)1 << 30) || !al16(xbar_in) || !al16(xbar_out) ||
       !al16(x_in) || !al16(x_out) || !al16(bt) || !al16(p_out) ||
       (p_in && !al16(p_in)) || (nz * ny * nx) % VW != 0)
@@ -986,6 +990,7 @@ int nsol_hip_set_param_pdk(const char *name, int value) {
   else if (!strcmp(name, "pdk_verbose")) nsol_pdk::g_tunek.verbose = value;
   else if (!strcmp(name, "pdk_autotune")) nsol_pdk::g_tunek.autotune = value;
   else if (!strcmp(name, "pdk_pf2")) nsol_pdk::g_tunek.pf2 = value;
+  else if (!strcmp(name, "pdk_min_kvox")) nsol_pdk::g_tunek.min_kvox = value;
   else if (!strcmp(name, "pdk_tune_min_mvox")) nsol_pdk::g_tunek.tune_min_mvox = value;
   else if (!strcmp(name, "pdk_forget")) {
     std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);

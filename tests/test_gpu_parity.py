@@ -355,6 +355,17 @@ def test_config1_lena_and_config2_phantom(nsol, golden):
     s = _pd_solver(noisy, "TV", "L1", 0.6, 200, 16.0, "ALG2", np.float32)
     s.run()
     assert rel_l2(s.get_x(), g["cfg2_noisy_TVL1_200it_L2eq16"]) < F32_TOL
+    # the same through the three-iterations-per-pass kernel (volumes this small
+    # normally stay with the one-iteration kernel); this case caught a store-data
+    # hazard that the bit-identity shapes of the time did not
+    from nsol_amd import _lib
+    _lib.set_param("pdk_min_kvox", 0)
+    try:
+        s = _pd_solver(noisy, "TV", "L1", 0.6, 200, 16.0, "ALG2", np.float32)
+        s.run()
+    finally:
+        _lib.set_param("pdk_min_kvox", 1024)
+    assert rel_l2(s.get_x(), g["cfg2_noisy_TVL1_200it_L2eq16"]) < F32_TOL
     s = _pd_solver(noisy, "Huber", "L2", 0.03, 200, 16.0, "ALG2", np.float32)
     s.run()
     assert rel_l2(s.get_x(), g["cfg2_noisy_HuberL2_200it_L2eq16"]) < F32_TOL
@@ -720,7 +731,9 @@ def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
     _lib.set_param("pd2_zchunk", zchunk2)
     _lib.set_param("pd_two_pass", two_pass)
     pdk_defaults = dict(pdk_enable=1, pdk_kmax=3, pdk_nw=0, pdk_zchunk=0,
-                        pdk_ntx=0)
+                        pdk_ntx=0, pdk_min_kvox=1024)
+    if pdk:                     # small test volumes must reach the kernel
+        pdk = dict(dict(pdk_min_kvox=0), **pdk)
     # pdk=None: the depth-3 kernel stays out of the way (the callers compare
     # the one-iteration kernel with k_pd_fused2)
     for k, v in dict(pdk_defaults, **(pdk or {"pdk_enable": 0})).items():

@@ -35,6 +35,7 @@ def main():
     xb = [bt.clone(), torch.empty_like(bt)]
     p = [torch.zeros(3 * nv, device=dev, dtype=td) for _ in range(2)]
     w = (1., 1., 1.)
+    _lib.set_param("pdk_min_kvox", 0)
     cfgs = [tuple(int(t) for t in c.split(":")) for c in args.cfg.split(",")]
     cfgs.append(("pd2", 0, 0, 0))
     times = {c: [] for c in cfgs}
