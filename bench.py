@@ -56,23 +56,20 @@ class HipEvents(object):
 
 
 def measured_traffic(n, plan=None):
-    """HBM bytes per launch of the fused kernel from the committed rocprofv3
-    PMC passes (profiles/latest_pmc.json, written by tools/summarize_profiles.py);
-    None when no profile of this problem size -- and, if the profile names the
-    kernel configuration it was taken with, of this configuration -- is on
-    record."""
-    path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3
+    PMC passes (profiles/pmc_by_config.json, written by
+    tools/summarize_profiles.py): the passes are pinned to one kernel
+    configuration, so the figure is looked up by the configuration this run's
+    tuner settled on; None when that one has not been profiled."""
+    if not plan:
+        return None
+    path = os.path.join(ROOT, "profiles", "pmc_by_config.json")
     try:
-        rec = json.load(open(path))
-        if int(rec.get("size", 0)) != n:
-            return None
-        cfg = rec.get("kernel_config")
-        if cfg and plan and tuple(cfg) != tuple(plan[:3]):
-            return None
-        return float(rec["traffic_bytes_per_launch"])
+        table = json.load(open(path))
+        rec = table.get("k_pd_fusedk:%d:%d:%d:%d" % ((n,) + tuple(plan[:3])))
+        return float(rec["traffic_bytes_per_launch"]) if rec else None
     except Exception:
-        pass
-    return None
+        return None
 
 
 def cpu_baseline(sample_n, iters):

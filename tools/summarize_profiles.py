@@ -105,6 +105,19 @@ def main():
                            "FETCH_SIZE counts half of a wide coalesced read)")
         with open(os.path.join(out, "latest_pmc.json"), "w") as f:
             json.dump(summary, f, indent=1)
+        # bench.py looks the traffic up by the configuration its tuner chose
+        table_path = os.path.join(out, "pmc_by_config.json")
+        try:
+            table = json.load(open(table_path))
+        except Exception:
+            table = {}
+        key = "%s:%d:%s" % (args.kernel, args.size,
+                            ":".join(str(v) for v in
+                                     summary.get("kernel_config", [])))
+        table[key] = {"traffic_bytes_per_launch":
+                      summary["traffic_bytes_per_launch"], "tag": args.tag}
+        with open(table_path, "w") as f:
+            json.dump(table, f, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1))
 
 
