@@ -437,6 +437,17 @@ int nsol_pair_stats_f64(const double *x, const double *y, int64_t n, double mx,
  *                 result[1] = its smallest index (-1 if none)
  *   trunc_apply   xnew = free ? (i == ibd ? bound : xcp + alpha*d) : xcp
  * ---------------------------------------------------------------------- */
+/* masked_gram: result[(i,j)], i <= j row by row, = sum over the free variables
+ * (iwhere <= 0; all if iwhere is NULL) of vecs[i] * vecs[j], for nvec <= 22
+ * vectors in ONE pass over them -- the Y'ZZ'Y, S'ZZ'S and S'ZZ'Y blocks of the
+ * subspace matrix (2c^2 + c masked dots for c stored pairs).  vecs is a HOST
+ * array of nvec device pointers (16-byte aligned); ws holds at least
+ * nsol_lb_gram_ws_doubles() doubles. */
+int64_t nsol_lb_gram_ws_doubles(void);
+int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
+                            int64_t n, double *result, double *ws, void *stream);
+int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *iwhere,
+                            int64_t n, double *result, double *ws, void *stream);
 int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
                        double *ws, void *stream);
 int nsol_lb_projgr_f32(const float *x, const float *g, int64_t n, double lo, double hi,

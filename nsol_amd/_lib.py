@@ -71,6 +71,8 @@ def load():
     lib.nsol_lb_walk_table_doubles.argtypes = [c_int, c_int]
     lib.nsol_lb_walk_tmp_bytes.restype = c_i64
     lib.nsol_lb_walk_tmp_bytes.argtypes = [c_int]
+    lib.nsol_lb_gram_ws_doubles.restype = c_i64
+    lib.nsol_lb_gram_ws_doubles.argtypes = []
     lib.nsol_hip_set_param_conv.restype = c_int
     lib.nsol_hip_set_param_conv.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_hip_set_param_pd2.restype = c_int

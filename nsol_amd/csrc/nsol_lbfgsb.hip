@@ -138,6 +138,144 @@ __global__ __launch_bounds__(kBlock) void k_mdot(const T *__restrict__ x,
   block_partials<1>(a, ws, false);
 }
 
+// ---- masked Gram matrix of up to kGramMax vectors in one pass ---------------
+// out[(i,j)], i <= j, = sum over free variables of v_i * v_j, for all pairs at
+// once: a workgroup stages a tile of 4 KiB of every vector in LDS
+// (zero where the variable is not free), then thread (pair, split) accumulates
+// its product over the tile in double.  One read of each vector instead of one
+// per pair: the subspace matrix of L-BFGS-B needs 2c^2 + c masked dots of c = 1..m
+// stored pairs (tikhonov_linear_solver.py:214-220 -> scipy's formk).
+constexpr int kGramMax = 32;
+template <typename T> constexpr int gram_tile() { return 4096 / (int)sizeof(T); }   // voxels staged per step
+constexpr int kGramBlocks = 512;
+
+template <typename T>
+struct GramPtrs {
+  const T *p[kGramMax];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_masked_gram(GramPtrs<T> P, int nvec,
+                                                         const int8_t *iw, int64_t n,
+                                                         int npairs, int splits,
+                                                         double *ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_raw[];
+  T *tile = reinterpret_cast<T *>(gram_raw);           // [nvec][kGramTile + pad]
+  constexpr int kGramTile = gram_tile<T>();
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int LD = kGramTile + VEC;                   // row pitch: rows on different banks
+  const int tid = threadIdx.x;
+  const int pair = tid / splits, q = tid - pair * splits;
+  const bool worker = pair < npairs;
+  int vi = 0, vj = 0;
+  if (worker) {                                         // pair -> (i, j), i <= j
+    int r = pair;
+    while (r >= nvec - vi) { r -= nvec - vi; ++vi; }
+    vj = vi + r;
+  }
+  double acc = 0.0;
+  const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t base = t * kGramTile;
+    // stage: every thread brings VEC consecutive voxels of every vector
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    typedef int8_t M __attribute__((ext_vector_type(VEC)));
+    for (int e = tid * VEC; e < kGramTile; e += kBlock * VEC) {
+      const int64_t g = base + e;
+      const bool full = g + VEC <= n;       // pointers are 16-byte aligned (host check)
+      bool keep[VEC];
+      if (full && iw) {
+        const M m = *reinterpret_cast<const M *>(iw + g);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) keep[k] = m[k] <= 0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          keep[k] = (g + k < n) && (!iw || iw[g + k] <= 0);
+      }
+      for (int v = 0; v < nvec; ++v) {
+        V val;
+        if (full) {
+          val = *reinterpret_cast<const V *>(P.p[v] + g);
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) val[k] = (g + k < n) ? P.p[v][g + k] : T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) val[k] = keep[k] ? val[k] : T(0);
+        *reinterpret_cast<V *>(tile + v * LD + e) = val;
+      }
+    }
+    __syncthreads();
+    if (worker) {
+      const T *a = tile + vi * LD, *b = tile + vj * LD;
+      for (int e = q * VEC; e < kGramTile; e += splits * VEC) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc += (double)a[e + k] * (double)b[e + k];
+      }
+    }
+    __syncthreads();
+  }
+  ws[(int64_t)blockIdx.x * kBlock + tid] = worker ? acc : 0.0;
+}
+
+// one workgroup per pair: sums the (block, split) partials in a fixed order
+__global__ __launch_bounds__(kBlock) void k_gram_final(const double *ws, int nblocks,
+                                                        int splits, double *result) {
+  __shared__ double s[kBlock / kWave];
+  const int pair = blockIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+    const double *row = ws + (int64_t)b * kBlock + pair * splits;
+    double u = row[0];
+    for (int k = 1; k < splits; ++k) u += row[k];
+    t += u;
+  }
+  t = wsum(t);
+  if (lane == 0) s[wv] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = s[0];
+    for (int j = 1; j < kBlock / kWave; ++j) r += s[j];
+    result[pair] = r;
+  }
+}
+
+template <typename T>
+int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
+                     double *result, double *ws, void *stream) {
+  if (!vecs || nvec < 1 || nvec > kGramMax || n < 1 || !result || !ws)
+    return NSOL_EINVAL;
+  const int npairs = nvec * (nvec + 1) / 2;
+  if (npairs > kBlock) return NSOL_EINVAL;      // nvec <= 22
+  if (iwhere && ((uintptr_t)iwhere & 15u)) return NSOL_EINVAL;
+  GramPtrs<T> P;
+  for (int v = 0; v < kGramMax; ++v) {
+    P.p[v] = v < nvec ? vecs[v] : nullptr;
+    if (v < nvec && (!vecs[v] || ((uintptr_t)vecs[v] & 15u))) return NSOL_EINVAL;
+  }
+  int splits = 1;
+  while (splits * 2 * npairs <= kBlock) splits *= 2;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int kGramTile = gram_tile<T>();
+  const size_t lds = (size_t)nvec * (kGramTile + VEC) * sizeof(T);
+  const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
+  const int blocks = (int)(ntiles < kGramBlocks ? ntiles : kGramBlocks);
+  auto kern = k_masked_gram<T>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds, as_stream(stream), P, nvec,
+                     iwhere, n, npairs, splits, ws);
+  hipLaunchKernelGGL(k_gram_final, dim3(npairs), dim3(kBlock), 0, as_stream(stream), ws,
+                     blocks, splits, result);
+  return launch_status();
+}
+
 // ---- Cauchy set-up: classify, d = -g on moving variables, breakpoints
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_cauchy_setup(
@@ -399,6 +537,18 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
   hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, g,
                      1, false, result);
   return launch_status();
+}
+
+extern "C" {
+int64_t nsol_lb_gram_ws_doubles(void) { return (int64_t)kGramBlocks * kBlock; }
+int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
+                            int64_t n, double *result, double *ws, void *stream) {
+  return masked_gram_impl<float>(vecs, nvec, iwhere, n, result, ws, stream);
+}
+int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *iwhere,
+                            int64_t n, double *result, double *ws, void *stream) {
+  return masked_gram_impl<double>(vecs, nvec, iwhere, n, result, ws, stream);
+}
 }
 
 #define NSOL_LB_DEF(T, SUF)                                                      \

@@ -26,6 +26,7 @@ class DeviceBackend(object):
     def __init__(self):
         self._res = None
         self._tmp = None
+        self._gram_ws = None
 
     # ---- small helpers
     def _bufs(self, like):
@@ -93,10 +94,14 @@ class DeviceBackend(object):
                         "mdot")
         return [float(t) for t in out.cpu().numpy()]
 
+    USE_GRAM_KERNEL = True    # False: one masked dot per matrix entry
+
     def masked_grams(self, ws_list, wy_list, free):
         """Y'ZZ'Y, S'ZZ'S, S'ZZ'Y over the free variables (Z), col x col."""
         c = len(ws_list)
         like = ws_list[0]
+        if self.USE_GRAM_KERNEL and 2 * c <= 22:
+            return self._masked_grams_one_pass(ws_list, wy_list, free)
         wsb, _ = self._bufs(like)
         out = torch.empty(3 * c * c, dtype=torch.float64, device=like.device)
         fn = _fn("mdot", like)
@@ -116,6 +121,29 @@ class DeviceBackend(object):
         yy = np.triu(h[0]) + np.triu(h[0], 1).T
         ss = np.triu(h[1]) + np.triu(h[1], 1).T
         return yy, ss, h[2]
+
+    def _masked_grams_one_pass(self, ws_list, wy_list, free):
+        """All entries from ONE pass over the 2c vectors (nsol_lb_masked_gram_*)."""
+        import ctypes
+        c = len(ws_list)
+        vecs = list(wy_list) + list(ws_list)           # Y first, then S
+        like = vecs[0]
+        nv = 2 * c
+        lib = _lib.load()
+        if self._gram_ws is None or self._gram_ws.device != like.device:
+            self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
+                                        dtype=torch.float64, device=like.device)
+        npairs = nv * (nv + 1) // 2
+        out = torch.empty(npairs, dtype=torch.float64, device=like.device)
+        ptrs = (ctypes.c_void_p * nv)(*[v.data_ptr() for v in vecs])
+        self._check(_fn("masked_gram", like)(
+            ptrs, nv, _p(free), like.numel(), _p(out), _p(self._gram_ws),
+            stream_ptr()), "masked_gram")
+        flat = out.cpu().numpy()
+        g = np.zeros((nv, nv))
+        g[np.triu_indices(nv)] = flat                  # row-major pairs, i <= j
+        g = g + np.triu(g, 1).T
+        return g[:c, :c], g[c:, c:], g[c:, :c]         # Y'Y, S'S, S'Y
 
     # ---- Cauchy point
     def cauchy_setup(self, x, g, lo, hi, iwhere):

@@ -840,6 +840,39 @@ def test_two_iterations_per_pass_large_shapes(nsol, shape):
         assert torch.equal(a, b), shape
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("c,n", [(1, 1000), (3, 70001), (7, 262144), (10, 300007)])
+def test_masked_gram_matches_masked_dots(nsol, dtype, c, n):
+    """nsol_lb_masked_gram_* (all Y'ZZ'Y, S'ZZ'S, S'ZZ'Y entries from one pass)
+    against one nsol_lb_mdot_* per entry and against NumPy in float64."""
+    import torch
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(c)
+    ws = [torch.randn(n, device="cuda", dtype=td, generator=gen) for _ in range(c)]
+    wy = [torch.randn(n, device="cuda", dtype=td, generator=gen) for _ in range(c)]
+    free = (torch.rand(n, device="cuda", generator=gen) < 0.3).to(torch.int8)
+    free = free * 2 - 1 * (torch.rand(n, device="cuda", generator=gen) < 0.1).to(
+        torch.int8)                                   # values in {-1, 0, 1, 2}
+    be = DeviceBackend()
+    one = be.masked_grams(ws, wy, free)
+    be.USE_GRAM_KERNEL = False
+    many = be.masked_grams(ws, wy, free)
+    m = (free.cpu().numpy() <= 0).astype(np.float64)
+    S = np.stack([w.cpu().numpy().astype(np.float64) * m for w in ws])
+    Y = np.stack([w.cpu().numpy().astype(np.float64) * m for w in wy])
+    ref = (Y.dot(Y.T), S.dot(S.T), S.dot(Y.T))
+    for a, b, r in zip(one, many, ref):
+        scale = np.abs(r).max() + 1e-300
+        assert np.abs(a - r).max() / scale < 1e-12
+        assert np.abs(a - b).max() / scale < 1e-12
+    none = be._masked_grams_one_pass(ws, wy, None)   # no mask: all variables
+    assert np.abs(none[0] - np.stack([w.cpu().numpy().astype(np.float64)
+                                      for w in wy]).dot(
+        np.stack([w.cpu().numpy().astype(np.float64) for w in wy]).T)).max() \
+        / (np.abs(none[0]).max()) < 1e-12
+
+
 def test_two_iterations_per_pass_vs_oracle(nsol):
     from oracle import nsol_oracle as orc
     shape = (12, 21, 256)

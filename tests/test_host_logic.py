@@ -24,12 +24,16 @@ def test_library_builds_loads_and_exports_declared_symbols():
                  "prox_ell1", "prox_ell2", "dot", "pd_dual_step",
                  "pd_primal_step", "pd_fused_iter", "pd_run",
                  "admm_vw_update", "vector_shrink", "loss_cost_grad",
-                 "loss_eval", "vector_norm_sum"):
+                 "loss_eval", "vector_norm_sum", "pd_fused2_iter",
+                 "pd_fusedk_iter", "corr3_wrap", "lb_masked_gram", "lb_mdot"):
         for suf in ("f32", "f64"):
             assert "nsol_%s_%s" % (base, suf) in decl
     lib = _lib.load()            # binds every symbol or raises
     assert lib.nsol_hip_abi_version() == 1
     assert lib.nsol_hip_reduce_ws_doubles() == 16384
+    assert lib.nsol_lb_gram_ws_doubles() >= 256
+    for name in ("nsol_pd_fusedk_tuned", "nsol_pd_fusedk_plan"):
+        assert name in decl
 
 
 def test_product_does_not_import_the_oracle():
