@@ -443,6 +443,15 @@ int nsol_pair_stats_f64(const double *x, const double *y, int64_t n, double mx,
  * subspace matrix (2c^2 + c masked dots for c stored pairs).  vecs is a HOST
  * array of nvec device pointers (16-byte aligned); ws holds at least
  * nsol_lb_gram_ws_doubles() doubles. */
+/* mdots: result[k] = sum over the free variables of vecs[k] * y, k < nvec, with y
+ * and the mask read once (W^T v of the compact L-BFGS representation).  vecs is
+ * a HOST array of device pointers; ws: nsol_lb_gram_ws_doubles() doubles. */
+int nsol_lb_mdots_f32(const float *const *vecs, int nvec, const float *y,
+                      const int8_t *iwhere, int64_t n, double *result, double *ws,
+                      void *stream);
+int nsol_lb_mdots_f64(const double *const *vecs, int nvec, const double *y,
+                      const int8_t *iwhere, int64_t n, double *result, double *ws,
+                      void *stream);
 int64_t nsol_lb_gram_ws_doubles(void);
 int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream);

@@ -138,6 +138,87 @@ __global__ __launch_bounds__(kBlock) void k_mdot(const T *__restrict__ x,
   block_partials<1>(a, ws, false);
 }
 
+// ---- one vector against several: result[k] = sum_free vecs[k] * v ------------
+// (v and the mask are read once instead of once per product)
+constexpr int kDotsMax = 12;
+
+template <typename T>
+struct DotsPtrs {
+  const T *p[kDotsMax];
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_mdots(DotsPtrs<T> P, int nvec,
+                                                   const T *__restrict__ y,
+                                                   const int8_t *iw, int64_t n,
+                                                   double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
+  double a[kDotsMax];
+#pragma unroll
+  for (int k = 0; k < kDotsMax; ++k) a[k] = 0.0;
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    V yv = reinterpret_cast<const V *>(y)[j];
+    if (iw) {
+      const M m = reinterpret_cast<const M *>(iw)[j];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) yv[e] = m[e] <= 0 ? yv[e] : T(0);
+    }
+#pragma unroll
+    for (int k = 0; k < kDotsMax; ++k) {
+      if (k < nvec) {
+        const V xv = reinterpret_cast<const V *>(P.p[k])[j];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[k] += (double)xv[e] * (double)yv[e];
+      }
+    }
+  }
+  // per-statistic block sums; layout ws[k * kRed + block] like block_partials
+  __shared__ double s[kDotsMax][kBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < kDotsMax; ++k) {
+    const double v = wsum(a[k]);
+    if (lane == 0) s[k][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < nvec) {
+    const int k = threadIdx.x;
+    double t = s[k][0];
+    for (int j = 1; j < kBlock / kWave; ++j) t += s[k][j];
+    ws[(int64_t)k * kRed + blockIdx.x] = t;
+  }
+}
+
+template <typename T>
+int mdots_impl(const T *const *vecs, int nvec, const T *y, const int8_t *iwhere,
+               int64_t n, double *result, double *ws, void *stream) {
+  if (!vecs || nvec < 1 || !y || n < 1 || !result || !ws) return NSOL_EINVAL;
+  constexpr int VW = 16 / sizeof(T);
+  bool vec = n % VW == 0 && !((uintptr_t)y & 15) &&
+             (!iwhere || !((uintptr_t)iwhere & (VW - 1)));
+  for (int k = 0; k < nvec; ++k) {
+    if (!vecs[k]) return NSOL_EINVAL;
+    vec = vec && !((uintptr_t)vecs[k] & 15);
+  }
+  const int gr = rgrid(vec ? n / VW : n);
+  for (int b = 0; b < nvec; b += kDotsMax) {       // at most kDotsMax per launch
+    const int cnt = nvec - b < kDotsMax ? nvec - b : kDotsMax;
+    DotsPtrs<T> P;
+    for (int k = 0; k < kDotsMax; ++k) P.p[k] = k < cnt ? vecs[b + k] : nullptr;
+    if (vec)
+      hipLaunchKernelGGL((k_mdots<T, VW>), dim3(gr), dim3(kBlock), 0,
+                         as_stream(stream), P, cnt, y, iwhere, n, ws);
+    else
+      hipLaunchKernelGGL((k_mdots<T, 1>), dim3(gr), dim3(kBlock), 0, as_stream(stream),
+                         P, cnt, y, iwhere, n, ws);
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, gr,
+                       cnt, false, result + b);
+  }
+  return launch_status();
+}
+
 // ---- masked Gram matrix of up to kGramMax vectors in one pass ---------------
 // out[(i,j)], i <= j, = sum over free variables of v_i * v_j, for all pairs at
 // once: a workgroup stages a tile of 4 KiB of every vector in LDS
@@ -571,6 +652,16 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
 
 extern "C" {
 int64_t nsol_lb_gram_ws_doubles(void) { return (int64_t)kGramBlocks * kBlock; }
+int nsol_lb_mdots_f32(const float *const *vecs, int nvec, const float *y,
+                      const int8_t *iwhere, int64_t n, double *result, double *ws,
+                      void *stream) {
+  return mdots_impl<float>(vecs, nvec, y, iwhere, n, result, ws, stream);
+}
+int nsol_lb_mdots_f64(const double *const *vecs, int nvec, const double *y,
+                      const int8_t *iwhere, int64_t n, double *result, double *ws,
+                      void *stream) {
+  return mdots_impl<double>(vecs, nvec, y, iwhere, n, result, ws, stream);
+}
 int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream) {
   return masked_gram_impl<float>(vecs, nvec, iwhere, n, result, ws, stream);

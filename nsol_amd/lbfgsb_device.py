@@ -82,16 +82,19 @@ class DeviceBackend(object):
         return float(res[0].item())
 
     def dots(self, vecs, v, free=None):
-        """[sum_free vecs[k]*v]: one kernel per vector, one read-back."""
+        """[sum_free vecs[k]*v]: one pass over v and the vectors, one read-back."""
+        import ctypes
         if not vecs:
             return []
-        ws, _ = self._bufs(v)
+        lib = _lib.load()
+        if self._gram_ws is None or self._gram_ws.device != v.device:
+            self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
+                                        dtype=torch.float64, device=v.device)
         out = torch.empty(len(vecs), dtype=torch.float64, device=v.device)
-        fn = _fn("mdot", v)
-        for k, w in enumerate(vecs):
-            self._check(fn(_p(w), _p(v), _p(free), v.numel(),
-                           out.data_ptr() + 8 * k, _p(ws), stream_ptr()),
-                        "mdot")
+        ptrs = (ctypes.c_void_p * len(vecs))(*[w.data_ptr() for w in vecs])
+        self._check(_fn("mdots", v)(ptrs, len(vecs), _p(v), _p(free), v.numel(),
+                                    _p(out), _p(self._gram_ws), stream_ptr()),
+                    "mdots")
         return [float(t) for t in out.cpu().numpy()]
 
     USE_GRAM_KERNEL = True    # False: one masked dot per matrix entry
