@@ -185,7 +185,6 @@ class DeviceBackend(object):
         sel = _fn("select", tbk)
         gat = _fn("gather", tbk)
         srt = _fn("sort_candidates", tbk)
-        cntw = _fn("count_window", tbk)
         walk = _fn("cauchy_walk", tbk)
         PW = ctypes.c_void_p * max(col, 1)
         wy_p = PW(*[w.data_ptr() for w in wy_list])
@@ -216,21 +215,19 @@ class DeviceBackend(object):
 
         def advance(S):
             lim = (S.tsum + S.dtm) * (1.0 + (1e-6 if f32 else 1e-12)) + 1e-300
-            wsb, res = self._bufs(tbk)
+            # the compaction counts as it goes (its counter runs past the
+            # capacity): a window that overflows is halved and selected again
             while True:
-                self._check(cntw(_p(tbk), n, float(S.t_done), int(S.i_done),
-                                 float(lim), _p(res), _p(wsb), stream_ptr()),
-                            "count_window")
-                count = int(round(float(res[0].item())))
+                self._check(sel(_p(tbk), n, float(S.t_done), int(S.i_done),
+                                float(lim), _p(idx), cap, _p(cnt),
+                                stream_ptr()), "select")
+                count = int(cnt.item())
                 if count <= cap:
                     break
                 base = max(S.t_done, 0.0)
                 lim = base + 0.5 * (lim - base)
             if count == 0:
                 return None
-            self._check(sel(_p(tbk), n, float(S.t_done), int(S.i_done),
-                            float(lim), _p(idx), cap, _p(cnt), stream_ptr()),
-                        "select")
             tmp = scratch("sort", lib.nsol_lb_sort_tmp_bytes(
                 count, 4 if f32 else 8), torch.uint8)
             self._check(srt(_p(tbk), _p(idx), count, _p(tmp), tmp.numel(),
