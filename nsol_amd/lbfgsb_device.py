@@ -224,8 +224,10 @@ class DeviceBackend(object):
                 count = int(cnt.item())
                 if count <= cap:
                     break
+                # shrink in proportion to the overflow (breakpoints are dense
+                # and fairly even on image data), at least by half
                 base = max(S.t_done, 0.0)
-                lim = base + 0.5 * (lim - base)
+                lim = base + min(0.5, 0.8 * cap / count) * (lim - base)
             if count == 0:
                 return None
             tmp = scratch("sort", lib.nsol_lb_sort_tmp_bytes(
