@@ -10,6 +10,26 @@ from .solver import Solver
 from ._accessors import add_accessors
 
 
+class _LazyScaled(object):
+    """A host array standing for raw / x_scale; the quotient is formed on the
+    device, in the working precision, the first time it is needed."""
+
+    def __init__(self, raw, x_scale):
+        arr = np.asarray(raw)
+        keep = arr.dtype if arr.dtype in (np.float32, np.float64) \
+            else np.float64
+        self.raw = np.array(arr, dtype=keep).reshape(-1)   # private copy
+        self.x_scale = float(x_scale)
+        self._cache = {}
+
+    def device(self, dtype):
+        key = np.dtype(dtype).name
+        if key not in self._cache:
+            self._cache[key] = ops.scale(to_device(self.raw, dtype),
+                                         self.x_scale, divide=True)
+        return self._cache[key]
+
+
 class LinearSolver(Solver):
 
     def __init__(self, A, A_adj, b, x0, alpha, x_scale, data_loss,
@@ -18,7 +38,7 @@ class LinearSolver(Solver):
                         dtype=dtype)
         self._A = A
         self._A_adj = A_adj
-        self._b = self._scaled(b)                 # linear_solver.py:73
+        self._b = self._scaled_data(b)            # linear_solver.py:73
         self._alpha = float(alpha)
         self._data_loss = data_loss
         self._data_loss_scale = float(data_loss_scale)
@@ -32,14 +52,27 @@ class LinearSolver(Solver):
                              .view(-1), self._x_scale, divide=True)
         return np.asarray(v, dtype=np.float64) / self._x_scale
 
+    def _scaled_data(self, v):
+        """The observation b: a large host array is kept as given and divided by
+        x_scale on the device at its first use (once; the device copy is cached)
+        instead of in two float64 passes on the host at construction and one
+        float64 upload per outer iteration."""
+        if not is_device_tensor(v) and np.size(v) >= (1 << 20):
+            return _LazyScaled(v, self._x_scale)
+        return self._scaled(v)
+
     def _dev(self, v):
         """Flat device tensor of the working dtype (uploads host arrays)."""
+        if isinstance(v, _LazyScaled):
+            return v.device(self._dtype)
         if is_device_tensor(v):
             return v.to(torch_dtype(self._dtype)).contiguous().view(-1)
         return to_device(np.asarray(v, dtype=np.float64).reshape(-1),
                          self._dtype)
 
     def get_b(self):
+        if isinstance(self._b, _LazyScaled):
+            return np.array(self._b.raw, dtype=np.float64)
         if is_device_tensor(self._b):
             return to_numpy(ops.scale(self._b, self._x_scale))
         return np.array(self._b) * self._x_scale
