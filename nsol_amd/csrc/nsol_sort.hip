@@ -26,11 +26,12 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 template <typename T>
 size_t cub_bytes(int count) {
   size_t a = 0, b = 0;
-  hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const int64_t *)nullptr,
-                                    (int64_t *)nullptr, count);
-  hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const T *)nullptr,
-                                     (T *)nullptr, (const int64_t *)nullptr,
-                                     (int64_t *)nullptr, count);
+  // size queries: nothing is launched
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const int64_t *)nullptr,
+                                          (int64_t *)nullptr, count);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const T *)nullptr,
+                                           (T *)nullptr, (const int64_t *)nullptr,
+                                           (int64_t *)nullptr, count);
   return a > b ? a : b;
 }
 
@@ -228,8 +229,8 @@ __global__ void k_walk_out(int K, int col2, double f1, double f2, double dtm,
 
 inline size_t scan_bytes(int K) {
   size_t b = 0;
-  hipcub::DeviceScan::InclusiveSum(nullptr, b, (const double *)nullptr,
-                                   (double *)nullptr, K);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const double *)nullptr,
+                                         (double *)nullptr, K);
   return b;
 }
 
@@ -257,19 +258,21 @@ int walk_impl(const T *tbk, const T *d, const T *x, const int64_t *idx, int K,
   size_t tb = (size_t)tmp_bytes;
   hipLaunchKernelGGL(k_walk_build<T>, g, b, 0, st, tbk, d, x, idx, K, P, col,
                      theta, lo, hi, tj, C);
-  for (int j = 0; j < col2; ++j)
-    hipcub::DeviceScan::InclusiveSum(tmp, tb, C.G + (int64_t)j * K,
-                                     C.Pcum + (int64_t)j * K, K, st);
+  hipError_t ce = hipSuccess;            // first failure of a hipCUB scan
+  auto scan = [&](const double *in, double *outp) {
+    const hipError_t r = hipcub::DeviceScan::InclusiveSum(tmp, tb, in, outp, K, st);
+    if (ce == hipSuccess) ce = r;
+  };
+  for (int j = 0; j < col2; ++j) scan(C.G + (int64_t)j * K, C.Pcum + (int64_t)j * K);
   if (col2 > 0) {
     hipLaunchKernelGGL(k_walk_h, g, b, 0, st, K, col2, params, C);
-    for (int j = 0; j < col2; ++j)
-      hipcub::DeviceScan::InclusiveSum(tmp, tb, C.G + (int64_t)j * K,
-                                       C.Ccum + (int64_t)j * K, K, st);
+    for (int j = 0; j < col2; ++j) scan(C.G + (int64_t)j * K, C.Ccum + (int64_t)j * K);
     hipLaunchKernelGGL(k_walk_quad, g, b, 0, st, K, col2, params, C);
   }
-  hipcub::DeviceScan::InclusiveSum(tmp, tb, C.inc2, C.f2cum, K, st);
+  scan(C.inc2, C.f2cum);
   hipLaunchKernelGGL(k_walk_inc1, g, b, 0, st, K, f2, C);
-  hipcub::DeviceScan::InclusiveSum(tmp, tb, C.inc1, C.f1cum, K, st);
+  scan(C.inc1, C.f1cum);
+  if (ce != hipSuccess) return (int)ce;
   const int init[2] = {0x7fffffff, 0x7fffffff};
   hipError_t e = hipMemcpyAsync(event, init, sizeof(init), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
