@@ -908,6 +908,12 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     it = g_plans.emplace(key, std::move(P)).first;
   }
   Plan &P = it->second;
+  // no event queries / records on a stream that is being captured into a graph:
+  // such launches use the settled plan, or the model's best while exploring
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+  if (cap != hipStreamCaptureStatusNone)
+    return NSOL_GO(P.cand[P.chosen >= 0 ? P.chosen : 0]);
   plan_poll(P, K);
   if (P.chosen >= 0) return NSOL_GO(P.cand[P.chosen]);
   // exploring: next candidate that still needs a sample (the first launch of a
