@@ -171,10 +171,11 @@ def main():
     # Plan pass (untimed, like creating an FFT plan): the depth-3 kernel tunes
     # its footprint shape online during the first few dozen launches on a new
     # problem shape.  Run until it has settled, then reset the state.
-    for _ in range(8):
-        run(0, min(60, total), True)
+    psig, pta, pth = step_schedule("ALG2", 16.0, lmbda, 60)   # its own schedule:
+    for _ in range(8):                  # independent of --steps / --warmup
+        ops.pd_run(xbar[0], xbar[1], x, bt, p[0], p[1], shape, w, lmbda, psig,
+                   pta, pth, True, 0.05, flags, x_alt=x_alt)
         torch.cuda.synchronize()
-        state["slot"] = 0
         if pinned or ops.pd_fusedk_tuned(x, shape) != 0:
             break
     plan = pinned or ops.pd_fusedk_plan(x, shape)
