@@ -438,7 +438,7 @@ int nsol_pair_stats_f64(const double *x, const double *y, int64_t n, double mx,
  *   trunc_apply   xnew = free ? (i == ibd ? bound : xcp + alpha*d) : xcp
  * ---------------------------------------------------------------------- */
 /* masked_gram: result[(i,j)], i <= j row by row, = sum over the free variables
- * (iwhere <= 0; all if iwhere is NULL) of vecs[i] * vecs[j], for nvec <= 22
+ * (iwhere <= 0; all if iwhere is NULL) of vecs[i] * vecs[j], for nvec <= 24
  * vectors in ONE pass over them -- the Y'ZZ'Y, S'ZZ'S and S'ZZ'Y blocks of the
  * subspace matrix (2c^2 + c masked dots for c stored pairs).  vecs is a HOST
  * array of nvec device pointers (16-byte aligned); ws holds at least

@@ -229,38 +229,53 @@ int mdots_impl(const T *const *vecs, int nvec, const T *y, const int8_t *iwhere,
 constexpr int kGramMax = 32;
 template <typename T> constexpr int gram_tile() { return 4096 / (int)sizeof(T); }   // voxels staged per step
 constexpr int kGramBlocks = 512;
+constexpr int kGramMaxVec = 24;                 // 8 x 8 blocks of 3 x 3 pairs
+constexpr int kGramEnt = 36 * 9;                // block entries one workgroup writes
 
 template <typename T>
 struct GramPtrs {
   const T *p[kGramMax];
 };
 
+// Register tiling: a thread owns a 3 x 3 block of pairs (vectors 3bi..3bi+2 against
+// 3bj..3bj+2, bi <= bj) for a share of the tile's voxels, so six LDS reads and six
+// conversions feed nine double FMAs (a thread per single pair needed two reads and
+// two conversions per FMA).
+constexpr int kGramB = 3;
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_masked_gram(GramPtrs<T> P, int nvec,
                                                          const int8_t *iw, int64_t n,
-                                                         int npairs, int splits,
-                                                         double *ws) {
+                                                         int nb, int splits, double *ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gram_raw[];
-  T *tile = reinterpret_cast<T *>(gram_raw);           // [nvec][kGramTile + pad]
+  T *tile = reinterpret_cast<T *>(gram_raw);           // [nb * 3][kGramTile + pad]
   constexpr int kGramTile = gram_tile<T>();
   constexpr int VEC = 16 / sizeof(T);
   constexpr int LD = kGramTile + VEC;                   // row pitch: rows on different banks
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
   const int tid = threadIdx.x;
-  const int pair = tid / splits, q = tid - pair * splits;
-  const bool worker = pair < npairs;
-  int vi = 0, vj = 0;
-  if (worker) {                                         // pair -> (i, j), i <= j
-    int r = pair;
-    while (r >= nvec - vi) { r -= nvec - vi; ++vi; }
-    vj = vi + r;
+  const int nblk = nb * (nb + 1) / 2;
+  const int blk = tid / splits, q = tid - blk * splits;
+  const bool worker = blk < nblk;
+  int bi = 0, bj = 0;
+  if (worker) {                                         // blk -> (bi, bj), bi <= bj
+    int r = blk;
+    while (r >= nb - bi) { r -= nb - bi; ++bi; }
+    bj = bi + r;
   }
-  double acc = 0.0;
+  double acc[kGramB][kGramB];
+#pragma unroll
+  for (int u = 0; u < kGramB; ++u)
+#pragma unroll
+    for (int v = 0; v < kGramB; ++v) acc[u][v] = 0.0;
+  // rows beyond nvec (padding of the last block) stay zero
+  for (int v = nvec; v < nb * kGramB; ++v)
+    for (int e = tid; e < kGramTile; e += kBlock) tile[v * LD + e] = T(0);
   const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int64_t base = t * kGramTile;
     // stage: every thread brings VEC consecutive voxels of every vector
-    typedef T V __attribute__((ext_vector_type(VEC)));
-    typedef int8_t M __attribute__((ext_vector_type(VEC)));
     for (int e = tid * VEC; e < kGramTile; e += kBlock * VEC) {
       const int64_t g = base + e;
       const bool full = g + VEC <= n;       // pointers are 16-byte aligned (host check)
@@ -289,58 +304,91 @@ __global__ __launch_bounds__(kBlock) void k_masked_gram(GramPtrs<T> P, int nvec,
     }
     __syncthreads();
     if (worker) {
-      const T *a = tile + vi * LD, *b = tile + vj * LD;
+      const T *a = tile + (bi * kGramB) * LD, *b = tile + (bj * kGramB) * LD;
       for (int e = q * VEC; e < kGramTile; e += splits * VEC) {
+        V av[kGramB], bv[kGramB];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc += (double)a[e + k] * (double)b[e + k];
+        for (int u = 0; u < kGramB; ++u) {
+          av[u] = *reinterpret_cast<const V *>(a + u * LD + e);
+          bv[u] = *reinterpret_cast<const V *>(b + u * LD + e);
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          double ad[kGramB], bd[kGramB];
+#pragma unroll
+          for (int u = 0; u < kGramB; ++u) { ad[u] = (double)av[u][k]; bd[u] = (double)bv[u][k]; }
+#pragma unroll
+          for (int u = 0; u < kGramB; ++u)
+#pragma unroll
+            for (int v = 0; v < kGramB; ++v) acc[u][v] += ad[u] * bd[v];
+        }
       }
     }
     __syncthreads();
   }
-  ws[(int64_t)blockIdx.x * kBlock + tid] = worker ? acc : 0.0;
+  // sum the splits of every block entry inside the workgroup (fixed order)
+  double *red = reinterpret_cast<double *>(gram_raw);   // [kBlock][9]
+#pragma unroll
+  for (int u = 0; u < kGramB; ++u)
+#pragma unroll
+    for (int v = 0; v < kGramB; ++v)
+      red[tid * (kGramB * kGramB) + u * kGramB + v] = worker ? acc[u][v] : 0.0;
+  __syncthreads();
+  const int nent = nblk * kGramB * kGramB;
+  for (int o = tid; o < nent; o += kBlock) {
+    const int kb = o / (kGramB * kGramB), ent = o - kb * (kGramB * kGramB);
+    double sum = 0.0;
+    for (int sq = 0; sq < splits; ++sq)
+      sum += red[(kb * splits + sq) * (kGramB * kGramB) + ent];
+    ws[(int64_t)blockIdx.x * kGramEnt + o] = sum;
+  }
 }
 
-// one workgroup per pair: sums the (block, split) partials in a fixed order
+// one workgroup per pair (i <= j): sums the workgroups' partials in a fixed order
 __global__ __launch_bounds__(kBlock) void k_gram_final(const double *ws, int nblocks,
-                                                        int splits, double *result) {
+                                                        int nvec, int nb,
+                                                        double *result) {
   __shared__ double s[kBlock / kWave];
-  const int pair = blockIdx.x;
+  int vi = 0, r = blockIdx.x;
+  while (r >= nvec - vi) { r -= nvec - vi; ++vi; }
+  const int vj = vi + r;
+  const int bi = vi / kGramB, bj = vj / kGramB;
+  int kb = bj - bi;                                 // block index of (bi, bj), bi <= bj
+  for (int u = 0; u < bi; ++u) kb += nb - u;
+  const int o = kb * (kGramB * kGramB) + (vi % kGramB) * kGramB + (vj % kGramB);
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   double t = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-    const double *row = ws + (int64_t)b * kBlock + pair * splits;
-    double u = row[0];
-    for (int k = 1; k < splits; ++k) u += row[k];
-    t += u;
-  }
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) t += ws[(int64_t)b * kGramEnt + o];
   t = wsum(t);
   if (lane == 0) s[wv] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double r = s[0];
-    for (int j = 1; j < kBlock / kWave; ++j) r += s[j];
-    result[pair] = r;
+    double rr = s[0];
+    for (int j = 1; j < kBlock / kWave; ++j) rr += s[j];
+    result[blockIdx.x] = rr;
   }
 }
 
 template <typename T>
 int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
                      double *result, double *ws, void *stream) {
-  if (!vecs || nvec < 1 || nvec > kGramMax || n < 1 || !result || !ws)
+  if (!vecs || nvec < 1 || nvec > kGramMaxVec || n < 1 || !result || !ws)
     return NSOL_EINVAL;
-  const int npairs = nvec * (nvec + 1) / 2;
-  if (npairs > kBlock) return NSOL_EINVAL;      // nvec <= 22
   if (iwhere && ((uintptr_t)iwhere & 15u)) return NSOL_EINVAL;
   GramPtrs<T> P;
   for (int v = 0; v < kGramMax; ++v) {
     P.p[v] = v < nvec ? vecs[v] : nullptr;
     if (v < nvec && (!vecs[v] || ((uintptr_t)vecs[v] & 15u))) return NSOL_EINVAL;
   }
+  const int nb = (nvec + kGramB - 1) / kGramB;
+  const int nblk = nb * (nb + 1) / 2;               // <= 36 for nvec <= 24
   int splits = 1;
-  while (splits * 2 * npairs <= kBlock) splits *= 2;
+  while (splits * 2 * nblk <= kBlock) splits *= 2;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int kGramTile = gram_tile<T>();
-  const size_t lds = (size_t)nvec * (kGramTile + VEC) * sizeof(T);
+  size_t lds = (size_t)nb * kGramB * (kGramTile + VEC) * sizeof(T);
+  const size_t red = (size_t)kBlock * kGramB * kGramB * sizeof(double);
+  if (lds < red) lds = red;
   const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
   const int blocks = (int)(ntiles < kGramBlocks ? ntiles : kGramBlocks);
   auto kern = k_masked_gram<T>;
@@ -351,9 +399,9 @@ int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), lds, as_stream(stream), P, nvec,
-                     iwhere, n, npairs, splits, ws);
-  hipLaunchKernelGGL(k_gram_final, dim3(npairs), dim3(kBlock), 0, as_stream(stream), ws,
-                     blocks, splits, result);
+                     iwhere, n, nb, splits, ws);
+  hipLaunchKernelGGL(k_gram_final, dim3(nvec * (nvec + 1) / 2), dim3(kBlock), 0,
+                     as_stream(stream), ws, blocks, nvec, nb, result);
   return launch_status();
 }
 
@@ -651,7 +699,7 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
 }
 
 extern "C" {
-int64_t nsol_lb_gram_ws_doubles(void) { return (int64_t)kGramBlocks * kBlock; }
+int64_t nsol_lb_gram_ws_doubles(void) { return (int64_t)kGramBlocks * kGramEnt; }
 int nsol_lb_mdots_f32(const float *const *vecs, int nvec, const float *y,
                       const int8_t *iwhere, int64_t n, double *result, double *ws,
                       void *stream) {

@@ -103,7 +103,7 @@ class DeviceBackend(object):
         """Y'ZZ'Y, S'ZZ'S, S'ZZ'Y over the free variables (Z), col x col."""
         c = len(ws_list)
         like = ws_list[0]
-        if self.USE_GRAM_KERNEL and 2 * c <= 22:
+        if self.USE_GRAM_KERNEL and 2 * c <= 24:
             return self._masked_grams_one_pass(ws_list, wy_list, free)
         wsb, _ = self._bufs(like)
         out = torch.empty(3 * c * c, dtype=torch.float64, device=like.device)
