@@ -62,6 +62,7 @@ struct Tiling {
   int rows;   // footprint rows
   int xv;     // valid voxels per tile along x; 0 = one tile spans the row
   int ntx, nty;
+  int split;  // 1: whole waves hold the interior lanes of a row, halo lanes at the end
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   constexpr int LN = LdsShape<NT, K>::N;
   __shared__ __attribute__((aligned(16))) T s_xb[2][K - 1][LN * VEC];
   __shared__ __attribute__((aligned(16))) T s_py[2][K - 1][LN * VEC];
-  __shared__ T s_px[2][K - 1][NW];   // last p_x^(k-1) of each wave's lane 63
+  __shared__ T s_px[2][K - 1][LN];   // last p_x^(k-1) of every lane's vector
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -202,9 +203,34 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   const int ty = tile / Q.ntx;
 
   // ---- geometry of this lane
+  // lane -> (row, lx) of the footprint.  Plain: row-major.  Split (the interior of
+  // a row is a multiple of 32 lanes): whole (half) waves hold the interior lanes of
+  // one row -- aligned, contiguous 512 B / 1 KiB per array -- and the halo lanes of
+  // all rows sit together behind them; rows that straddle waves cost ~15 % of the
+  // achievable bandwidth (tools/micro/copy_pattern.hip).
   const int lxb = Q.lxb;
-  const int row = tid / lxb;
-  const int lx = tid - row * lxb;
+  constexpr int HL = HX / VEC;                 // halo lanes on each side of a row
+  int row, lx;
+  bool lone = false;                           // neighbours along x are not adjacent lanes
+  if (Q.split) {
+    const int inner = lxb - 2 * HL;
+    const int main = Q.rows * inner;
+    if (tid < main) {
+      row = tid / inner;
+      lx = HL + (tid - row * inner);
+      // the interior's first / last lane: the neighbour is a halo lane elsewhere
+      lone = (lx == HL) || (lx == HL + inner - 1);
+    } else {
+      const int h = tid - main;
+      row = h / (2 * HL);
+      const int side = h - row * (2 * HL);
+      lx = side < HL ? side : inner + side;
+      lone = true;
+    }
+  } else {
+    row = tid / lxb;
+    lx = tid - row * lxb;
+  }
   const bool active = row < Q.rows;
   const bool single_x = (Q.xv == 0);
   const int64_t xv_lo = single_x ? 0 : (int64_t)tx * Q.xv;
@@ -259,8 +285,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
 
   // per-lane byte offsets inside a plane (loop invariant); the plane is selected
   // by the scalar offset.  Stage-1 halos: old data from global memory (L1/L2).
-  const bool row_end = (lx == lxb - 1) || lane == 63;
-  const bool row_beg = (lx == 0) || lane == 0;
+  const bool row_end = (lx == lxb - 1) || lane == 63 || lone;
+  const bool row_beg = (lx == 0) || lane == 0 || lone;
   const uint32_t o0 = (uint32_t)((y * G.sy + x0) * (int64_t)sizeof(T));
   const uint32_t v_own = rin ? o0 : kInvalid;
   const uint32_t v_up = (rin && y > 0) ? o0 - syb : kInvalid;
@@ -276,7 +302,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   const bool v_u = rin && row > 0 && y > 0;
   const bool g_l = rin && row_beg && x0 > 0;
   const bool g_u = rin && y > 0;
-  const int li = (tid + lxb) * VEC;              // LDS slot of this lane (row + 1)
+  // LDS slot of this lane: logical position, one padding row above.  Idle lanes
+  // (row >= rows) keep the plain mapping: their zeros land in the bottom padding.
+  const int slot = active ? (row + 1) * lxb + lx : tid + lxb;
+  const int li = slot * VEC;
   // step size of the recomputed dual of the voxel above: zero where there is none
   // (its inputs are zero there -- out-of-range load, zero LDS row, or a lane outside
   // the volume -- so the result is exactly zero without a select per value)
@@ -447,10 +476,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       stv<T, VEC>(&s_xb[buf][k - 2][li], fr_xb[k - 2]);
       if (k == 2) {
         stv<T, VEC>(&s_py[buf][0][li], f_py);
-        if (lane == 63) s_px[buf][0][tid >> 6] = f_px[VEC - 1];
+        s_px[buf][0][slot] = f_px[VEC - 1];
       } else {
         stv<T, VEC>(&s_py[buf][k - 2][li], P.c_py[k - 1]);
-        if (lane == 63) s_px[buf][k - 2][tid >> 6] = P.c_px[k - 1][VEC - 1];
+        s_px[buf][k - 2][slot] = P.c_px[k - 1][VEC - 1];
       }
     }
 #if !(PDK_ABLATE & 4)
@@ -466,8 +495,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       T right = s_xb[buf][k - 2][li + VEC];
       if (!n_r) right = T(0);
       const T left_xb = s_xb[buf][k - 2][li - 1];
-      T left_px = __shfl_up((k == 2) ? f_px[VEC - 1] : P.c_px[k - 1][VEC - 1], 1, kWave);
-      if (lane == 0) left_px = s_px[buf][k - 2][tid > 0 ? (tid >> 6) - 1 : 0];
+      const T left_px = s_px[buf][k - 2][slot - 1];
       const T pl0 = v_l ? dual_update_u<HUBER, UNIT>(left_px, fr_xb[k - 2][0], left_xb, G.wx,
                                                S.sigma[k - 1], S.hden[k - 1])
                         : T(0);
@@ -580,6 +608,8 @@ inline int cu_count() {
   return n;
 }
 
+int g_split = -1;   // -1 / 1: split lane mapping where it applies; 0: never (experiment)
+
 struct Config {
   int nw = 0;
   int pf2 = 0;       // 1 = two prefetch register sets
@@ -607,6 +637,8 @@ inline bool make_tiling(int64_t nx, int64_t ny, int nt, int vec, int h, int hx,
   if (q.rows - 2 * h < 1) return false;
   q.ntx = ntx;
   q.nty = (int)((ny + (q.rows - 2 * h) - 1) / (q.rows - 2 * h));
+  // interior of a row = whole half-waves: give them to whole half-waves
+  q.split = (ntx > 1 && (q.xv / vec) % 32 == 0 && g_split != 0) ? 1 : 0;
   *out = q;
   return true;
 }
@@ -682,8 +714,8 @@ int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x
   }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
   if (g_tunek.verbose == 1)
-    fprintf(stderr, "k_pd_fusedk K=%d waves=%d pf2=%d: lxb=%d rows=%d xv=%d tiles=%dx%d "
-            "zchunk=%lld blocks=%lld slab=%lld model=%.3f GB\n", K, NW, (int)PF2, Q.lxb, Q.rows,
+    fprintf(stderr, "k_pd_fusedk K=%d waves=%d pf2=%d split=%d: lxb=%d rows=%d xv=%d tiles=%dx%d "
+            "zchunk=%lld blocks=%lld slab=%lld model=%.3f GB\n", K, NW, (int)PF2, Q.split, Q.lxb, Q.rows,
             Q.xv, Q.ntx, Q.nty, (long long)c.zchunk, (long long)blocks,
             (long long)slab, c.cost * 1e-9);
   hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1, PF2, UNIT>),
@@ -773,6 +805,17 @@ std::vector<Config> candidates(const Geom<T> &G) {
       c.cost = model_cost(c.q, G.nx, G.ny, G.nz, VW, (int)sizeof(T), H, HX, zeff);
       // fewer waves hide less latency: mild penalty so that ties go to more waves
       c.cost *= 1.0 + 0.02 * (16 - nw) / 4.0;
+      if (c.q.split) {
+        // rows of whole waves stream ~15 % better (measured); rows of half waves
+        // gain less and not always: the plain mapping stays a candidate there
+        const bool whole = ((c.q.lxb - 2 * (HX / VW)) % 64) == 0;
+        if (!whole) {
+          Config d = c;
+          d.q.split = 0;
+          out.push_back(d);
+        }
+        c.cost *= whole ? 0.88 : 0.97;
+      }
       out.push_back(c);
     }
   }
@@ -996,6 +1039,7 @@ int nsol_hip_set_param_pdk(const char *name, int value) {
   else if (!strcmp(name, "pdk_verbose")) nsol_pdk::g_tunek.verbose = value;
   else if (!strcmp(name, "pdk_autotune")) nsol_pdk::g_tunek.autotune = value;
   else if (!strcmp(name, "pdk_pf2")) nsol_pdk::g_tunek.pf2 = value;
+  else if (!strcmp(name, "pdk_split")) nsol_pdk::g_split = value;
   else if (!strcmp(name, "pdk_min_kvox")) nsol_pdk::g_tunek.min_kvox = value;
   else if (!strcmp(name, "pdk_tune_min_mvox")) nsol_pdk::g_tunek.tune_min_mvox = value;
   else if (!strcmp(name, "pdk_forget")) {

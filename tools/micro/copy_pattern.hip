@@ -3,7 +3,7 @@
 // marches along z, reading six arrays and writing five (16 B per lane and array),
 // with the same tile / z-chunk decomposition (halo lanes read but do not write).
 //   hipcc --offload-arch=gfx950 -O3 -o copy_pattern copy_pattern.hip
-//   ./copy_pattern n lxb rows halo_x halo_y zchunk nw
+//   ./copy_pattern n lxb rows halo_x halo_y zchunk nw [split_halo]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,9 +14,16 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void k_copy(const float *a0, const float *a1, const float *a2, const float *a3,
                        const float *a4, const float *a5, float *b0, float *b1, float *b2,
                        float *b3, float *b4, long nz, long ny, long nx, int lxb, int rows,
-                       int hx, int hy, int ntx, int nty, int zchunk) {
+                       int hx, int hy, int ntx, int nty, int zchunk, int split_halo) {
   const int tid = threadIdx.x;
-  const int row = tid / lxb, lx = tid - row * lxb;
+  int row = tid / lxb, lx = tid - row * lxb;
+  if (split_halo) {
+    // whole waves hold the 64 interior lanes of a row (aligned 1 KiB segments);
+    // the two halo lanes of every row sit together in the last wave(s)
+    const int main = rows * 64;
+    if (tid < main) { row = tid >> 6; lx = 1 + (tid & 63); }
+    else { const int h = tid - main; row = h >> 1; lx = (h & 1) ? 65 : 0; }
+  }
   int bid = blockIdx.x;
   const int tx = bid % ntx; bid /= ntx;
   const int ty = bid % nty;
@@ -47,6 +54,7 @@ int main(int argc, char **argv) {
   const int lxb = argc > 2 ? atoi(argv[2]) : 45, rows = argc > 3 ? atoi(argv[3]) : 17;
   const int hx = argc > 4 ? atoi(argv[4]) : 4, hy = argc > 5 ? atoi(argv[5]) : 2;
   const int zchunk = argc > 6 ? atoi(argv[6]) : 64, nw = argc > 7 ? atoi(argv[7]) : 12;
+  const int split_halo = argc > 8 ? atoi(argv[8]) : 0;   // needs lxb = 66
   const long nv = n * n * n;
   std::vector<float *> in(6), out(5);
   for (auto &p : in) { hipMalloc(&p, nv * 4); hipMemset(p, 0, nv * 4); }
@@ -63,7 +71,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 5; ++i)
       hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(nw * 64), 0, 0, in[0], in[1],
                          in[2], in[3], in[4], in[5], out[0], out[1], out[2], out[3], out[4],
-                         n, n, n, lxb, rows, hx, hy, ntx, nty, zchunk);
+                         n, n, n, lxb, rows, hx, hy, ntx, nty, zchunk, split_halo);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;

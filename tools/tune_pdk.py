@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--launches", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--cfg", default="3:16:0:0,3:12:0:0,2:16:0:0",
-                    help="comma list of K:waves:ntx:zchunk[:pf2]")
+                    help="comma list of K:waves:ntx:zchunk[:pf2[:split]]")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--flags", type=int, default=0)
     args = ap.parse_args()
@@ -52,6 +52,7 @@ def main():
                 _lib.set_param("pdk_ntx", c[2])
                 _lib.set_param("pdk_zchunk", c[3])
                 _lib.set_param("pdk_pf2", c[4] if len(c) > 4 else -1)
+                _lib.set_param("pdk_split", c[5] if len(c) > 5 else -1)
             if c[0] != "pd2":
                 _lib.set_param("pdk_verbose", 1 if rnd == 0 else 0)
             e0 = torch.cuda.Event(enable_timing=True)
