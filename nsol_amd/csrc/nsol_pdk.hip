@@ -313,6 +313,20 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   sig_u[0] = g_u ? S.sigma[0] : T(0);
 #pragma unroll
   for (int k = 1; k < K; ++k) sig_u[k] = v_u ? S.sigma[k] : T(0);
+  // Stage k is exact -- and its result used -- only k-1 rows inside the footprint
+  // (and, for the last stage, off the x halo lanes): the outer rows run stage 1
+  // only, the next ones stages 1-2, ...  A wave none of whose lanes needs a stage
+  // skips its arithmetic (it still publishes its previous stage and joins the
+  // barrier); with the split lane mapping a wave is one row, so 6 of 33
+  // row-stages disappear at 11 rows.
+  bool wneed[K];
+  wneed[0] = true;
+#pragma unroll
+  for (int k = 2; k <= K; ++k) {
+    const bool in_x = single_x || k < K || (lx >= HL && lx < lxb - HL);
+    const bool mine = active && row >= k - 1 && row <= Q.rows - k && in_x;
+    wneed[k - 1] = __ballot(mine) != 0ull;
+  }
 
   // zero rows above and below the footprint, once
   for (int i = tid; i < 2 * (K - 1) * 2 * lxb * VEC; i += NT) {
@@ -447,6 +461,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       const bool inr = f >= 0 && f < nzi;
       const T sk = inr ? sig_m[k - 1] : T(0);
       const T tk = inr ? tau_m[k - 1] : T(0);
+      if (!wneed[k - 1]) {                         // wave-uniform
+        zero(fr_x[k - 1]); zero(fr_xb[k - 1]); zero(fr_bt[k - 1]); zero(pzn[k - 1]);
+        continue;
+      }
       T pkz[VEC];
       dual_vec<HUBER, UNIT>(pkz, P.pz[k - 2], fr_xb[k - 2], P.c_xb[k - 1], G.wz, sk,
                             S.hden[k - 1]);
@@ -488,6 +506,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     T n_kt[K][VEC], n_px[K][VEC], n_py[K][VEC];
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
+      if (!wneed[k - 1]) {                         // wave-uniform
+        zero(n_kt[k - 1]); zero(n_px[k - 1]); zero(n_py[k - 1]);
+        continue;
+      }
       T below[VEC], above[VEC], above_py[VEC];
       ldv<T, VEC>(&s_xb[buf][k - 2][li + lxb * VEC], below);
       ldv<T, VEC>(&s_xb[buf][k - 2][li - lxb * VEC], above);
