@@ -641,14 +641,16 @@ struct Config {
 };
 
 // Footprint of `nt` lanes cut into ntx columns of tiles.
+// xv_fixed > 0: that many valid voxels per tile (the last tile may be shorter)
+// instead of nx spread evenly over ntx tiles
 inline bool make_tiling(int64_t nx, int64_t ny, int nt, int vec, int h, int hx,
-                        int lxm, int ntx, Tiling *out) {
+                        int lxm, int ntx, Tiling *out, int64_t xv_fixed = 0) {
   Tiling q;
   if (ntx == 1) {
     q.xv = 0;
     q.lxb = (int)(nx / vec);
   } else {
-    int64_t xv = (nx + ntx - 1) / ntx;
+    int64_t xv = xv_fixed > 0 ? xv_fixed : (nx + ntx - 1) / ntx;
     xv = (xv + vec - 1) / vec * vec;
     if (xv * (ntx - 1) >= nx) return false;   // fewer tiles would do
     q.xv = (int)xv;
@@ -808,13 +810,25 @@ std::vector<Config> candidates(const Geom<T> &G) {
     if (g_tunek.nw > 0 && g_tunek.nw != nw) continue;
     const int nt = nw * 64;
     const int lxm = nt / (2 * K);
-    for (int ntx = 1; ntx <= 64; ++ntx) {
+    // tile counts 1..64 with nx spread evenly, plus tiles whose interior is exactly
+    // one or two waves wide (256 / 512 B-aligned rows for the split lane mapping)
+    // where nx is not a multiple of that
+    struct Spec { int ntx; int64_t xv; };
+    std::vector<Spec> specs;
+    for (int ntx = 1; ntx <= 64; ++ntx) specs.push_back({ntx, 0});
+    for (int lanes : {64, 128}) {
+      const int64_t xv = (int64_t)lanes * VW;
+      if (G.nx > xv && G.nx % xv != 0)
+        specs.push_back({(int)((G.nx + xv - 1) / xv), xv});
+    }
+    for (const Spec &sp : specs) {
+      const int ntx = sp.ntx;
       if (g_tunek.ntx > 0 && ntx != g_tunek.ntx) continue;
       Config c;
       c.nw = nw;
       c.pf2 = (nw == 8) ? 1 : 0;
       if (g_tunek.pf2 == 0) c.pf2 = 0;
-      if (!make_tiling(G.nx, G.ny, nt, VW, H, HX, lxm, ntx, &c.q)) continue;
+      if (!make_tiling(G.nx, G.ny, nt, VW, H, HX, lxm, ntx, &c.q, sp.xv)) continue;
       const int64_t tiles = (int64_t)c.q.ntx * c.q.nty;
       double zeff;
       if (g_tunek.zchunk > 0) {
