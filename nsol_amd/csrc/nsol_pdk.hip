@@ -6,27 +6,37 @@
 // Per launch the kernel reads xbar, x, bt, p[3] once and writes p[3], x, xbar
 // once: 11 words per voxel for K iterations.
 //
-// Footprints.  The NW*64 lanes of a workgroup form a flat `rows` x `lxb` grid
-// (lxb lanes of VEC voxels per row; neither needs to divide the wave size), so
-// the footprint can be made close to square: iteration k needs iteration-(k-1)
-// values one voxel further out, hence a footprint loses K-1 voxels on every
-// side and only the interior (rows - 2(K-1)) x (lxb*VEC - 2*HX) is stored.
-// k_pd_fused2 uses full rows (512 x 8 at nx = 512: 25 % of the lanes recompute
-// overlap already at K = 2); here nx = 512 is cut into 4 x 128 valid columns
-// with 34-lane rows, 30 rows per workgroup.
+// Footprints.  The NW*64 lanes of a workgroup form a `rows` x `lxb` grid (lxb lanes
+// of VEC voxels per row), so the footprint can be made close to square:
+// iteration k needs iteration-(k-1) values one voxel further out, hence a
+// footprint loses K-1 voxels on every side and only the interior
+// (rows - 2(K-1)) x (lxb*VEC - 2*HX) is stored; the overlap is recomputed, never
+// exchanged between workgroups.  k_pd_fused2 uses full rows (512 x 8 at
+// nx = 512: 25 % of the lanes recompute overlap already at K = 2); here nx = 512
+// is cut into 2 x 256 valid columns: 64 interior + 2 halo lanes per row, 11 rows
+// per 12-wave workgroup, the interior lanes of a row in one wave ("split" lane
+// mapping) and the halo lanes of all rows together in the last wave.
 //
 // Pipeline along z (one barrier per plane).  At step s
 //   stage 1     runs iteration n+1 on plane s exactly like k_pd_fused (old-data
-//               halos from L1/L2), results stay in registers;
+//               halos from L1/L2), results stay in registers; the loads of plane
+//               s+1 are issued right behind it (software prefetch);
 //   F_k, k>=2   finishes iteration n+k on plane s-(k-1): z-component of the
 //               dual, K^T, prox, over-relaxation (it was waiting for
 //               xbar^(k-1) of the plane above);
 //   IP_k, k>=2  in-plane part of iteration n+k on plane s-(k-2): every lane
 //               publishes xbar^(k-1), p_y^(k-1) and the last p_x^(k-1) of its
-//               wave in LDS (double buffered), reads the four neighbours'
-//               entries and forms p_x^(k), p_y^(k) and the in-plane K^T.
-// The arithmetic per voxel is that of K launches of k_pd_fused in the same
-// order, so results are bit-identical.
+//               vector in LDS (double buffered, addressed by logical position),
+//               reads the four neighbours' entries and forms p_x^(k), p_y^(k)
+//               and the in-plane K^T.
+// Waves whose rows lie so far out that nobody uses their stage-k results skip
+// that arithmetic.  All global accesses are raw buffer loads / stores with a
+// loop-invariant per-lane offset (out of range for lanes outside the volume), so
+// the loop body has no exec-mask branches.  The arithmetic per voxel is that of K
+// launches of k_pd_fused in the same order, so results are bit-identical.
+//
+// Host side (bottom of the file): a cost model ranks footprint shapes; for large
+// volumes an online tuner measures the best few on the run's own launches.
 #include <stdio.h>
 #include <string.h>
 
