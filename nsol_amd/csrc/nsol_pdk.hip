@@ -113,8 +113,10 @@ template <> __device__ __forceinline__ double bld1<double>(rsrc_t r, uint32_t vo
 // scalar offset is a REGISTER the compiler (ROCm 7.2) assumes there is no hazard
 // and lets the next VALU instruction overwrite them -- on gfx950 that corrupted
 // the stored vector in the lanes of the later passes.  With a constant scalar
-// offset the hazard recogniser inserts the wait state; the s_nop makes it
-// independent of that rule.
+// offset its hazard recogniser keeps a wait state between the store and such a
+// write (checked in the ISA: at least one instruction separates them); the
+// s_nop below is belt and braces only -- the scheduler is free to move it away
+// from the store.
 template <typename T, int V>
 __device__ __forceinline__ void bst(rsrc_t r, uint32_t vo, const T (&v)[V]) {
   typedef typename Pack<T, V>::type P;
