@@ -393,22 +393,20 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
     if (++zw == nz) zw = 0;
     return v;
   };
-  // z pass: the window is a ring with compile-time slots (the step loop is
-  // unrolled NT times), so nothing is shifted
-  for (int64_t base = 0; base < nsteps; base += NT) {
+  // z pass: shift the window, emit the plane R behind.  (A ring with compile-time
+  // slots -- the step loop unrolled NT times -- is no faster at 13 taps and
+  // spills from 15 taps on.)
+  for (int64_t st = 0; st < nsteps; ++st) {
+    const V v = plane_xy(st);
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int64_t st = base + u;
-      if (st < nsteps) {                       // uniform
-        ring[u] = plane_xy(st);
-        if (st >= 2 * R && owner) {
-          V acc = tz.w[0] * ring[(u + 1) % NT];
+    for (int t = 0; t + 1 < NT; ++t) ring[t] = ring[t + 1];
+    ring[NT - 1] = v;
+    if (st >= 2 * R && owner) {
+      V acc = tz.w[0] * ring[0];
 #pragma unroll
-          for (int t = 1; t < NT; ++t) acc += tz.w[t] * ring[(u + 1 + t) % NT];
-          const int64_t z = zbeg + (st - 2 * R);
-          *reinterpret_cast<V *>(out + (z * ny + (y0 + row)) * nx + xv * VEC) = acc;
-        }
-      }
+      for (int t = 1; t < NT; ++t) acc += tz.w[t] * ring[t];
+      const int64_t z = zbeg + (st - 2 * R);
+      *reinterpret_cast<V *>(out + (z * ny + (y0 + row)) * nx + xv * VEC) = acc;
     }
   }
 }
@@ -459,8 +457,8 @@ int corr3_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
       ny < 1 || nx < 1 || ntaps < 1)
     return NSOL_EINVAL;
   constexpr int VEC = 16 / sizeof(T);
-  // longer windows spill (the z window alone is ntaps vectors per lane)
-  constexpr int kMaxFused = sizeof(T) == 4 ? 17 : 15;
+  // longer windows do not pay (the z window alone is ntaps vectors per lane)
+  constexpr int kMaxFused = 15;   // 17 taps: no faster than three passes (measured)
   if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > kMaxFused || nx % VEC != 0 ||
       (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return -2;
