@@ -471,8 +471,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       const int f = s - (k - 1);
       // below the volume and above it everything is zero padding
       const bool inr = f >= 0 && f < nzi;
-      const T sk = inr ? sig_m[k - 1] : T(0);
-      const T tk = inr ? tau_m[k - 1] : T(0);
+      // the last stage needs no per-lane masks: what it computes for a voxel
+      // outside the volume is neither stored nor read by anyone
+      const T sk = inr ? (k == K ? S.sigma[K - 1] : sig_m[k - 1]) : T(0);
+      const T tk = inr ? (k == K ? S.tau[K - 1] : tau_m[k - 1]) : T(0);
       if (!wneed[k - 1]) {                         // wave-uniform
         zero(fr_x[k - 1]); zero(fr_xb[k - 1]); zero(fr_bt[k - 1]); zero(pzn[k - 1]);
         continue;
@@ -534,18 +536,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
                                                S.sigma[k - 1], S.hden[k - 1])
                         : T(0);
       T pkx[VEC], pky[VEC], puv[VEC];
+      const T sgk = (k == K) ? S.sigma[K - 1] : sig_m[k - 1];   // see F_k
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const T px_old = (k == 2) ? f_px[j] : P.c_px[k - 1][j];
         const T hx = (j + 1 < VEC) ? fr_xb[k - 2][(j + 1) % VEC] : right;
-        pkx[j] = dual_update_u<HUBER, UNIT>(px_old, hx, fr_xb[k - 2][j], G.wx, sig_m[k - 1],
+        pkx[j] = dual_update_u<HUBER, UNIT>(px_old, hx, fr_xb[k - 2][j], G.wx, sgk,
                                       S.hden[k - 1]);
       }
       if (k == 2)
-        dual_vec<HUBER, UNIT>(pky, f_py, below, fr_xb[k - 2], G.wy, sig_m[k - 1],
-                              S.hden[k - 1]);
+        dual_vec<HUBER, UNIT>(pky, f_py, below, fr_xb[k - 2], G.wy, sgk, S.hden[k - 1]);
       else
-        dual_vec<HUBER, UNIT>(pky, P.c_py[k - 1], below, fr_xb[k - 2], G.wy, sig_m[k - 1],
+        dual_vec<HUBER, UNIT>(pky, P.c_py[k - 1], below, fr_xb[k - 2], G.wy, sgk,
                               S.hden[k - 1]);
       dual_vec<HUBER, UNIT>(puv, above_py, fr_xb[k - 2], above, G.wy, sig_u[k - 1],
                             S.hden[k - 1]);
