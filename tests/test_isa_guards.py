@@ -56,3 +56,11 @@ def test_no_store_data_hazard_in_k_pd_fusedk(tmp_path):
             assert not (data & dst), "store data overwritten at once: %s | %s" % (
                 t, nxt)
     assert stores > 100
+    # the headline instantiation (float, depth 3, 12 waves, TV, l2, unit spacing)
+    # must not spill: a few scratch dwords in its plane loop cost several percent
+    text = out.read_text()
+    names = re.findall(r"\.name:\s+(\S+)", text)
+    scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
+    head = [int(p) for n, p in zip(names, scratch)
+            if "k_pd_fusedkIfLi4ELi12ELi3ELi3ELb0ELb0ELb0ELb1" in n]
+    assert head == [0], head
