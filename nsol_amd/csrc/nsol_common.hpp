@@ -78,6 +78,19 @@ template <> __device__ __forceinline__ double dual_clamp<double>(double q) {
   return fmin(fmax(q, -1.0), 1.0);
 }
 
+// q / (1 + sigma*gamma)  (proximal_operators.py:157).  `hd` comes from
+// huber_den<T>(1 + sigma*gamma): float64 divides as NumPy does (bit-comparable);
+// float32 multiplies by the reciprocal formed in double on the host (<= 1 ulp from
+// the quotient; an IEEE float division costs ~10 VALU instructions and the Huber
+// kernels do one per dual component).  Every kernel uses these two helpers, so the
+// fused, two-pass and generic forms stay bit-identical to each other.
+template <typename T> inline T huber_den(double den);
+template <> inline double huber_den<double>(double den) { return den; }
+template <> inline float huber_den<float>(double den) { return (float)(1.0 / den); }
+template <typename T> __device__ __forceinline__ T huber_div(T q, T hd);
+template <> __device__ __forceinline__ double huber_div<double>(double q, double hd) { return q / hd; }
+template <> __device__ __forceinline__ float huber_div<float>(float q, float hd) { return q * hd; }
+
 // np.sign
 template <typename T> __device__ __forceinline__ T t_sign(T v) {
   return v > T(0) ? T(1) : (v < T(0) ? T(-1) : T(0));

@@ -610,9 +610,9 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
   int nsol_prox_dual_clamp_##SUF(T *out, const T *x, double den, int64_t n,      \
                                  void *s) {                                      \
     if (n > 0 && (!out || !x)) return NSOL_EINVAL;                               \
-    const T td = (T)den;                                                         \
+    const T td = huber_den<T>(den);                                              \
     return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
-      out[i] = dual_clamp<T>(x[i] / td);                                         \
+      out[i] = dual_clamp<T>(huber_div<T>(x[i], td));                            \
     });                                                                          \
   }                                                                              \
   int nsol_prox_ell2_##SUF(T *out, const T *x, const T *bt, double tau,          \

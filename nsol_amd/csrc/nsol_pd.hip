@@ -51,20 +51,20 @@ __global__ __launch_bounds__(kBlock) void k_dual_step(
     {
       const T nb = (ix + 1 < G.nx) ? xbar[i + 1] : T(0);
       T q = (p_in ? p_in[i] : T(0)) + sigma * (nb * G.wx + c * (-G.wx));
-      if (huber) q = q / hden;
+      if (huber) q = huber_div(q, hden);
       p_out[i] = dual_clamp(q);
     }
     if (G.ndim >= 2) {
       const T nb = (iy + 1 < G.ny) ? xbar[i + G.sy] : T(0);
       T q = (p_in ? p_in[G.n + i] : T(0)) + sigma * (nb * G.wy + c * (-G.wy));
-      if (huber) q = q / hden;
+      if (huber) q = huber_div(q, hden);
       p_out[G.n + i] = dual_clamp(q);
     }
     if (G.ndim >= 3) {
       const T nb = (iz + 1 < G.nz) ? xbar[i + G.sz] : T(0);
       T q = (p_in ? p_in[2 * G.n + i] : T(0)) +
             sigma * (nb * G.wz + c * (-G.wz));
-      if (huber) q = q / hden;
+      if (huber) q = huber_div(q, hden);
       p_out[2 * G.n + i] = dual_clamp(q);
     }
   }
@@ -402,7 +402,7 @@ template <typename T>
 PdScalars<T> make_scalars(double sigma, double hden, double tau, double tl,
                           double theta, int flags, bool has_p) {
   PdScalars<T> S;
-  S.sigma = (T)sigma; S.hden = (T)hden; S.tau = (T)tau; S.tl = (T)tl;
+  S.sigma = (T)sigma; S.hden = huber_den<T>(hden); S.tau = (T)tau; S.tl = (T)tl;
   S.one_plus_tl = prox_den<T>(tl); S.theta = (T)theta;
   S.huber = (flags & NSOL_PD_REG_HUBER) ? 1 : 0;
   S.l1 = (flags & NSOL_PD_DATA_L1) ? 1 : 0;
@@ -446,7 +446,7 @@ int dual_step_impl(const T *xbar, const T *p_in, T *p_out, int ndim, int64_t nz,
   if (!xbar || !p_out) return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   hipLaunchKernelGGL(k_dual_step<T>, dim3(grid_for(G.n)), dim3(kBlock), 0,
-                     as_stream(stream), xbar, p_in, p_out, G, (T)sigma, (T)hden,
+                     as_stream(stream), xbar, p_in, p_out, G, (T)sigma, huber_den<T>(hden),
                      hden != 1.0);
   return launch_status();
 }

@@ -479,7 +479,7 @@ int fused2_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   PdScalars<T> S[2];
   for (int i = 0; i < 2; ++i) {
-    S[i].sigma = (T)sigma[i]; S[i].hden = (T)hden[i]; S[i].tau = (T)tau[i];
+    S[i].sigma = (T)sigma[i]; S[i].hden = huber_den<T>(hden[i]); S[i].tau = (T)tau[i];
     S[i].tl = (T)tl[i]; S[i].one_plus_tl = prox_den<T>(tl[i]);
     S[i].theta = (T)theta[i];
     S[i].huber = (flags & NSOL_PD_REG_HUBER) ? 1 : 0;

@@ -55,7 +55,7 @@ __device__ __forceinline__ T dual_update(T p_old, T hi, T lo, T w,
   T q = p_old + S.sigma * (hi * w + lo * (-w));
   if (S.huber) {
     pin(q);            // a real (uniform) branch, not a speculated division
-    q = q / S.hden;
+    q = huber_div(q, S.hden);
   }
   return dual_clamp(q);
 }
@@ -66,7 +66,7 @@ template <bool HUBER, typename T>
 __device__ __forceinline__ T dual_update_s(T p_old, T hi, T lo, T w, T sigma,
                                            T hden) {
   T q = p_old + sigma * (hi * w + lo * (-w));
-  if constexpr (HUBER) q = q / hden;
+  if constexpr (HUBER) q = huber_div(q, hden);
   return dual_clamp(q);
 }
 
@@ -77,7 +77,7 @@ template <bool HUBER, bool UNIT, typename T>
 __device__ __forceinline__ T dual_update_u(T p_old, T hi, T lo, T w, T sigma, T hden) {
   const T g = UNIT ? hi - lo : hi * w + lo * (-w);
   T q = p_old + sigma * g;
-  if constexpr (HUBER) q = q / hden;
+  if constexpr (HUBER) q = huber_div(q, hden);
   return dual_clamp(q);
 }
 // one axis of K^T p: p*(-w) + p_prev*w

@@ -154,7 +154,7 @@ __device__ __forceinline__ void dual_vec(T (&out)[V], const T (&p_old)[V],
       const f32x2 p = {p_old[2 * h], p_old[2 * h + 1]};
       const f32x2 g = UNIT ? pk_sub(a, b) : a * w + b * (-w);
       f32x2 q = p + sigma * g;
-      if constexpr (HUBER) q = q / hden;
+      if constexpr (HUBER) q = q * hden;      // float: hden holds the reciprocal
       out[2 * h] = dual_clamp(q[0]);
       out[2 * h + 1] = dual_clamp(q[1]);
     }
@@ -954,7 +954,7 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
              const double *theta, int flags, hipStream_t st) {
   StageScalars<T, K> S;
   for (int i = 0; i < K; ++i) {
-    S.sigma[i] = (T)sigma[i]; S.hden[i] = (T)hden[i]; S.tau[i] = (T)tau[i];
+    S.sigma[i] = (T)sigma[i]; S.hden[i] = huber_den<T>(hden[i]); S.tau[i] = (T)tau[i];
     S.tl[i] = (T)tl[i]; S.optl[i] = prox_den<T>(tl[i]); S.theta[i] = (T)theta[i];
   }
   S.has_p = p_in != nullptr ? 1 : 0;

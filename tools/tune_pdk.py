@@ -24,6 +24,7 @@ def main():
                     help="comma list of K:waves:ntx:zchunk[:pf2[:split]]")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--w", default="1,1,1", help="inverse spacings wx,wy,wz")
     args = ap.parse_args()
     n = args.size
     shape = (n, n, args.nx or n)
@@ -34,7 +35,7 @@ def main():
     x = [bt.clone(), torch.empty_like(bt)]
     xb = [bt.clone(), torch.empty_like(bt)]
     p = [torch.zeros(3 * nv, device=dev, dtype=td) for _ in range(2)]
-    w = (1., 1., 1.)
+    w = tuple(float(t) for t in args.w.split(","))
     _lib.set_param("pdk_min_kvox", 0)
     cfgs = [tuple(int(t) for t in c.split(":")) for c in args.cfg.split(",")]
     cfgs.append(("pd2", 0, 0, 0))
