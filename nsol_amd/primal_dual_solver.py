@@ -5,8 +5,11 @@ nsol/primal_dual_solver.py:26-403).
   fused   B = grad, B_conj = grad_adj of nsol_amd.linear_operators, prox_g_conj
           in {prox_tv_conj, prox_huber_conj}, prox_f in {prox_ell1_denoising,
           prox_ell2_denoising} -- recognised THROUGH caller-side lambdas with
-          a symbolic probe; every iteration is one single-pass HIP kernel
-          (nsol_pd_run_*), 11 words of HBM traffic per voxel in 3-D;
+          a symbolic probe; nsol_pd_run_* enqueues the whole run: three
+          iterations per pass over memory on large 3-D volumes (11 words of
+          HBM traffic per voxel for all three; bit-identical to one
+          iteration per launch), one single-pass kernel per iteration
+          otherwise;
   device  any callables that work on torch HIP tensors (e.g.
           prox_linear_least_squares for deconvolution): the loop keeps all
           state in HBM and glues the callables with HIP axpy kernels;
