@@ -290,124 +290,181 @@ int try_launch_wrap(const T *x, T *out, int axis, int64_t nz, int64_t ny,
 //
 // A workgroup owns a tile of TY rows x LXB*VEC voxels and marches along z:
 //   x pass  every lane filters its own row segment straight from global memory
-//           (the taps' neighbours are L1 hits, as in k_corr_x_wrap) -- for the
-//           tile's rows and, in a second round, for the 2R halo rows -- and
-//           writes the filtered vectors to LDS (double buffered, one barrier);
+//           (raw buffer loads with 32-bit offsets; the taps' neighbours are L1
+//           hits, as in k_corr_x_wrap) -- for the tile's rows and, in a second
+//           round on the first waves, for the 2R halo rows -- and writes the
+//           filtered vectors to LDS (double buffered, one barrier);
 //   y pass  a lane reads the NT vectors of its column from LDS;
-//   z pass  the xy-filtered values of the last NT planes live in registers (a
-//           shifting window); once it is full every new plane yields one
+//   z pass  the xy-filtered values of the last NT - 1 planes live in registers
+//           (a shifting window); once it is full every new plane yields one
 //           output plane R planes behind.
+// What bounds it (512^3, 13 taps, 0.45 ms = 2.4 TB/s of the 8 B per voxel; switches
+// compiled in for the measurement): loads and stores alone take 0.31 ms, the
+// arithmetic alone 0.17 ms, and the two do not overlap -- one 16-wave workgroup
+// per CU (the z window is 48 registers per lane) runs its phases in lock step.
+// Prefetching the next plane's x windows needs 32 more registers and spills;
+// fused multiply-adds, 8-wave workgroups and a tile with the halo rows on their
+// own waves were measured and are no faster.
 // Order of the passes: x, y, z, each accumulating t = 0..NT-1 like ndimage.
 // (The three-kernel path runs z, y, x; both are rank-1 evaluations of the same
 // dense kernel and differ from it, and from each other, by rounding only.)
 // ---------------------------------------------------------------------------
+// Raw buffer addressing for the one-pass blur: a 32-bit byte offset per lane
+// plus a scalar plane offset; a lane whose offset is kNoLane is out of range of
+// every buffer, so its load returns 0 without touching memory.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kNoLane = 0xC0000000u;
+constexpr uint64_t kBlur3MaxBytes = 0xC0000000ull;
+
+// The x window of one lane: NB aligned vectors around its own one.  With 4-wide
+// vectors and R % 4 == 2 only half of the two outermost vectors is used, and
+// only that half is loaded.
+template <typename T, int VEC, int NT>
+struct XWindow {
+  static constexpr int R = NT / 2;
+  static constexpr int NBH = (R + VEC - 1) / VEC;
+  static constexpr int NB = 2 * NBH + 1;
+  static constexpr bool HALF = (VEC == 4) && (R % VEC == 2);
+  T v[NB * VEC];
+  __device__ __forceinline__ void load(rsrc_t r, const uint32_t (&xo)[NB], uint32_t yo,
+                                       uint32_t so) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      typedef typename VecOf<T, VEC>::type V;
+      if constexpr (HALF) {
+        if (b == 0 || b == NB - 1) {
+          const int h = b == 0 ? VEC / 2 : 0;
+          // (bit_cast the whole pair: applied to one element of a vector it
+          // reads element 0 whatever the index)
+          typedef T Pair __attribute__((ext_vector_type(2)));
+          const Pair t = __builtin_bit_cast(Pair, __builtin_amdgcn_raw_buffer_load_b64(
+              r, xo[b] + yo + (uint32_t)(h * sizeof(T)), so, 0));
+          v[b * VEC + h] = t[0];
+          v[b * VEC + h + 1] = t[1];
+          continue;
+        }
+      }
+      const V t = __builtin_bit_cast(
+          V, __builtin_amdgcn_raw_buffer_load_b128(r, xo[b] + yo, so, 0));
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[b * VEC + k] = t[k];
+    }
+  }
+  __device__ __forceinline__ typename VecOf<T, VEC>::type filter(const Taps<T> &tx) const {
+    typename VecOf<T, VEC>::type res;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      T acc = tx.w[0] * v[NBH * VEC + k - R];
+#pragma unroll
+      for (int t = 1; t < NT; ++t) acc += tx.w[t] * v[NBH * VEC + k - R + t];
+      res[k] = acc;
+    }
+    return res;
+  }
+};
+
 template <typename T, int VEC, int NT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
     const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
-    Taps<T> tz, Taps<T> ty, Taps<T> tx, int lxb, int tyr, int ntx, int nty,
-    int zchunk) {
+    Taps<T> tz, Taps<T> ty, Taps<T> tx, int lxb, int ntx, int nty, int zchunk) {
   typedef typename VecOf<T, VEC>::type V;
+  typedef XWindow<T, VEC, NT> W;
   constexpr int R = NT / 2;
-  constexpr int NBH = (R + VEC - 1) / VEC;   // vectors on each side in x
-  constexpr int NB = 2 * NBH + 1;
+  constexpr int NB = W::NB, NBH = W::NBH;
   constexpr int NT_THREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
+  const int tyr = NT_THREADS / lxb;            // rows of the tile = rows of lanes
   const int frows = tyr + 2 * R;               // footprint rows
   const int rowlen = lxb * VEC;
   const int tid = threadIdx.x;
   const int row = tid / lxb;
   const int lx = tid - row * lxb;
-  const bool active = row < tyr;
   int bid = blockIdx.x;
   const int bx = bid % ntx; bid /= ntx;
   const int by = bid % nty;
   const int bz = bid / nty;
-  const int64_t nxv = nx / VEC;
-  const int64_t xv = (int64_t)bx * lxb + lx;           // own vector along x
+  const int nxv = (int)(nx / VEC);
+  const int xv = bx * lxb + lx;                        // own vector along x
   const int64_t y0 = (int64_t)by * tyr;
-  const bool xin = xv < nxv;
-  const bool owner = active && xin && (y0 + row < ny);
-  // wrapped vector offsets of the x window (loop invariant)
-  int64_t xoff[NB];
+  const bool owner = xv < nxv && (y0 + row < ny);
+  const uint32_t plane_bytes = (uint32_t)(ny * nx * sizeof(T));
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T *>(x), 0, (uint32_t)(nz * plane_bytes), 0x00020000);
+  // wrapped byte offsets of the x window (loop invariant)
+  uint32_t xo[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    int64_t j = (xv + b - NBH) % nxv;
+    int j = (xv + b - NBH) % nxv;
     if (j < 0) j += nxv;
-    xoff[b] = j * VEC;
+    xo[b] = (uint32_t)j * (uint32_t)(VEC * sizeof(T));
   }
-  // rows this lane filters along x: footprint row `row` (always) and footprint
-  // row tyr + row (the halo round, lanes with row < 2R)
-  const bool second = active && row < 2 * R;
-  int64_t yoff[2];
+  // footprint rows this lane filters along x: `row` (round 0) and `tyr + row`
+  // (round 1: the 2R halo rows, the first waves of the workgroup)
+  const bool second = row < 2 * R;
+  const bool second_wave = __builtin_amdgcn_readfirstlane((int)second) != 0;
+  uint32_t yo[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     int64_t yy = (y0 - R + row + (int64_t)q * tyr) % ny;
     if (yy < 0) yy += ny;
-    yoff[q] = yy * nx;
+    yo[q] = (uint32_t)(yy * nx * sizeof(T));
   }
+  if (!second) yo[1] = kNoLane;                // lanes of a mixed wave: no access
   const int64_t zbeg = (int64_t)bz * zchunk;
   int64_t zend = zbeg + zchunk;
   if (zend > nz) zend = nz;
-  int64_t zw = (zbeg - R) % nz;
-  if (zw < 0) zw += nz;
-  V ring[NT];
+  int zw = (int)((zbeg - R) % nz);             // plane the x pass reads
+  if (zw < 0) zw += (int)nz;
+  V ring[NT - 1];                              // xy-filtered planes, oldest first
 #pragma unroll
-  for (int t = 0; t < NT; ++t) ring[t] = V(T(0));
-  const int64_t nsteps = (zend - zbeg) + 2 * R;
-  // one plane: x pass -> LDS -> y pass; returns the xy-filtered vector of this lane
-  auto plane_xy = [&](int64_t st) {
+  for (int t = 0; t + 1 < NT; ++t) ring[t] = V(T(0));
+  const int nsteps = (int)(zend - zbeg) + 2 * R;
+  const uint32_t own_off =
+      (uint32_t)((y0 + row) * nx * sizeof(T)) + (uint32_t)xv * (uint32_t)(VEC * sizeof(T));
+  const rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(nz * plane_bytes),
+                                                      0x00020000);
+  // (A window with compile-time slots -- the step loop unrolled NT times -- is no
+  // faster at 13 taps and spills from 15 taps on.)
+#pragma unroll 1
+  for (int st = 0; st < nsteps; ++st) {
     T *buf = smem + (size_t)(st & 1) * frows * rowlen;
-    const T *plane = x + zw * ny * nx;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q == 0 ? active : second) {
-        T win[NB * VEC];
-        const T *rp = plane + yoff[q];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const V v = *reinterpret_cast<const V *>(rp + xoff[b]);
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) win[b * VEC + k] = v[k];
-        }
-        V res;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          T acc = tx.w[0] * win[NBH * VEC + k - R];
-#pragma unroll
-          for (int t = 1; t < NT; ++t) acc += tx.w[t] * win[NBH * VEC + k - R + t];
-          res[k] = acc;
-        }
-        *reinterpret_cast<V *>(buf + (size_t)(row + q * tyr) * rowlen + lx * VEC) = res;
-      }
+    const uint32_t so = (uint32_t)zw * plane_bytes;
+    {
+      W w;
+      w.load(rs, xo, yo[0], so);
+      *reinterpret_cast<V *>(buf + (size_t)row * rowlen + lx * VEC) = w.filter(tx);
     }
+    if (second_wave) {
+      W w;
+      w.load(rs, xo, yo[1], so);
+      const V r1 = w.filter(tx);
+      if (second) *reinterpret_cast<V *>(buf + (size_t)(row + tyr) * rowlen + lx * VEC) = r1;
+    }
+    if (++zw == (int)nz) zw = 0;
     __syncthreads();
-    V v = V(T(0));
-    if (active) {
-      const T *col = buf + (size_t)row * rowlen + lx * VEC;
-      v = ty.w[0] * *reinterpret_cast<const V *>(col);
+    const T *col = buf + (size_t)row * rowlen + lx * VEC;
+    V v = ty.w[0] * *reinterpret_cast<const V *>(col);
 #pragma unroll
-      for (int t = 1; t < NT; ++t)
-        v += ty.w[t] * *reinterpret_cast<const V *>(col + (size_t)t * rowlen);
-    }
-    if (++zw == nz) zw = 0;
-    return v;
-  };
-  // z pass: shift the window, emit the plane R behind.  (A ring with compile-time
-  // slots -- the step loop unrolled NT times -- is no faster at 13 taps and
-  // spills from 15 taps on.)
-  for (int64_t st = 0; st < nsteps; ++st) {
-    const V v = plane_xy(st);
-#pragma unroll
-    for (int t = 0; t + 1 < NT; ++t) ring[t] = ring[t + 1];
-    ring[NT - 1] = v;
+    for (int t = 1; t < NT; ++t)
+      v += ty.w[t] * *reinterpret_cast<const V *>(col + (size_t)t * rowlen);
+    // z pass over the NT - 1 planes in the window and the new one; the window
+    // then moves on by one plane
     if (st >= 2 * R && owner) {
       V acc = tz.w[0] * ring[0];
 #pragma unroll
-      for (int t = 1; t < NT; ++t) acc += tz.w[t] * ring[t];
-      const int64_t z = zbeg + (st - 2 * R);
-      *reinterpret_cast<V *>(out + (z * ny + (y0 + row)) * nx + xv * VEC) = acc;
+      for (int t = 1; t + 1 < NT; ++t) acc += tz.w[t] * ring[t];
+      acc += tz.w[NT - 1] * v;
+      const uint32_t z = (uint32_t)(zbeg + (st - 2 * R));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), ws,
+                                             own_off + z * plane_bytes, 0, 0);
+      asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
     }
+#pragma unroll
+    for (int t = 0; t + 2 < NT; ++t) ring[t] = ring[t + 1];
+    ring[NT - 2] = v;
   }
 }
 
@@ -423,6 +480,7 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   while (lxb > 8 && lxb / 2 >= nxv) lxb /= 2;
   const int tyr = (NW * 64) / lxb;
   if (tyr < 2 * R) return -2;
+  if ((uint64_t)nz * ny * nx * sizeof(T) > kBlur3MaxBytes) return -2;   // 32-bit offsets
   const int64_t ntx = (nxv + lxb - 1) / lxb;
   const int64_t nty = (ny + tyr - 1) / tyr;
   // z chunks: enough workgroups for the chip, each long enough to amortise the
@@ -444,7 +502,7 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
     if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds, st, x, out, nz,
-                     ny, nx, tz, ty, tx, lxb, tyr, (int)ntx, (int)nty, (int)zchunk);
+                     ny, nx, tz, ty, tx, lxb, (int)ntx, (int)nty, (int)zchunk);
   return launch_status();
 }
 
@@ -458,7 +516,7 @@ int corr3_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
     return NSOL_EINVAL;
   constexpr int VEC = 16 / sizeof(T);
   // longer windows do not pay (the z window alone is ntaps vectors per lane)
-  constexpr int kMaxFused = 15;   // 17 taps: no faster than three passes (measured)
+  constexpr int kMaxFused = 17;   // 0.60 ms against 0.65 for three passes at 512^3; spills beyond
   if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > kMaxFused || nx % VEC != 0 ||
       (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return -2;
