@@ -36,6 +36,28 @@ def test_library_builds_loads_and_exports_declared_symbols():
         assert name in decl
 
 
+def test_every_tuning_knob_named_in_python_exists_in_the_library():
+    """tools/, bench and tests set kernel parameters by name; a knob that was
+    removed from the HIP sources must not linger in a script."""
+    import glob
+    import re
+    csrc = "".join(open(f).read() for f in
+                   glob.glob(os.path.join(ROOT, "nsol_amd", "csrc", "*.hip")))
+    names = set()
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__")]
+        for f in files:
+            if f.endswith(".py"):
+                names.update(re.findall(r'set_param\("([a-z0-9_]+)"',
+                                        open(os.path.join(dirpath, f)).read()))
+    assert len(names) > 10
+    missing = sorted(n for n in names if '"%s"' % n not in csrc)
+    assert not missing, missing
+    from nsol_amd import _lib
+    with pytest.raises(ValueError):
+        _lib.set_param("pdk_" + "no_such_knob", 1)
+
+
 def test_product_does_not_import_the_oracle():
     import re
     pkg = os.path.join(ROOT, "nsol_amd")
