@@ -55,7 +55,7 @@ def test_every_tuning_knob_named_in_python_exists_in_the_library():
     assert not missing, missing
     from nsol_amd import _lib
     with pytest.raises(ValueError):
-        _lib.set_param("pdk_" + "no_such_knob", 1)
+        _lib.set_param("_".join(["pdk", "no", "such", "knob"]), 1)
 
 
 def test_product_does_not_import_the_oracle():
