@@ -99,7 +99,10 @@ def main():
                          "configuration instead of tuning (profiling passes)")
     ap.add_argument("--verbose-tuning", action="store_true",
                     help="print the online tuner's decision (stderr)")
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="edge length of the volume the CPU baseline is timed "
+                         "on (0 = the benchmark's own size: about 20 s of CPU "
+                         "work at 512^3)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo only to rehearse N > 1 on a box with fewer "
                          "GPUs than ranks (collectives then go through host "
@@ -311,7 +314,7 @@ def main():
                 "single_pass_reference": single},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sn = args.cpu_sample
+            sn = args.cpu_sample or n
             its = cpu_baseline(sn, 2)
             out["cpu_baseline"] = {
                 "value": its * (sn ** 3) / float(nvox),
@@ -319,8 +322,9 @@ def main():
                 "host_cores_available": os.cpu_count(),
                 "sample": "oracle pd_tvl2_refstyle (NumPy float64 + "
                           "scipy.ndimage, reference op sequence), %d^3 "
-                          "volume, 2 iterations after 1 warm-up, scaled by "
-                          "voxel count to %d^3" % (sn, n)}
+                          "volume, 2 iterations after 1 warm-up%s" %
+                          (sn, "" if sn == n else
+                           ", scaled by voxel count to %d^3" % n)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
