@@ -279,6 +279,10 @@ int nsol_pd_fusedk_iter_f64(const double *xbar_in, double *xbar_out,
  * for the life of the process.  Returns 1 once a shape has settled, 0 while it
  * is still exploring, -1 if the shape has not been seen. */
 int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx);
+/* Number of k_pd_fusedk launches of depth k (2 or 3) this process has made
+ * (any entry point, any shape); -1 for another k.  For tests and tools that
+ * must know which kernel a run went through. */
+int nsol_pd_fusedk_launches(int k);
 /* The settled configuration (waves per workgroup, tiles along x, z-chunk);
  * NSOL_EINVAL while the shape is unknown or still exploring. */
 int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,

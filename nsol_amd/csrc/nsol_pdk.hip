@@ -41,6 +41,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -66,6 +67,9 @@ struct StageScalars {
   T sigma[K], hden[K], tau[K], tl[K], optl[K], theta[K];
   int has_p;
 };
+
+// launches of k_pd_fusedk so far, [0]: K = 2, [1]: K = 3 (tests ask which kernel ran)
+std::atomic<int> g_launches[2];
 
 struct Tiling {
   int lxb;    // lanes per footprint row
@@ -759,6 +763,7 @@ int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x
   hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1, PF2, UNIT>),
                      dim3((unsigned)blocks), dim3(NW * 64), 0, st, xbar_in, xbar_out,
                      x_in, x_out, bt, p_in, p_out, G, S, Q, (int)c.zchunk, (int)slab);
+  g_launches[K == 3 ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
   return launch_status();
 }
 
@@ -1111,6 +1116,11 @@ int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t n
   if (it == nsol_pdk::g_plans.end()) return -1;
   nsol_pdk::plan_poll(it->second, k);
   return it->second.chosen >= 0 ? 1 : 0;
+}
+
+int nsol_pd_fusedk_launches(int k) {
+  if (k != 2 && k != 3) return -1;
+  return nsol_pdk::g_launches[k - 2].load(std::memory_order_relaxed);
 }
 
 int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,

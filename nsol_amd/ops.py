@@ -349,6 +349,11 @@ def pd_fusedk_tuned(x, shape, k=3):
                                                 nz, ny, nx))
 
 
+def pd_fusedk_launches(k=3):
+    """k_pd_fusedk launches of depth k made by this process so far."""
+    return int(_lib.load().nsol_pd_fusedk_launches(int(k)))
+
+
 def pd_fusedk_plan(x, shape, k=3):
     """(waves, tiles along x, z-chunk) the online tuner settled on, or None."""
     import ctypes

@@ -832,20 +832,34 @@ def test_k_iterations_per_pass_is_bit_identical(nsol, shape, dtype, iters, nw):
         for cfg in (dict(), dict(pdk_ntx=2, pdk_zchunk=4)):
             cfg = dict(dict(pdk_enable=1, pdk_nw=nw), **cfg)
             a = _run_pd_raw(shape, dtype, iters, flags, enable2=0, w=w[::-1])
+            before = ops.pd_fusedk_launches(3)
             b = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg,
                             w=w[::-1])
+            # (a forced tiling may not fit a shape; the library then falls back)
+            assert "pdk_ntx" in cfg or \
+                ops.pd_fusedk_launches(3) == before + iters // 3, \
+                "the depth-3 kernel did not run"
             for u, v in zip(a[:3], b[:3]):
                 assert torch.equal(u, v), (shape, cfg, flags, "w swapped")
         ref = _run_pd_raw(shape, dtype, iters, flags, enable2=0, w=w)
+        forced_ran = 0
         for cfg in (dict(), dict(pdk_zchunk=5), dict(pdk_ntx=1),
                     dict(pdk_ntx=2, pdk_zchunk=4), dict(pdk_ntx=3),
                     dict(pdk_kmax=2), dict(pdk_kmax=2, pdk_ntx=2, pdk_zchunk=3),
                     dict(pdk_kmax=2, pdk_nw=16), dict(pdk_nw=0)):
             cfg = dict(dict(pdk_enable=1, pdk_nw=nw), **cfg)
+            depth = cfg.get("pdk_kmax", 3)
+            before = ops.pd_fusedk_launches(depth)
             got = _run_pd_raw(shape, dtype, iters, flags, enable2=0, pdk=cfg,
                               w=w)
+            ran = ops.pd_fusedk_launches(depth) >= before + iters // 3
+            assert ran or "pdk_ntx" in cfg, ("k_pd_fusedk did not run", cfg)
+            forced_ran += int(ran and "pdk_ntx" in cfg)
             for a, b in zip(ref[:3], got[:3]):
                 assert torch.equal(a, b), (shape, cfg, flags)
+        # (rows of more than 4 KiB need more than the three tiles forced above)
+        assert forced_ran >= 1 or shape[2] * np.dtype(dtype).itemsize > 4096, \
+            "no forced tiling fitted this shape"
 
 
 @pytest.mark.parametrize("shape", [(200, 333, 640), (97, 1030, 512),
@@ -976,8 +990,10 @@ def test_full_size_512_properties(nsol):
         assert torch.equal(u, v)
     del a
     torch.cuda.empty_cache()
+    before = _ops.pd_fusedk_launches(3)
     a = _run_pd_raw(shape, np.float32, 5, flags, enable2=1,
                     pdk=dict(pdk_enable=1))                      # 3 + 2 (default)
+    assert _ops.pd_fusedk_launches(3) == before + 1
     for u, v in zip(a[:3], b[:3]):
         assert torch.equal(u, v)
     del a
@@ -985,6 +1001,43 @@ def test_full_size_512_properties(nsol):
     c = _run_pd_raw(shape, np.float32, 5, flags, enable2=0, two_pass=1)
     for u, v in zip(b[:3], c[:3]):
         assert torch.equal(u, v)
+
+
+def test_more_than_two_to_the_31_voxels(nsol):
+    """A volume whose voxel count does not fit 32 bits (1040 x 1440 x 1440 =
+    2.16e9 voxels, 8.6 GB per float32 field, 95 GB of solver state): the
+    three-iterations-per-pass kernel, the two-iteration kernel and the
+    one-iteration kernel still agree bit for bit, and grad / grad_adj are
+    still adjoint -- i.e. no index anywhere is computed in 32 bits."""
+    import torch
+    from nsol_amd import ops
+    if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
+        pytest.skip("needs about 140 GB of device memory")
+    shape = (1040, 1440, 1440)
+    n = int(np.prod(shape))
+    assert n > 2 ** 31
+    flags = ops.PD_REG_TV | ops.PD_DATA_L2
+    w = (1.0, 1.0, 1.0)
+    before = ops.pd_fusedk_launches(3)
+    a = _run_pd_raw(shape, np.float32, 5, flags, enable2=1,
+                    pdk=dict(pdk_enable=1), w=w)                 # 3 + 2
+    assert ops.pd_fusedk_launches(3) == before + 1
+    ax, ap = a[0], a[2]
+    del a
+    torch.cuda.empty_cache()
+    b = _run_pd_raw(shape, np.float32, 5, flags, enable2=0, w=w)  # 5 x 1
+    assert torch.equal(ax, b[0])
+    assert torch.equal(ap, b[2])
+    assert bool(torch.isfinite(ax[-4096:]).all())
+    assert float(ax[-4096:].abs().max()) > 0       # the far end was written
+    del ax, ap, b
+    torch.cuda.empty_cache()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(n, device="cuda", dtype=torch.float32, generator=gen)
+    p = torch.rand(3 * n, device="cuda", dtype=torch.float32, generator=gen)
+    lhs = ops.dot(ops.grad(x, shape, w), p)
+    rhs = ops.dot(x, ops.grad_adj(p, shape, w))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
 
 
 def test_mid_size_parity_vs_oracle(nsol):
