@@ -1038,6 +1038,28 @@ def test_more_than_two_to_the_31_voxels(nsol):
     lhs = ops.dot(ops.grad(x, shape, w), p)
     rhs = ops.dot(x, ops.grad_adj(p, shape, w))
     assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    # the periodic Gaussian blur (sigma = 2) is symmetric: <Ax, y> = <x, Ay>.
+    # The one-pass kernel addresses with 32-bit byte offsets and must decline
+    # a volume of 8.6 GB; the three per-axis passes take over.
+    import nsol_amd.kernels as K
+    taps = K.Kernels1D().get_gaussian(4.0)
+    y = p[:n]
+
+    def blur(v):
+        assert ops.corr3_wrap(v, shape, taps, taps, taps) is None
+        for axis in (0, 1, 2):
+            v = ops.corr_axis(v, shape, axis, taps, taps.size // 2, "wrap")
+        return v
+
+    lhs = ops.dot(blur(x), y)
+    rhs = ops.dot(x, blur(y))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    # a constant stays constant under a normalised periodic blur, also at the
+    # far end of the volume
+    ones = torch.ones(n, device="cuda", dtype=torch.float32)
+    b1 = blur(ones)
+    assert float((b1[-65536:] - 1).abs().max()) < 1e-5
+    assert float((b1[:65536] - 1).abs().max()) < 1e-5
 
 
 def test_mid_size_parity_vs_oracle(nsol):
