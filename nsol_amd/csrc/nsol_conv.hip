@@ -382,6 +382,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
   const int tid = threadIdx.x;
   const int row = tid / lxb;
   const int lx = tid - row * lxb;
+  // (Plain tile order, x fastest: giving every XCD a contiguous run of tiles so
+  // that shared halo lines meet in one L2 is slower here, 0.472 vs 0.456 ms.)
   int bid = blockIdx.x;
   const int bx = bid % ntx; bid /= ntx;
   const int by = bid % nty;
