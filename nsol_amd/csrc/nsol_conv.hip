@@ -210,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
   }
 }
 
+int g_blur3_zchunk = 0; // planes per z chunk of the one-pass blur; 0 = by the round model
 int g_blur3_lxb = 16;   // lanes per row of the one-pass blur's tile (experiment knob)
 int g_corr_ra = 8;   // outputs per lane along a strided axis (experiment knob)
 int g_corr_xv = 1;   // output vectors per lane in the x pass (experiment knob)
@@ -298,7 +299,7 @@ int try_launch_wrap(const T *x, T *out, int axis, int64_t nz, int64_t ny,
 //   z pass  the xy-filtered values of the last NT - 1 planes live in registers
 //           (a shifting window); once it is full every new plane yields one
 //           output plane R planes behind.
-// What bounds it (512^3, 13 taps, 0.45 ms = 2.4 TB/s of the 8 B per voxel; switches
+// What bounds it (512^3, 13 taps, 0.42-0.43 ms = 2.5 TB/s of the 8 B per voxel; switches
 // compiled in for the measurement): loads and stores alone take 0.31 ms, the
 // arithmetic alone 0.17 ms, and the two do not overlap -- one 16-wave workgroup
 // per CU (the z window is 48 registers per lane) runs its phases in lock step.
@@ -470,6 +471,19 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
   }
 }
 
+inline int blur3_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <typename T, int VEC, int NT>
 int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                  const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
@@ -485,12 +499,21 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   if ((uint64_t)nz * ny * nx * sizeof(T) > kBlur3MaxBytes) return -2;   // 32-bit offsets
   const int64_t ntx = (nxv + lxb - 1) / lxb;
   const int64_t nty = (ny + tyr - 1) / tyr;
-  // z chunks: enough workgroups for the chip, each long enough to amortise the
-  // 2R extra planes
-  int64_t zchunk = nz;
-  const int64_t want = 2 * 256;
-  while (ntx * nty * ((nz + zchunk - 1) / zchunk) < want && zchunk > 8 * R)
-    zchunk = (zchunk + 1) / 2;
+  // z chunks: one 16-wave workgroup runs per CU, so a launch takes
+  // ceil(workgroups / CUs) rounds of (chunk + 2R) plane steps; take the chunk
+  // count that minimises that (512^3, 64 tiles: 4 chunks = 256 workgroups = one
+  // round of 140 steps, 0.418 ms; 8 chunks = two rounds of 76, 0.444 ms)
+  const int64_t cus = blur3_cu_count();
+  int64_t zchunk = nz, best = -1;
+  for (int64_t c = 1; c <= nz && (nz + c - 1) / c >= R; ++c) {
+    const int64_t len = (nz + c - 1) / c;
+    const int64_t chunks = (nz + len - 1) / len;
+    const int64_t rounds = (ntx * nty * chunks + cus - 1) / cus;
+    const int64_t cost = rounds * (len + 2 * R);
+    if (best < 0 || cost < best) { best = cost; zchunk = len; }
+    if (ntx * nty * chunks >= 64 * cus) break;
+  }
+  if (g_blur3_zchunk > 0) zchunk = g_blur3_zchunk < nz ? g_blur3_zchunk : nz;
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t blocks = ntx * nty * nzc;
   if (blocks > 0x7fffffff) return -2;
@@ -582,6 +605,7 @@ int nsol_hip_set_param_conv(const char *name, int value) {
   if (!strcmp(name, "corr_ra")) g_corr_ra = value;
   else if (!strcmp(name, "corr_xv")) g_corr_xv = value;
   else if (!strcmp(name, "corr_blur3_lxb")) g_blur3_lxb = value;
+  else if (!strcmp(name, "corr_blur3_zchunk")) g_blur3_zchunk = value;
   else return NSOL_EINVAL;
   return 0;
 }

@@ -33,11 +33,12 @@ for ra, xvv in ((4, 1), (8, 1), (8, 2)):
 _lib.set_param("corr_ra", 8)
 _lib.set_param("corr_xv", 1)
 ref = None
-cfgs = (16, 8, 32)
+cfgs = ((16, 0), (16, 64), (16, 171), (32, 0), (8, 0))
 times = {c: [] for c in cfgs}
 for rnd in range(4):                      # interleaved: boxes drift
-    for lxb in cfgs:
+    for lxb, want in cfgs:  # want = forced z-chunk, 0 = model
         _lib.set_param("corr_blur3_lxb", lxb)
+        _lib.set_param("corr_blur3_zchunk", want)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
@@ -45,17 +46,18 @@ for rnd in range(4):                      # interleaved: boxes drift
                 raise SystemExit("one-pass kernel does not apply")
         e1.record(); torch.cuda.synchronize()
         if rnd > 0:
-            times[lxb].append(e0.elapsed_time(e1) / 10)
+            times[(lxb, want)].append(e0.elapsed_time(e1) / 10)
         if ref is None:
             ref = out.clone()
         assert float((out - ref).abs().max()) == 0.0
-for lxb, ts in times.items():
+for (lxb, want), ts in times.items():
     ms = float(np.median(ts))
-    print(json.dumps({"kernel": "corr3_wrap", "taps": len(taps), "lanes_per_row": lxb,
+    print(json.dumps({"kernel": "corr3_wrap", "taps": len(taps), "lanes_per_row": lxb, "zchunk": want,
                       "ms": round(ms, 4),
                       "min_ms": round(float(np.min(ts)), 4),
                       "GBps_algorithmic": round(8.0 * n ** 3 / ms / 1e6, 1)}), flush=True)
 _lib.set_param("corr_blur3_lxb", 16)
+_lib.set_param("corr_blur3_zchunk", 0)
 # against the three-pass path
 _lib.set_param("corr_ra", 8)
 o3 = x
