@@ -406,6 +406,21 @@ int nsol_lsmr_hx_update_f64(double *hbar, double *x, double *h,
                             double c_x, double c_h, double c_v, double *result,
                             double *ws, void *stream);
 
+/* The first-order Tikhonov regulariser's share of the robust-loss objective
+ * (tikhonov_linear_solver.py:201-208, :229-236 with B = gradient, B_adj its
+ * adjoint): grad = g + alpha * K^T(K x) and result[0] = sum |K x|^2 in one pass
+ * over x instead of nsol_grad_*, nsol_dot_*, nsol_grad_adj_*, nsol_lincomb2_*
+ * (grad is bit-identical to theirs).  g may alias grad; x may not.
+ * ws: nsol_hip_reduce_ws_doubles() doubles. */
+int nsol_tk1_reg_cost_grad_f32(const float *x, const float *g, float *grad, int ndim,
+                               int64_t nz, int64_t ny, int64_t nx, double wx,
+                               double wy, double wz, double alpha, double *result,
+                               double *ws, void *stream);
+int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
+                               int ndim, int64_t nz, int64_t ny, int64_t nx,
+                               double wx, double wy, double wz, double alpha,
+                               double *result, double *ws, void *stream);
+
 /* ---------------------------------------------------------------------- *
  * Pair statistics for the evaluation measures of similarity_measures.py:26-120
  * (SSD, MAE, MSE, RMSE, PSNR, NCC).  result: device double[8] =

@@ -228,6 +228,70 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_hx(T *__restrict__ hbar,
   store_partial(acc, ws);
 }
 
+// grad = g + alpha * K^T(K x) and sum |K x|^2 in one pass over x (K = gradient
+// with zero padding): the regulariser's share of cost and gradient of the
+// robust-loss objective (tikhonov_linear_solver.py:201-208 with B = grad).
+// Every difference is rounded as k_grad stores it and combined in the order of
+// k_grad_adj and nsol_lincomb2, so grad equals the three-kernel result bit for bit.
+template <typename T, int VEC, int ROWS>
+__global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
+                                                     const T *g, T *grad, Geom<T> G,
+                                                     T alpha, double *ws) {
+  const int64_t nrg = row_groups<T, ROWS>(G);
+  double acc = 0.0;
+  for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
+    const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
+    if (!c.ok) continue;
+    T v[VEC], nb[VEC], d[VEC], dp[VEC], out[VEC];
+    vload<T, VEC>(x + c.i, v);
+    // x: forward differences at the lane's voxels and at the voxel to the left
+    const T right = (c.ix + VEC < G.nx) ? x[c.i + VEC] : T(0);
+    fwd_diff_x<T, VEC>(v, right, G.wx, d);
+    const T dleft = (c.ix > 0) ? v[0] * G.wx + x[c.i - 1] * (-G.wx) : T(0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const T l = (k > 0) ? d[(k + VEC - 1) % VEC] : dleft;
+      out[k] = d[k] * (-G.wx) + l * G.wx;
+      acc += (double)d[k] * (double)d[k];
+    }
+    if (G.ndim >= 2) {
+      vzero(nb);
+      if (c.iy + 1 < G.ny) vload<T, VEC>(x + c.i + G.sy, nb);
+      fwd_diff<T, VEC>(v, nb, G.wy, d);
+      vzero(dp);
+      if (c.iy > 0) {
+        vload<T, VEC>(x + c.i - G.sy, nb);
+        fwd_diff<T, VEC>(nb, v, G.wy, dp);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        out[k] += d[k] * (-G.wy) + dp[k] * G.wy;
+        acc += (double)d[k] * (double)d[k];
+      }
+    }
+    if (G.ndim >= 3) {
+      vzero(nb);
+      if (c.iz + 1 < G.nz) vload<T, VEC>(x + c.i + G.sz, nb);
+      fwd_diff<T, VEC>(v, nb, G.wz, d);
+      vzero(dp);
+      if (c.iz > 0) {
+        vload<T, VEC>(x + c.i - G.sz, nb);
+        fwd_diff<T, VEC>(nb, v, G.wz, dp);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        out[k] += d[k] * (-G.wz) + dp[k] * G.wz;
+        acc += (double)d[k] * (double)d[k];
+      }
+    }
+    vload<T, VEC>(g + c.i, nb);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) out[k] = T(1) * nb[k] + alpha * out[k];
+    vstore<T, VEC>(grad + c.i, out);
+  }
+  store_partial3(acc, ws);
+}
+
 inline int rgrid(int64_t n) {
   int g = grid_for(n);
   return g > kReducePartials ? kReducePartials : g;
@@ -304,6 +368,25 @@ int hx_impl(T *hbar, T *x, T *h, const T *v, int64_t n, double c_hbar,
   return launch_status();
 }
 
+template <typename T>
+int tk1_reg_impl(const T *x, const T *g, T *grad, int ndim, int64_t nz, int64_t ny,
+                 int64_t nx, double wx, double wy, double wz, double alpha,
+                 double *result, double *ws, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !g || !grad || !result || !ws || x == grad) return NSOL_EINVAL;
+  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  const bool al = ptr16(x) && ptr16(g) && ptr16(grad) && G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
+    hipLaunchKernelGGL((k_tk1_reg<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), x, g, grad, G, (T)alpha, ws);
+    hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
+                       nb, result);
+    return launch_status();
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -332,4 +415,18 @@ extern "C" {
   }
 NSOL_LSMR_DEF(float, f32)
 NSOL_LSMR_DEF(double, f64)
+int nsol_tk1_reg_cost_grad_f32(const float *x, const float *g, float *grad, int ndim,
+                               int64_t nz, int64_t ny, int64_t nx, double wx,
+                               double wy, double wz, double alpha, double *result,
+                               double *ws, void *stream) {
+  return tk1_reg_impl<float>(x, g, grad, ndim, nz, ny, nx, wx, wy, wz, alpha, result,
+                             ws, stream);
+}
+int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
+                               int ndim, int64_t nz, int64_t ny, int64_t nx,
+                               double wx, double wy, double wz, double alpha,
+                               double *result, double *ws, void *stream) {
+  return tk1_reg_impl<double>(x, g, grad, ndim, nz, ny, nx, wx, wy, wz, alpha, result,
+                              ws, stream);
+}
 }

@@ -239,6 +239,21 @@ def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None):
     return float(res.item()), g
 
 
+def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None):
+    """(sum |grad x|^2, g + alpha * grad_adj(grad x)) in one pass over x
+    (the regulariser's share of tikhonov_linear_solver.py:201-208 with
+    B = gradient).  out may be g."""
+    _chk(x), _chk(g)
+    ndim, nz, ny, nx = dims3(shape)
+    if out is None:
+        out = empty_like(g)
+    ws, res = _workspace(x.device)
+    _lib.check(_fn("tk1_reg_cost_grad", x)(
+        _p(x), _p(g), _p(out), ndim, nz, ny, nx, w[0], w[1], w[2], float(alpha),
+        _p(res), _p(ws), stream_ptr()), "nsol_tk1_reg_cost_grad")
+    return float(res.item()), out
+
+
 _ws8 = {}
 
 

@@ -33,6 +33,9 @@ USE_FUSED_LSMR = True
 # algorithm and defaults as SciPy's, iterates agree to rounding); False = SciPy's
 # host driver with GPU-evaluated cost / gradient
 USE_DEVICE_LBFGSB = True
+# robust-loss objective with B = gradient: 1/2||Bx||^2 and B_adj(Bx) from one
+# pass over x (nsol_tk1_reg_cost_grad_*); False = grad, dot, grad_adj, lincomb2
+USE_FUSED_TK1_REG = True
 
 
 class TikhonovLinearSolver(LinearSolver):
@@ -223,17 +226,43 @@ class TikhonovLinearSolver(LinearSolver):
         alpha = self._alpha
         loss, fscale = self._data_loss, self._data_loss_scale
 
+        native = self._native_gradient(b.numel()) \
+            if use_reg and USE_FUSED_TK1_REG else None
+
         def fun_and_grad(x):
             r = ops.lincomb2(1.0, A(x), -1.0, b)
             cost, g = ops.loss_cost_grad(r, loss, fscale, out=r)
             grad = A_adj(g)
-            if use_reg:
+            if native is not None:
+                # B = gradient, B_adj its adjoint: 1/2||Bx||^2 and B_adj(Bx)
+                # from one pass over x (same values as the branch below)
+                shape, w = native
+                e, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
+                                                out=grad)
+                cost = cost + alpha * (0.5 * e)
+            elif use_reg:
                 Bx = B(x)
                 # reference quirk kept: 1/2||Bx||^2, b_reg is ignored here
                 cost = cost + alpha * (0.5 * ops.dot(Bx, Bx))
                 grad = ops.lincomb2(1.0, grad, alpha, B_adj(Bx))
             return cost, grad
         return fun_and_grad
+
+    def _native_gradient(self, n):
+        """(shape, inverse spacings) when B / B_adj are nsol_amd's gradient
+        and its adjoint on an n-voxel volume; None otherwise."""
+        dB = trace_operator(self._B, n)
+        if dB is None or dB[0] != "grad":
+            return None
+        gop, shape = dB[1], tuple(dB[2])
+        if len(shape) != gop.dimension or int(np.prod(shape)) != n:
+            return None
+        dBt = trace_operator(self._B_adj, gop.dimension * n)
+        if dBt is None or dBt[0] != "grad_adj" or \
+                tuple(dBt[1].w) != tuple(gop.w) or \
+                dBt[1].dimension != gop.dimension:
+            return None
+        return shape, gop.w
 
     def _run_minimize(self, x0):
         if self._minimizer == "L-BFGS-B" and USE_DEVICE_LBFGSB:

@@ -1003,6 +1003,35 @@ def test_full_size_512_properties(nsol):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("shape", [(1000,), (7,), (33, 20), (64, 256),
+                                   (7, 10, 13), (24, 20, 64), (5, 3, 260),
+                                   (1, 1, 8), (2, 1, 4), (40, 33, 132)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_tk1_regulariser_is_bit_identical(nsol, shape, dtype):
+    """nsol_tk1_reg_cost_grad_* (one pass) against grad -> dot -> grad_adj ->
+    lincomb2, the robust-loss objective's regulariser branch
+    (tikhonov_linear_solver.py:201-208): the gradient bit for bit, the energy
+    to summation order; in place as well."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    g = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    w = (1.0, 0.5, 2.0)
+    alpha = 0.37
+    Bx = ops.grad(x, shape, w)
+    e_ref = ops.dot(Bx, Bx)
+    ref = ops.lincomb2(1.0, g, alpha, ops.grad_adj(Bx, shape, w))
+    e, got = ops.tk1_reg_cost_grad(x, g, shape, w, alpha)
+    assert torch.equal(got, ref)
+    assert abs(e - e_ref) <= 1e-12 * abs(e_ref)
+    g2 = g.clone()
+    e2, got2 = ops.tk1_reg_cost_grad(x, g2, shape, w, alpha, out=g2)
+    assert got2 is g2 and torch.equal(g2, ref) and e2 == e
+
+
 def test_more_than_two_to_the_31_voxels(nsol):
     """A volume whose voxel count does not fit 32 bits (1040 x 1440 x 1440 =
     2.16e9 voxels, 8.6 GB per float32 field, 95 GB of solver state): the
