@@ -472,6 +472,15 @@ int nsol_lb_mdots_f32(const float *const *vecs, int nvec, const float *y,
 int nsol_lb_mdots_f64(const double *const *vecs, int nvec, const double *y,
                       const int8_t *iwhere, int64_t n, double *result, double *ws,
                       void *stream);
+/* diff_dots: out = a - b, result[0] = sum out^2, result[1] = sum out * c (0 when c
+ * is NULL) in one pass: the line search's d = z - x with d'd and g'd, and the BFGS
+ * pair y = g - g_old with y'y (scipy lbfgsb.f lnsrlb / matupd behind
+ * tikhonov_linear_solver.py:214-220).  ws: 4 * 1024 doubles. */
+int nsol_lb_diff_dots_f32(const float *a, const float *b, const float *c, float *out,
+                          int64_t n, double *result, double *ws, void *stream);
+int nsol_lb_diff_dots_f64(const double *a, const double *b, const double *c,
+                          double *out, int64_t n, double *result, double *ws,
+                          void *stream);
 int64_t nsol_lb_gram_ws_doubles(void);
 int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream);

@@ -219,6 +219,62 @@ int mdots_impl(const T *const *vecs, int nvec, const T *y, const int8_t *iwhere,
   return launch_status();
 }
 
+// out = a - b ; result = { sum out^2, sum out * c } (c may be null): the line
+// search's d = z - x with d'd and g'd, and the BFGS pair's y = g - g_old with y'y
+// (scipy's lnsrlb / matupd), one pass instead of a difference and two dots.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_diff_dots(const T *__restrict__ a,
+                                                       const T *__restrict__ b,
+                                                       const T *__restrict__ c,
+                                                       T *__restrict__ out, int64_t n,
+                                                       double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  double acc[2] = {0.0, 0.0};
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    V ov;
+    if constexpr (VEC == 1) {
+      ov[0] = T(1) * a[j] + T(-1) * b[j];
+      out[j] = ov[0];
+    } else {
+      const V av = reinterpret_cast<const V *>(a)[j];
+      const V bv = reinterpret_cast<const V *>(b)[j];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) ov[e] = T(1) * av[e] + T(-1) * bv[e];
+      reinterpret_cast<V *>(out)[j] = ov;
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0] += (double)ov[e] * (double)ov[e];
+    if (c) {
+      V cv;
+      if constexpr (VEC == 1) cv[0] = c[j];
+      else cv = reinterpret_cast<const V *>(c)[j];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[1] += (double)ov[e] * (double)cv[e];
+    }
+  }
+  block_partials<2>(acc, ws, false);
+}
+
+template <typename T>
+int diff_dots_impl(const T *a, const T *b, const T *c, T *out, int64_t n,
+                   double *result, double *ws, void *stream) {
+  if (!a || !b || !out || n < 1 || !result || !ws) return NSOL_EINVAL;
+  constexpr int VW = 16 / sizeof(T);
+  const bool vec = n % VW == 0 && !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)out |
+                                     (uintptr_t)c) & 15);
+  const int gr = rgrid(vec ? n / VW : n);
+  if (vec)
+    hipLaunchKernelGGL((k_diff_dots<T, VW>), dim3(gr), dim3(kBlock), 0,
+                       as_stream(stream), a, b, c, out, n, ws);
+  else
+    hipLaunchKernelGGL((k_diff_dots<T, 1>), dim3(gr), dim3(kBlock), 0, as_stream(stream),
+                       a, b, c, out, n, ws);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, gr, 2,
+                     false, result);
+  return launch_status();
+}
+
 // ---- masked Gram matrix of up to kGramMax vectors in one pass ---------------
 // out[(i,j)], i <= j, = sum over free variables of v_i * v_j, for all pairs at
 // once: a workgroup stages a tile of 4 KiB of every vector in LDS
@@ -709,6 +765,15 @@ int nsol_lb_mdots_f64(const double *const *vecs, int nvec, const double *y,
                       const int8_t *iwhere, int64_t n, double *result, double *ws,
                       void *stream) {
   return mdots_impl<double>(vecs, nvec, y, iwhere, n, result, ws, stream);
+}
+int nsol_lb_diff_dots_f32(const float *a, const float *b, const float *c, float *out,
+                          int64_t n, double *result, double *ws, void *stream) {
+  return diff_dots_impl<float>(a, b, c, out, n, result, ws, stream);
+}
+int nsol_lb_diff_dots_f64(const double *a, const double *b, const double *c,
+                          double *out, int64_t n, double *result, double *ws,
+                          void *stream) {
+  return diff_dots_impl<double>(a, b, c, out, n, result, ws, stream);
 }
 int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream) {

@@ -390,8 +390,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 updatd = False
                 continue
         # ---------------- line search --------------------------------------
-        d = be.lincomb2(1.0, z, -1.0, x)
-        dtd = be.dot(d, d)
+        d, dtd, gd = be.diff_dots(z, x, g)        # d = z - x, d'd, g'd
         dnorm = math.sqrt(dtd)
         stpmx = BIG
         if cnstnd:
@@ -403,10 +402,11 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             stp = min(1.0 / dnorm, stpmx) if dnorm > 0 else stpmx
         else:
             stp = 1.0
-        xold = be.copy(x)
-        gold = be.copy(g)
+        # (no backend operation writes into its arguments, so the old iterate
+        # and gradient are kept by reference)
+        xold = x
+        gold = g
         fold = f
-        gd = be.dot(g, d)
         gdold = gd
         restart = False
         if gd >= 0:
@@ -434,7 +434,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 nfgv += 1
                 stp = ls.stp
                 if stp == 1.0:
-                    x = be.copy(z)
+                    x = z
                 else:
                     x = be.lincomb2(stp, d, 1.0, xold)
                 f, g = fun_and_grad(x)
@@ -467,8 +467,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             info["task"] = "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"
             break
         # ---------------- BFGS update ---------------------------------------
-        r = be.lincomb2(1.0, g, -1.0, gold)
-        rr = be.dot(r, r)
+        r, rr, _ = be.diff_dots(g, gold)          # y = g - g_old, y'y
         if stp == 1.0:
             dr = gd - gdold
             ddum = -gdold

@@ -57,7 +57,17 @@ class DeviceBackend(object):
         return ops.dot(x, y)
 
     def dot_diff(self, a, b, g):
-        return ops.dot(ops.lincomb2(1.0, a, -1.0, b), g)
+        return self.diff_dots(a, b, g)[2]
+
+    def diff_dots(self, a, b, c=None):
+        """(a - b, its squared norm, its product with c) from one pass."""
+        ws, res = self._bufs(a)
+        out = torch.empty_like(a)
+        self._check(_fn("diff_dots", a)(
+            _p(a), _p(b), _p(c) if c is not None else None, _p(out), a.numel(),
+            _p(res), _p(ws), stream_ptr()), "diff_dots")
+        r = res[:2].cpu().numpy()
+        return out, float(r[0]), float(r[1])
 
     def init_where(self, x, lo, hi):
         bounded = np.isfinite(lo) or np.isfinite(hi)

@@ -35,6 +35,11 @@ class NumpyBackend(object):
     def dot_diff(self, a, b, g):
         return float(np.dot(a - b, g))
 
+    def diff_dots(self, a, b, c=None):
+        d = a - b
+        return d, float(np.dot(d, d)), \
+            (float(np.dot(d, c)) if c is not None else 0.0)
+
     def init_where(self, x, lo, hi):
         bounded = np.isfinite(lo) or np.isfinite(hi)
         if np.isfinite(lo) and np.isfinite(hi) and hi - lo <= 0:
