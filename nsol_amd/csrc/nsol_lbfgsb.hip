@@ -500,11 +500,14 @@ __global__ __launch_bounds__(kBlock) void k_cauchy_setup(
 
 // ---- breakpoints (t, i) lexicographically after (t_done, i_done), t <= t_hi
 // Compaction into out[] (any order; the candidates are sorted afterwards).  A
-// workgroup looks at kSelPer elements per thread and sweep and reserves its
-// range with ONE returning atomic: with one element per thread the 4096
-// workgroups issued half a million same-address atomics per call (2.4 ms at
-// 512^3; a plain scan of tbk takes 0.1 ms).
+// workgroup looks at kSelSweeps x kSelPer elements per thread (16-byte loads, one
+// bit of state per element) and reserves its range with ONE returning atomic:
+// same-address atomics are what this kernel's time is made of -- one per 256
+// elements cost 2.4 ms at 512^3, one per 4 096 elements 0.32 ms, one per wave
+// and 1 024 elements (no barrier) was slower again; a plain scan of tbk takes
+// 0.1 ms.
 constexpr int kSelPer = 16;
+constexpr int kSelSweeps = 8;
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_select(const T *__restrict__ tbk,
@@ -516,54 +519,72 @@ __global__ __launch_bounds__(kBlock) void k_select(const T *__restrict__ tbk,
   __shared__ int s_base;
   constexpr int VEC = 4;
   constexpr int NV = kSelPer / VEC;
+  typedef T V __attribute__((ext_vector_type(VEC)));
   const int64_t chunk = (int64_t)kBlock * kSelPer;          // elements per sweep
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  for (int64_t base = (int64_t)blockIdx.x * chunk; base < n;
-       base += (int64_t)gridDim.x * chunk) {
-    // thread t looks at NV groups of VEC consecutive elements, groups kBlock apart
-    unsigned flags = 0;
+  const bool al = (reinterpret_cast<uintptr_t>(tbk) % sizeof(V)) == 0;
+  const int64_t first = (int64_t)blockIdx.x * kSelSweeps * chunk;
+  // thread t looks, in each of kSelSweeps sweeps, at NV groups of VEC consecutive
+  // elements, groups kBlock apart; one bit per element
+  unsigned flags[kSelSweeps];
+  int mine = 0;
+#pragma unroll
+  for (int sw = 0; sw < kSelSweeps; ++sw) {
+    const int64_t base = first + sw * chunk;
+    unsigned f = 0;
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
       const int64_t i0 = base + ((int64_t)r * kBlock + threadIdx.x) * VEC;
+      T t4[VEC];
+      if (al && i0 + VEC <= n) {
+        const V v = *reinterpret_cast<const V *>(tbk + i0);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) t4[k] = v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) t4[k] = (i0 + k < n) ? tbk[i0 + k] : t_hi;
+      }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const int64_t i = i0 + k;
-        if (i < n) {
-          const T t = tbk[i];
-          if (t <= t_hi && (t > t_done || (t == t_done && i > i_done)))
-            flags |= 1u << (r * VEC + k);
-        }
+        const T t = t4[k];
+        if (i < n && t <= t_hi && (t > t_done || (t == t_done && i > i_done)))
+          f |= 1u << (r * VEC + k);
       }
     }
-    const int mine = __popc(flags);
-    // exclusive prefix of `mine` inside the wave
-    int incl = mine;
+    flags[sw] = f;
+    mine += __popc(f);
+  }
+  // exclusive prefix of `mine` inside the wave, then over the waves
+  int incl = mine;
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const int up = __shfl_up(incl, d, kWave);
-      if (lane >= d) incl += up;
-    }
-    if (lane == kWave - 1) s_cnt[wv] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int k = 0; k < kBlock / kWave; ++k) tot += s_cnt[k];
-      s_base = tot ? atomicAdd(count, tot) : 0;
-    }
-    __syncthreads();
-    if (mine) {
-      int slot = s_base + incl - mine;
-      for (int k = 0; k < wv; ++k) slot += s_cnt[k];
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int up = __shfl_up(incl, d, kWave);
+    if (lane >= d) incl += up;
+  }
+  if (lane == kWave - 1) s_cnt[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) tot += s_cnt[k];
+    s_base = tot ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  if (mine) {
+    int slot = s_base + incl - mine;
+    for (int k = 0; k < wv; ++k) slot += s_cnt[k];
+#pragma unroll
+    for (int sw = 0; sw < kSelSweeps; ++sw) {
 #pragma unroll
       for (int b = 0; b < kSelPer; ++b) {
-        if (flags & (1u << b)) {
-          const int64_t i = base + ((int64_t)(b / VEC) * kBlock + threadIdx.x) * VEC + b % VEC;
+        if (flags[sw] & (1u << b)) {
+          const int64_t i = first + sw * chunk +
+                            ((int64_t)(b / VEC) * kBlock + threadIdx.x) * VEC + b % VEC;
           if (slot < capacity) out[slot] = i;
           ++slot;
         }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -835,9 +856,12 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
       return NSOL_EINVAL;                                                        \
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), as_stream(s));          \
     if (e != hipSuccess) return (int)e;                                          \
-    hipLaunchKernelGGL(k_select<T>, dim3(grid_for((n + kSelPer - 1) / kSelPer)), \
-                       dim3(kBlock), 0, as_stream(s), tbk, n, (T)t_done, i_done, \
-                       (T)t_hi, out_idx, capacity, count);                       \
+    const int64_t per = (int64_t)kBlock * kSelPer * kSelSweeps;                  \
+    const int64_t blocks = (n + per - 1) / per;                                  \
+    if (blocks > 0x7fffffff) return NSOL_EINVAL;                                 \
+    hipLaunchKernelGGL(k_select<T>, dim3((unsigned)blocks), dim3(kBlock), 0,     \
+                       as_stream(s), tbk, n, (T)t_done, i_done, (T)t_hi,         \
+                       out_idx, capacity, count);                                \
     return launch_status();                                                      \
   }                                                                              \
   int nsol_lb_count_window_##SUF(const T *tbk, int64_t n, double t_done,         \
