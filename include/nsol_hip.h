@@ -346,6 +346,15 @@ int nsol_loss_cost_grad_f64(const double *r, double *g, int64_t n, int loss,
                             double f_scale, double *result, double *ws,
                             void *stream);
 
+/* The same with the residual formed on the way, r = ax - b (ax = A x; the
+ * reference's `A(x) - b`, linear_solver.py:318): g may alias ax. */
+int nsol_loss_residual_cost_grad_f32(const float *ax, const float *b, float *g,
+                                     int64_t n, int loss, double f_scale,
+                                     double *result, double *ws, void *stream);
+int nsol_loss_residual_cost_grad_f64(const double *ax, const double *b, double *g,
+                                     int64_t n, int loss, double f_scale,
+                                     double *result, double *ws, void *stream);
+
 /* element-wise rho(f2) and rho'(f2) (either output may be NULL); the API of
  * loss_functions.py:82-248 (huber's gamma is a parameter there, default 1.345). */
 int nsol_loss_eval_f32(const float *f2, float *rho, float *drho, int64_t n,

@@ -85,30 +85,46 @@ inline int rgrid(int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);   \
        i += (int64_t)gridDim.x * blockDim.x)
 
-// ---- max |projected gradient|
-template <typename T>
+// ---- max |projected gradient| (VEC elements = 16 bytes per lane and trip)
+template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_projgr(const T *__restrict__ x,
                                                     const T *__restrict__ g,
                                                     int64_t n, T lo, T hi,
                                                     bool has_lo, bool has_hi,
                                                     double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
   double a[1] = {0.0};
-  GRID_STRIDE(i, n) {
-    T gi = g[i];
-    if (gi < T(0)) {
-      if (has_hi) gi = t_max(x[i] - hi, gi);
-    } else {
-      if (has_lo) gi = (x[i] - lo < gi) ? x[i] - lo : gi;
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    const V gv = reinterpret_cast<const V *>(g)[j];
+    const V xv = reinterpret_cast<const V *>(x)[j];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T gi = gv[e];
+      if (gi < T(0)) {
+        if (has_hi) gi = t_max(xv[e] - hi, gi);
+      } else {
+        if (has_lo) gi = (xv[e] - lo < gi) ? xv[e] - lo : gi;
+      }
+      a[0] = fmax(a[0], fabs((double)gi));
     }
-    a[0] = fmax(a[0], fabs((double)gi));
   }
   block_partials<1>(a, ws, true);
 }
 
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_count_free(const int8_t *iw,
                                                         int64_t n, double *ws) {
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
   double a[1] = {0.0};
-  GRID_STRIDE(i, n) a[0] += (iw[i] <= 0) ? 1.0 : 0.0;
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    const M m = reinterpret_cast<const M *>(iw)[j];
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) c += (m[e] <= 0) ? 1 : 0;
+    a[0] += (double)c;
+  }
   block_partials<1>(a, ws, false);
 }
 
@@ -767,9 +783,14 @@ extern "C" {
 int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
                        double *ws, void *stream) {
   if (n < 0 || !result || !ws || (n > 0 && !iwhere)) return NSOL_EINVAL;
-  const int g = rgrid(n);
-  hipLaunchKernelGGL(k_count_free, dim3(g), dim3(kBlock), 0, as_stream(stream),
-                     iwhere, n, ws);
+  const bool vec = n % 16 == 0 && !(reinterpret_cast<uintptr_t>(iwhere) & 15);
+  const int g = rgrid(vec ? n / 16 : n);
+  if (vec)
+    hipLaunchKernelGGL(k_count_free<16>, dim3(g), dim3(kBlock), 0, as_stream(stream),
+                       iwhere, n, ws);
+  else
+    hipLaunchKernelGGL(k_count_free<1>, dim3(g), dim3(kBlock), 0, as_stream(stream),
+                       iwhere, n, ws);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, g,
                      1, false, result);
   return launch_status();
@@ -810,10 +831,18 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
   int nsol_lb_projgr_##SUF(const T *x, const T *g, int64_t n, double lo,         \
                            double hi, double *result, double *ws, void *s) {     \
     if (n < 1 || !x || !g || !result || !ws) return NSOL_EINVAL;                 \
-    const int gr = rgrid(n);                                                     \
-    hipLaunchKernelGGL(k_projgr<T>, dim3(gr), dim3(kBlock), 0, as_stream(s), x,  \
-                       g, n, cast_bound<T>(lo), cast_bound<T>(hi),               \
-                       lo > -INFINITY, hi < INFINITY, ws);                       \
+    constexpr int VW = 16 / sizeof(T);                                           \
+    const bool vec = n % VW == 0 && !((reinterpret_cast<uintptr_t>(x) |          \
+                                       reinterpret_cast<uintptr_t>(g)) & 15);    \
+    const int gr = rgrid(vec ? n / VW : n);                                      \
+    if (vec)                                                                     \
+      hipLaunchKernelGGL((k_projgr<T, VW>), dim3(gr), dim3(kBlock), 0,           \
+                         as_stream(s), x, g, n, cast_bound<T>(lo),               \
+                         cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY, ws);  \
+    else                                                                         \
+      hipLaunchKernelGGL((k_projgr<T, 1>), dim3(gr), dim3(kBlock), 0,            \
+                         as_stream(s), x, g, n, cast_bound<T>(lo),               \
+                         cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY, ws);  \
     hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
                        1, true, result);                                         \
     return launch_status();                                                      \

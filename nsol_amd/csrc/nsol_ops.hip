@@ -303,19 +303,33 @@ __device__ __forceinline__ void loss_eval(int loss, T f2, T s2, T &rho, T &drho,
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_loss(const T *__restrict__ r,
-                                                  T *__restrict__ g, int64_t n,
-                                                  int loss, T s2, double *ws) {
+// residual r (minus b when given, as nsol_lincomb2 forms A x - b), its loss and
+// rho'(r^2) * r; VEC elements = 16 bytes per lane and trip when the arrays allow
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_loss(const T *r, const T *b, T *g,
+                                                  int64_t n, int loss, T s2,
+                                                  double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nv = n / VEC;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += stride) {
-    const T rv = r[i];
-    T rho, drho;
-    loss_eval(loss, rv * rv, s2, rho, drho);
-    acc += (double)rho;
-    if (g) g[i] = drho * rv;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv;
+       j += stride) {
+    V rv = reinterpret_cast<const V *>(r)[j];
+    if (b) {
+      const V bv = reinterpret_cast<const V *>(b)[j];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rv[e] = T(1) * rv[e] + T(-1) * bv[e];
+    }
+    V gv;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T rho, drho;
+      loss_eval(loss, rv[e] * rv[e], s2, rho, drho);
+      acc += (double)rho;
+      gv[e] = drho * rv[e];
+    }
+    if (g) reinterpret_cast<V *>(g)[j] = gv;
   }
   block_store_partial(acc, ws);
 }
@@ -537,13 +551,21 @@ int shrink_impl(const T *t, T *v, int ndim, int64_t m, double thr, void *stream)
 }
 
 template <typename T>
-int loss_impl(const T *r, T *g, int64_t n, int loss, double f_scale,
+int loss_impl(const T *r, const T *b, T *g, int64_t n, int loss, double f_scale,
               double *result, double *ws, void *stream) {
   if (n < 0 || !r || !result || !ws || loss < 0 || loss > 4) return NSOL_EINVAL;
-  const int gr = reduce_grid(n);
+  constexpr int VW = 16 / sizeof(T);
+  const bool vec = n % VW == 0 &&
+                   !((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(b) |
+                      reinterpret_cast<uintptr_t>(g)) & 15);
+  const int gr = reduce_grid(vec ? n / VW : n);
   const T s2 = (T)(f_scale * f_scale);
-  hipLaunchKernelGGL(k_loss<T>, dim3(gr), dim3(kBlock), 0, as_stream(stream), r,
-                     g, n, loss, s2, ws);
+  if (vec)
+    hipLaunchKernelGGL((k_loss<T, VW>), dim3(gr), dim3(kBlock), 0, as_stream(stream), r,
+                       b, g, n, loss, s2, ws);
+  else
+    hipLaunchKernelGGL((k_loss<T, 1>), dim3(gr), dim3(kBlock), 0, as_stream(stream), r,
+                       b, g, n, loss, s2, ws);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kBlock), 0, as_stream(stream),
                      ws, gr, result, 0.5);
   return launch_status();
@@ -648,7 +670,13 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
   }                                                                              \
   int nsol_loss_cost_grad_##SUF(const T *r, T *g, int64_t n, int loss,           \
                                 double fs, double *res, double *ws, void *s) {   \
-    return loss_impl<T>(r, g, n, loss, fs, res, ws, s);                          \
+    return loss_impl<T>(r, nullptr, g, n, loss, fs, res, ws, s);                 \
+  }                                                                              \
+  int nsol_loss_residual_cost_grad_##SUF(const T *ax, const T *b, T *g,          \
+                                         int64_t n, int loss, double fs,         \
+                                         double *res, double *ws, void *s) {     \
+    if (!b) return NSOL_EINVAL;                                                  \
+    return loss_impl<T>(ax, b, g, n, loss, fs, res, ws, s);                      \
   }                                                                              \
   int nsol_loss_eval_##SUF(const T *f2, T *rho, T *drho, int64_t n, int loss,    \
                            double fs, double gm, void *s) {                      \

@@ -226,16 +226,23 @@ def norm2(x):
     return float(np.sqrt(dot(x, x)))
 
 
-def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None):
-    """(0.5*sum rho(r^2), rho'(r^2)*r)."""
+def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None, minus=None):
+    """(0.5*sum rho(r^2), rho'(r^2)*r); with `minus` the residual is r - minus,
+    formed in the same pass."""
     _chk(r)
     ws, res = _workspace(r.device)
     g = None
     if want_grad:
         g = empty_like(r) if out is None else out
-    _lib.check(_fn("loss_cost_grad", r)(_p(r), _p(g), r.numel(), LOSSES[loss],
-                                        float(f_scale), _p(res), _p(ws),
-                                        stream_ptr()), "nsol_loss_cost_grad")
+    if minus is None:
+        _lib.check(_fn("loss_cost_grad", r)(
+            _p(r), _p(g), r.numel(), LOSSES[loss], float(f_scale), _p(res),
+            _p(ws), stream_ptr()), "nsol_loss_cost_grad")
+    else:
+        _chk(minus)
+        _lib.check(_fn("loss_residual_cost_grad", r)(
+            _p(r), _p(minus), _p(g), r.numel(), LOSSES[loss], float(f_scale),
+            _p(res), _p(ws), stream_ptr()), "nsol_loss_residual_cost_grad")
     return float(res.item()), g
 
 

@@ -230,8 +230,11 @@ class TikhonovLinearSolver(LinearSolver):
             if use_reg and USE_FUSED_TK1_REG else None
 
         def fun_and_grad(x):
-            r = ops.lincomb2(1.0, A(x), -1.0, b)
-            cost, g = ops.loss_cost_grad(r, loss, fscale, out=r)
+            r = A(x)
+            # in place unless A handed x itself back (an identity operator)
+            own = r.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()
+            cost, g = ops.loss_cost_grad(r, loss, fscale, out=r if own else None,
+                                         minus=b)
             grad = A_adj(g)
             if native is not None:
                 # B = gradient, B_adj its adjoint: 1/2||Bx||^2 and B_adj(Bx)

@@ -1032,6 +1032,30 @@ def test_fused_tk1_regulariser_is_bit_identical(nsol, shape, dtype):
     assert got2 is g2 and torch.equal(g2, ref) and e2 == e
 
 
+@pytest.mark.parametrize("n", [4096, 1001, 7])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("loss", ["linear", "huber", "soft_l1", "cauchy",
+                                  "arctan"])
+def test_loss_with_fused_residual(nsol, n, dtype, loss):
+    """nsol_loss_residual_cost_grad_* (A x - b formed in the same pass, 16-byte
+    accesses where the length allows) against lincomb2 followed by
+    nsol_loss_cost_grad_*: gradient bit for bit, cost to summation order."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    ax = 3 * torch.randn(n, device="cuda", dtype=td, generator=gen)
+    b = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    r = ops.lincomb2(1.0, ax, -1.0, b)
+    c_ref, g_ref = ops.loss_cost_grad(r, loss, 1.3)
+    c, g = ops.loss_cost_grad(ax.clone(), loss, 1.3, minus=b)
+    assert torch.equal(g, g_ref)
+    assert abs(c - c_ref) <= 1e-12 * abs(c_ref)
+    own = ax.clone()
+    c2, g2 = ops.loss_cost_grad(own, loss, 1.3, out=own, minus=b)
+    assert g2 is own and torch.equal(own, g_ref) and c2 == c
+
+
 def test_more_than_two_to_the_31_voxels(nsol):
     """A volume whose voxel count does not fit 32 bits (1040 x 1440 x 1440 =
     2.16e9 voxels, 8.6 GB per float32 field, 95 GB of solver state): the

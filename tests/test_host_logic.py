@@ -26,7 +26,8 @@ def test_library_builds_loads_and_exports_declared_symbols():
                  "admm_vw_update", "vector_shrink", "loss_cost_grad",
                  "loss_eval", "vector_norm_sum", "pd_fused2_iter",
                  "pd_fusedk_iter", "corr3_wrap", "lb_masked_gram", "lb_mdot",
-                 "tk1_reg_cost_grad", "lb_diff_dots"):
+                 "tk1_reg_cost_grad", "lb_diff_dots",
+                 "loss_residual_cost_grad"):
         for suf in ("f32", "f64"):
             assert "nsol_%s_%s" % (base, suf) in decl
     lib = _lib.load()            # binds every symbol or raises
