@@ -110,7 +110,7 @@ class ADMMLinearSolver(LinearSolver):
             b=self._dev(self._b), b_reg=b_reg, alpha=self._rho, x0=x,
             x_scale=1, iter_max=self._iter_max, data_loss=self._data_loss,
             minimizer=self._minimizer, verbose=self._verbose,
-            dtype=self._dtype)
+            dtype=self._dtype, _borrow=True)
         tikhonov.run()
         return tikhonov._x
 

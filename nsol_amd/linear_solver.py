@@ -33,9 +33,10 @@ class _LazyScaled(object):
 class LinearSolver(Solver):
 
     def __init__(self, A, A_adj, b, x0, alpha, x_scale, data_loss,
-                 data_loss_scale, minimizer, iter_max, verbose, dtype=None):
+                 data_loss_scale, minimizer, iter_max, verbose, dtype=None,
+                 _borrow=False):
         Solver.__init__(self, x0=x0, x_scale=x_scale, verbose=verbose,
-                        dtype=dtype)
+                        dtype=dtype, _borrow=_borrow)
         self._A = A
         self._A_adj = A_adj
         self._b = self._scaled_data(b)            # linear_solver.py:73
@@ -48,6 +49,9 @@ class LinearSolver(Solver):
     def _scaled(self, v):
         """v / x_scale, kept on the side (host/device) it was given on."""
         if is_device_tensor(v):
+            own = self._borrowed(v)
+            if own is not None:
+                return own
             return ops.scale(v.to(torch_dtype(self._dtype)).contiguous()
                              .view(-1), self._x_scale, divide=True)
         return np.asarray(v, dtype=np.float64) / self._x_scale

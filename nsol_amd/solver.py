@@ -18,11 +18,16 @@ from .device import (get_default_dtype, is_device_tensor, to_device, to_numpy,
 
 class Solver(object):
 
-    def __init__(self, x0, x_scale, verbose, dtype=None):
+    def __init__(self, x0, x_scale, verbose, dtype=None, _borrow=False):
         self._dtype = np.dtype(dtype or get_default_dtype()).type
         if self._dtype not in (np.float32, np.float64):
             raise ValueError("dtype must be float32 or float64")
         self._x_scale = float(x_scale)
+        # _borrow: the caller (an outer solver of this package) owns the device
+        # tensors it passes and will not touch them while this solver runs; with
+        # x_scale = 1 they are then used as they are instead of being copied
+        # through a division by one
+        self._borrow = bool(_borrow)
         self._verbose = verbose
         self._computational_time = datetime.timedelta(seconds=0)
         self._observer = None
@@ -34,13 +39,22 @@ class Solver(object):
     # device in the working precision -- the same way the data term is scaled,
     # so x0 = b gives bit-equal scaled arrays -- instead of two float64 passes
     # over the host copy (0.14 s at 512^3).
+    def _borrowed(self, v):
+        """v itself (flat) when it may be used without a private copy."""
+        if self._borrow and self._x_scale == 1.0 and is_device_tensor(v) and \
+                v.dtype == torch_dtype(self._dtype) and v.is_contiguous():
+            return v.view(-1)
+        return None
+
     def _set_x0(self, x0):
         if is_device_tensor(x0):
             self._x0_ndim = x0.dim()
             self._x0_host = None
-            self._x0_dev = ops.scale(
-                x0.to(torch_dtype(self._dtype)).contiguous().view(-1),
-                self._x_scale, divide=True)
+            self._x0_dev = self._borrowed(x0)
+            if self._x0_dev is None:
+                self._x0_dev = ops.scale(
+                    x0.to(torch_dtype(self._dtype)).contiguous().view(-1),
+                    self._x_scale, divide=True)
         else:
             arr = np.asarray(x0)
             keep = arr.dtype if arr.dtype in (np.float32, np.float64) \

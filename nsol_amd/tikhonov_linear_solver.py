@@ -43,12 +43,12 @@ class TikhonovLinearSolver(LinearSolver):
     def __init__(self, A, A_adj, b, B, B_adj, x0, alpha=0.01, b_reg=0,
                  data_loss="linear", data_loss_scale=1, minimizer="lsmr",
                  iter_max=10, x_scale=1, verbose=0, bounds=(0, np.inf),
-                 dtype=None):
+                 dtype=None, _borrow=False):
         LinearSolver.__init__(
             self, A=A, A_adj=A_adj, b=b, x0=x0, alpha=alpha, iter_max=iter_max,
             minimizer=minimizer, data_loss=data_loss,
             data_loss_scale=data_loss_scale, x_scale=x_scale, verbose=verbose,
-            dtype=dtype)
+            dtype=dtype, _borrow=_borrow)
         self._B = B
         self._B_adj = B_adj
         self._b_reg = self._scaled(b_reg)          # tikhonov :91
