@@ -299,7 +299,8 @@ int try_launch_wrap(const T *x, T *out, int axis, int64_t nz, int64_t ny,
 //   z pass  the xy-filtered values of the last NT - 1 planes live in registers
 //           (a shifting window); once it is full every new plane yields one
 //           output plane R planes behind.
-// What bounds it (512^3, 13 taps, 0.42-0.43 ms = 2.5 TB/s of the 8 B per voxel; switches
+// What bounds it (512^3, 13 taps, one plane per step: 0.42-0.43 ms = 2.5 TB/s of the
+// 8 B per voxel; k_blur3_wrap_pp below takes two planes per step, 0.39 ms; switches
 // compiled in for the measurement): loads and stores alone take 0.31 ms, the
 // arithmetic alone 0.17 ms, and the two do not overlap -- one 16-wave workgroup
 // per CU (the z window is 48 registers per lane) runs its phases in lock step.
@@ -471,6 +472,145 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
   }
 }
 
+// The same kernel with PP planes per step and barrier: the loads of both planes
+// travel together and the z window moves by PP planes at a time (half the
+// register moves per plane).  124 registers at 13 taps and PP = 2 -- used up to
+// 13 taps (8-byte elements: 11); 0.39 instead of 0.43 ms at 512^3.
+template <typename T, int VEC, int NT, int NW, int PP>
+__global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
+    const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
+    Taps<T> tz, Taps<T> ty, Taps<T> tx, int lxb, int ntx, int nty, int zchunk) {
+  typedef typename VecOf<T, VEC>::type V;
+  typedef XWindow<T, VEC, NT> W;
+  constexpr int R = NT / 2;
+  constexpr int NB = W::NB, NBH = W::NBH;
+  constexpr int NT_THREADS = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int tyr = NT_THREADS / lxb;            // rows of the tile = rows of lanes
+  const int frows = tyr + 2 * R;               // footprint rows
+  const int rowlen = lxb * VEC;
+  const int tid = threadIdx.x;
+  const int row = tid / lxb;
+  const int lx = tid - row * lxb;
+  // (Plain tile order, x fastest: giving every XCD a contiguous run of tiles so
+  // that shared halo lines meet in one L2 is slower here, 0.472 vs 0.456 ms.)
+  int bid = blockIdx.x;
+  const int bx = bid % ntx; bid /= ntx;
+  const int by = bid % nty;
+  const int bz = bid / nty;
+  const int nxv = (int)(nx / VEC);
+  const int xv = bx * lxb + lx;                        // own vector along x
+  const int64_t y0 = (int64_t)by * tyr;
+  const bool owner = xv < nxv && (y0 + row < ny);
+  const uint32_t plane_bytes = (uint32_t)(ny * nx * sizeof(T));
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T *>(x), 0, (uint32_t)(nz * plane_bytes), 0x00020000);
+  // wrapped byte offsets of the x window (loop invariant)
+  uint32_t xo[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    int j = (xv + b - NBH) % nxv;
+    if (j < 0) j += nxv;
+    xo[b] = (uint32_t)j * (uint32_t)(VEC * sizeof(T));
+  }
+  // footprint rows this lane filters along x: `row` (round 0) and `tyr + row`
+  // (round 1: the 2R halo rows, the first waves of the workgroup)
+  const bool second = row < 2 * R;
+  const bool second_wave = __builtin_amdgcn_readfirstlane((int)second) != 0;
+  uint32_t yo[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int64_t yy = (y0 - R + row + (int64_t)q * tyr) % ny;
+    if (yy < 0) yy += ny;
+    yo[q] = (uint32_t)(yy * nx * sizeof(T));
+  }
+  if (!second) yo[1] = kNoLane;                // lanes of a mixed wave: no access
+  const int64_t zbeg = (int64_t)bz * zchunk;
+  int64_t zend = zbeg + zchunk;
+  if (zend > nz) zend = nz;
+  int zw = (int)((zbeg - R) % nz);             // plane the x pass reads
+  if (zw < 0) zw += (int)nz;
+  V ring[NT - 1];                              // xy-filtered planes, oldest first
+#pragma unroll
+  for (int t = 0; t + 1 < NT; ++t) ring[t] = V(T(0));
+  const int nsteps = (int)(zend - zbeg) + 2 * R;
+  const uint32_t own_off =
+      (uint32_t)((y0 + row) * nx * sizeof(T)) + (uint32_t)xv * (uint32_t)(VEC * sizeof(T));
+  const rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(nz * plane_bytes),
+                                                      0x00020000);
+  // (A window with compile-time slots -- the step loop unrolled NT times -- is no
+  // faster at 13 taps and spills from 15 taps on.)
+  // PP planes per step (and per barrier): with two, their loads travel together
+  // and the window moves by two planes at a time (half the register moves)
+  const size_t tile = (size_t)frows * rowlen;            // one x-filtered plane
+#pragma unroll 1
+  for (int st = 0; st < nsteps; st += PP) {
+    T *buf = smem + (size_t)((st / PP) & 1) * PP * tile;
+    uint32_t so[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+      so[q] = (uint32_t)zw * plane_bytes;
+      if (++zw == (int)nz) zw = 0;     // (a step may read one valid plane too many)
+    }
+    {
+      W w[PP];
+#pragma unroll
+      for (int q = 0; q < PP; ++q) w[q].load(rs, xo, yo[0], so[q]);
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+        *reinterpret_cast<V *>(buf + q * tile + (size_t)row * rowlen + lx * VEC) =
+            w[q].filter(tx);
+    }
+    if (second_wave) {
+      W w[PP];
+#pragma unroll
+      for (int q = 0; q < PP; ++q) w[q].load(rs, xo, yo[1], so[q]);
+#pragma unroll
+      for (int q = 0; q < PP; ++q) {
+        const V r1 = w[q].filter(tx);
+        if (second)
+          *reinterpret_cast<V *>(buf + q * tile + (size_t)(row + tyr) * rowlen +
+                                 lx * VEC) = r1;
+      }
+    }
+    __syncthreads();
+    V v[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+      const T *col = buf + q * tile + (size_t)row * rowlen + lx * VEC;
+      v[q] = ty.w[0] * *reinterpret_cast<const V *>(col);
+#pragma unroll
+      for (int t = 1; t < NT; ++t)
+        v[q] += ty.w[t] * *reinterpret_cast<const V *>(col + (size_t)t * rowlen);
+    }
+    // z pass: plane st + q sees the window's planes q.., then v[0..q]; the window
+    // then moves on by PP planes
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+      const int sq = st + q;
+      const int64_t z = zbeg + (sq - 2 * R);
+      if (sq >= 2 * R && owner && (PP == 1 || z < zend)) {
+        V acc = tz.w[0] * ring[q];
+#pragma unroll
+        for (int t = 1; t < NT; ++t) {
+          if (t + q < NT - 1) acc += tz.w[t] * ring[t + q < NT - 1 ? t + q : 0];
+          else acc += tz.w[t] * v[t + q - (NT - 1) < PP ? t + q - (NT - 1) : 0];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), ws,
+                                               own_off + (uint32_t)z * plane_bytes, 0,
+                                               0);
+        asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
+      }
+    }
+#pragma unroll
+    for (int t = 0; t + PP < NT - 1; ++t) ring[t] = ring[t + PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q)
+      if (NT - 1 - PP + q >= 0) ring[NT - 1 - PP + q] = v[q];
+  }
+}
+
 inline int blur3_cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -517,9 +657,14 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t blocks = ntx * nty * nzc;
   if (blocks > 0x7fffffff) return -2;
-  const size_t lds = 2 * (size_t)(tyr + 2 * R) * lxb * VEC * sizeof(T);
+  // two planes per step where the registers allow it
+  constexpr int PP = (NT >= 5 && NT <= (sizeof(T) == 4 ? 13 : 11)) ? 2 : 1;
+  const size_t lds = 2 * PP * (size_t)(tyr + 2 * R) * lxb * VEC * sizeof(T);
   if (lds > 150 * 1024) return -2;
-  auto kern = k_blur3_wrap<T, VEC, NT, NW>;
+  void (*kern)(const T *, T *, int64_t, int64_t, int64_t, Taps<T>, Taps<T>, Taps<T>, int,
+               int, int, int);
+  if constexpr (PP == 2) kern = k_blur3_wrap_pp<T, VEC, NT, NW, 2>;
+  else kern = k_blur3_wrap<T, VEC, NT, NW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
