@@ -10,7 +10,12 @@ namespace nsol {
 
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kBlock = 256;          // 4 waves, one per SIMD
-constexpr int kMaxGridBlocks = 4096; // grid-stride cap: 256 CUs x 16
+// grid-stride cap: 256 CUs x 8.  Element-wise kernels with 2..4 streams are 5-7 %
+// faster than with 16 workgroups per CU (fewer concurrent DRAM streams), with 4
+// per CU the 4-byte accesses no longer cover the latency (tools/tune_grid.py).
+constexpr int kMaxGridBlocks = 2048;
+constexpr int kMaxGridBlocksLimit = 4096;
+inline int g_max_grid_blocks = kMaxGridBlocks;   // (runtime knob "max_grid_blocks")
 constexpr int kReducePartials = 16384;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -23,7 +28,7 @@ inline int launch_status() {
 inline int grid_for(int64_t n, int per_block = kBlock) {
   int64_t b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
-  if (b > kMaxGridBlocks) b = kMaxGridBlocks;
+  if (b > g_max_grid_blocks) b = g_max_grid_blocks;
   return static_cast<int>(b);
 }
 

@@ -595,6 +595,8 @@ int nsol_hip_set_param(const char *name, int value) {
   else if (!strcmp(name, "pd_ry")) g_tune.ry = value;
   else if (!strcmp(name, "pd_two_pass")) g_tune.force_two_pass = value;
   else if (!strcmp(name, "pd_xcd_map")) g_tune.xcd_map = value;
+  else if (!strcmp(name, "max_grid_blocks"))
+    g_max_grid_blocks = value < 1 ? 1 : (value > kMaxGridBlocksLimit ? kMaxGridBlocksLimit : value);
   else return NSOL_EINVAL;
   return 0;
 }
