@@ -653,18 +653,49 @@ struct WComb {
   int nbase, nw;
 };
 
-template <typename T>
+// VEC elements = 16 bytes per lane and trip; the W vectors are fetched four at a
+// time so that several loads are in flight (with one 4-byte load after the other
+// the kernel ran at 3.6 TB/s for ten stored pairs); the sum keeps its order.
+template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_wcomb(T *__restrict__ out, int64_t n,
                                                    const int8_t *iw, T scale,
                                                    WComb<T> C) {
-  GRID_STRIDE(i, n) {
-    T acc = T(0);
-    if (!iw || iw[i] <= 0) {
-      for (int k = 0; k < C.nbase; ++k) acc += C.bcoef[k] * C.base[k][i];
-      for (int j = 0; j < C.nw; ++j) acc += C.wcoef[j] * C.w[j][i];
-      acc *= scale;
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    M m;
+    bool any = true;
+    if (iw) {
+      m = reinterpret_cast<const M *>(iw)[j];
+      any = false;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) any = any || (m[e] <= 0);
     }
-    out[i] = acc;
+    V acc = V(T(0));
+    if (any) {
+      for (int k = 0; k < C.nbase; ++k)
+        acc += C.bcoef[k] * reinterpret_cast<const V *>(C.base[k])[j];
+      int q = 0;
+      for (; q + 4 <= C.nw; q += 4) {
+        const V a0 = reinterpret_cast<const V *>(C.w[q])[j];
+        const V a1 = reinterpret_cast<const V *>(C.w[q + 1])[j];
+        const V a2 = reinterpret_cast<const V *>(C.w[q + 2])[j];
+        const V a3 = reinterpret_cast<const V *>(C.w[q + 3])[j];
+        acc += C.wcoef[q] * a0;
+        acc += C.wcoef[q + 1] * a1;
+        acc += C.wcoef[q + 2] * a2;
+        acc += C.wcoef[q + 3] * a3;
+      }
+      for (; q < C.nw; ++q) acc += C.wcoef[q] * reinterpret_cast<const V *>(C.w[q])[j];
+      acc *= scale;
+      if (iw) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (m[e] > 0) acc[e] = T(0);
+      }
+    }
+    reinterpret_cast<V *>(out)[j] = acc;
   }
 }
 
@@ -941,8 +972,19 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
       C.w[j] = j < nw ? w_host[j] : nullptr;                                     \
       C.wcoef[j] = j < nw ? (T)wcoef_host[j] : T(0);                             \
     }                                                                            \
-    hipLaunchKernelGGL(k_wcomb<T>, dim3(grid_for(n)), dim3(kBlock), 0,           \
-                       as_stream(s), out, n, iwhere, (T)scale, C);               \
+    constexpr int VW = 16 / sizeof(T);                                           \
+    bool vec = n % VW == 0 && !(reinterpret_cast<uintptr_t>(out) & 15) &&        \
+               (!iwhere || !(reinterpret_cast<uintptr_t>(iwhere) & (VW - 1)));   \
+    for (int k = 0; k < nbase; ++k)                                              \
+      vec = vec && !(reinterpret_cast<uintptr_t>(base_host[k]) & 15);            \
+    for (int j = 0; j < nw; ++j)                                                 \
+      vec = vec && !(reinterpret_cast<uintptr_t>(w_host[j]) & 15);               \
+    if (vec)                                                                     \
+      hipLaunchKernelGGL((k_wcomb<T, VW>), dim3(grid_for(n / VW)), dim3(kBlock), \
+                         0, as_stream(s), out, n, iwhere, (T)scale, C);          \
+    else                                                                         \
+      hipLaunchKernelGGL((k_wcomb<T, 1>), dim3(grid_for(n)), dim3(kBlock), 0,    \
+                         as_stream(s), out, n, iwhere, (T)scale, C);             \
     return launch_status();                                                      \
   }                                                                              \
   int nsol_lb_project_step_##SUF(const T *xcp, const T *d, int64_t n, double lo, \
