@@ -429,10 +429,29 @@ def vector_shrink(t, ndim, thr, out=None):
 B_NONE, B_GRAD, B_IDENTITY = 0, 1, 2
 
 
+def flat_geometry(n):
+    """(ny, nx) with ny * nx = n for the element-wise modes of the LSMR kernels
+    (B = identity / no regulariser): their thread mapping wants rows of at most
+    a few thousand elements, a flat vector of 512^3 elements is folded.  None
+    when n has no suitable power-of-two factor (callers then take the generic
+    vector kernels)."""
+    n = int(n)
+    if n <= (1 << 16):
+        return 1, n
+    for nx in (4096, 2048, 1024, 512, 256, 128, 64):
+        if n % nx == 0:
+            return n // nx, nx
+    return None
+
+
 def _bgeom(bmode, shape, w, n):
     if bmode == B_GRAD:
         return dims3(shape), w
-    return (1, 1, 1, int(n)), (1.0, 1.0, 1.0)
+    geom = flat_geometry(n)
+    if geom is None:
+        raise ValueError("no row folding for a vector of %d elements" % n)
+    ny, nx = geom
+    return ((1 if ny == 1 else 2), 1, ny, nx), (1.0, 1.0, 1.0)
 
 
 def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u):

@@ -144,13 +144,18 @@ class TikhonovLinearSolver(LinearSolver):
         b = self._dev(self._b)
         if b.numel() != n:
             return None
+        flat_ok = ops.flat_geometry(n) is not None
         if not (self._alpha > EPS):
+            if not flat_ok:
+                return None
             return (A, A_adj, b.clone(), None, ops.B_NONE, (n,),
                     (1.0, 1.0, 1.0), 0.0)
         dB = trace_operator(self._B, n)
         if dB is None:
             return None
         if dB[0] == "identity":
+            if not flat_ok:
+                return None
             bmode, shape, w, rows = ops.B_IDENTITY, (n,), (1., 1., 1.), n
             dBt = trace_operator(self._B_adj, n)
             if dBt is None or dBt[0] != "identity":

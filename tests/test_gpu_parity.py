@@ -1195,6 +1195,29 @@ def test_full_size_admm_path_properties(nsol):
     d = ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, outs[1])) / \
         ops.norm2(outs[1])
     assert d < 2e-6
+    # B = identity (the prox of PD-deconvolution, proximal_operators.py:43-78)
+    # and no regulariser on the same 256^3 volume: the element-wise modes of the
+    # fused kernels see a flat vector of 16.8 M elements and fold it into rows
+    ident = lambda v: v.flatten()
+    for alpha, kw in ((0.5, dict(B=ident, B_adj=ident, b_reg=b)),
+                      (0.0, dict(B=ident, B_adj=ident))):
+        outs = []
+        for fused in (True, False):
+            tk.USE_FUSED_LSMR = fused
+            try:
+                s = tk.TikhonovLinearSolver(A=A_, A_adj=A_, b=b, x0=b,
+                                            alpha=alpha, iter_max=6,
+                                            dtype=np.float32, **kw)
+                s.run()
+                outs.append(s.get_x_device())
+            finally:
+                tk.USE_FUSED_LSMR = True
+        d = ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, outs[1])) / \
+            ops.norm2(outs[1])
+        assert d < 2e-6, alpha
+    assert ops.flat_geometry(512 ** 3) == (512 ** 3 // 4096, 4096)
+    assert ops.flat_geometry(1000) == (1, 1000)
+    assert ops.flat_geometry((1 << 20) + 1) is None
 
 
 def test_device_lbfgsb_vs_scipy_driver_at_64_cubed(nsol):
