@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
     const T *__restrict__ Av, const T *__restrict__ v, T *__restrict__ u_top,
     T *__restrict__ u_bot, Geom<T> G, int bmode, T c_av, T c_bv, T c_u,
     double *ws) {
-  const int64_t nrg = row_groups<T, ROWS>(G);
+  const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   double acc = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
@@ -150,7 +150,7 @@ template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_lsmr_v(
     const T *__restrict__ Atu, const T *__restrict__ u_bot, T *__restrict__ v,
     Geom<T> G, int bmode, T c_atu, T c_btu, T c_v, double *ws) {
-  const int64_t nrg = row_groups<T, ROWS>(G);
+  const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   double acc = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
@@ -237,7 +237,7 @@ template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
                                                      const T *g, T *grad, Geom<T> G,
                                                      T alpha, double *ws) {
-  const int64_t nrg = row_groups<T, ROWS>(G);
+  const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   double acc = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);

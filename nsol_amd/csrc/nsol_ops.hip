@@ -17,7 +17,7 @@ namespace {
 template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_grad(const T *__restrict__ x,
                                                   T *__restrict__ g, Geom<T> G) {
-  const int64_t nrg = row_groups<T, ROWS>(G);
+  const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
   const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
   if (!c.ok) continue;
@@ -77,7 +77,7 @@ template <typename T, int VEC, int ROWS>
 __global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
                                                       T *__restrict__ out,
                                                       Geom<T> G) {
-  const int64_t nrg = row_groups<T, ROWS>(G);
+  const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
                                                      T *__restrict__ rhs,
                                                      Geom<T> G, T thr,
                                                      T rhs_scale) {
-  const int64_t nrg = row_groups<T, ROWS>(G);
+  const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
   const Voxel q = voxel_at<T, VEC, ROWS>(G, rg);
   if (!q.ok) continue;

@@ -54,10 +54,20 @@ struct Voxel {
 };
 
 // Row groups (ROWS consecutive rows of one z-plane) are dealt to blockIdx.y
-// grid-stride: rg = blockIdx.y, blockIdx.y + gridDim.y, ...
-template <typename T, int ROWS>
+// grid-stride: rg = blockIdx.y, blockIdx.y + gridDim.y, ...  A row longer than
+// gridDim.x tiles (a 1-D signal of millions of samples) adds an outer x index to
+// the units dealt out: unit = row group * x_outer + xo, tile = xo * gridDim.x +
+// blockIdx.x.
+template <typename T, int VEC, int ROWS>
+__device__ __forceinline__ unsigned x_outer(const Geom<T> &G) {
+  constexpr int XT = kBlock / ROWS;
+  const int64_t tiles = (G.nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
+  return (unsigned)((tiles + gridDim.x - 1) / gridDim.x);
+}
+
+template <typename T, int VEC, int ROWS>
 __device__ __forceinline__ int64_t row_groups(const Geom<T> &G) {
-  return ((G.ny + ROWS - 1) / ROWS) * G.nz;
+  return ((G.ny + ROWS - 1) / ROWS) * G.nz * (int64_t)x_outer<T, VEC, ROWS>(G);
 }
 
 template <typename T, int VEC, int ROWS>
@@ -65,21 +75,29 @@ __device__ __forceinline__ Voxel voxel_at(const Geom<T> &G, int64_t rg) {
   Voxel c;
   constexpr int XT = kBlock / ROWS;  // threads along x
   const unsigned rgy = (unsigned)((G.ny + ROWS - 1) / ROWS);
-  const unsigned urg = (unsigned)rg;  // < 2^31 (checked on the host)
+  unsigned urg = (unsigned)rg;  // < 2^31 (checked on the host)
+  unsigned xo = 0;
+  const unsigned nxo = x_outer<T, VEC, ROWS>(G);
+  if (nxo > 1) {
+    xo = urg % nxo;
+    urg /= nxo;
+  }
   c.iz = urg / rgy;
   c.iy = (int64_t)(urg - (unsigned)c.iz * rgy) * ROWS + (threadIdx.x / XT);
-  c.ix = ((int64_t)blockIdx.x * XT + (threadIdx.x % XT)) * VEC;
+  c.ix = (((int64_t)xo * gridDim.x + blockIdx.x) * XT + (threadIdx.x % XT)) * VEC;
   c.ok = c.ix < G.nx && c.iy < G.ny;
   c.i = (c.iz * G.ny + c.iy) * G.nx + c.ix;
   return c;
 }
 
 constexpr int kStencilMaxBlocks = 16384;  // = reduction partials (kReducePartials)
+constexpr int kStencilMaxTilesX = 4096;   // x tiles per grid row; longer rows loop
 
 template <int VEC, int ROWS>
 inline dim3 stencil_grid(int64_t nz, int64_t ny, int64_t nx) {
   constexpr int XT = kBlock / ROWS;
-  const int64_t gx = (nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
+  int64_t gx = (nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
+  if (gx > kStencilMaxTilesX) gx = kStencilMaxTilesX;
   const int64_t nrg = ((ny + ROWS - 1) / ROWS) * nz;
   int64_t gy = kStencilMaxBlocks / (gx > 0 ? gx : 1);
   if (gy < 1) gy = 1;
@@ -87,9 +105,10 @@ inline dim3 stencil_grid(int64_t nz, int64_t ny, int64_t nx) {
   return dim3((unsigned)gx, (unsigned)gy, 1);
 }
 
+// units dealt to blockIdx.y (row groups x outer x index) must fit 31 bits
 inline bool stencil_grid_ok(int64_t nz, int64_t ny, int64_t nx) {
-  return ((ny + 3) / 4) * nz < (int64_t)0x7fffffff &&
-         nx / 64 + 1 <= kStencilMaxBlocks;
+  const int64_t outer = (nx / 64 + kStencilMaxTilesX) / kStencilMaxTilesX;
+  return ((ny + 3) / 4) * nz * outer < (int64_t)0x7fffffff;
 }
 
 template <typename T>

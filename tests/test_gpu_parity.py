@@ -1056,6 +1056,42 @@ def test_loss_with_fused_residual(nsol, n, dtype, loss):
     assert g2 is own and torch.equal(own, g_ref) and c2 == c
 
 
+@pytest.mark.parametrize("n", [3000017, 4000000])
+def test_long_1d_signal(nsol, n):
+    """A 1-D signal of millions of samples: one row far longer than a grid row
+    of tiles (the stencil mapping loops over x then).  grad / grad_adj bit-exact
+    against NumPy in float64, the 1-D primal-dual solver and the 1-D ADMM outer
+    update against the oracle."""
+    import torch
+    from nsol_amd import ops
+    from oracle import nsol_oracle as orc
+    rng = np.random.default_rng(n)
+    xh = rng.standard_normal(n)
+    w = 0.5
+    x = torch.from_numpy(xh).cuda()
+    g = ops.grad(x, (n,), (w, 1.0, 1.0)).cpu().numpy()
+    hi = np.append(xh[1:], 0.0)
+    assert np.array_equal(g, hi * w + xh * (-w))
+    ga = ops.grad_adj(x, (n,), (w, 1.0, 1.0)).cpu().numpy()
+    lo = np.append(0.0, xh[:-1])
+    assert np.array_equal(ga, xh * (-w) + lo * w)
+    obs = 60.0 + 25.0 * xh
+    s = _pd_solver(obs, "TV", "L2", 0.05, 12, 8.0, "ALG2", np.float64)
+    s.run()
+    assert s.get_execution() == "fused"
+    ref = orc.primal_dual_denoise(obs, (n,), "TV", "L2", 0.05, 12, 8.0, "ALG2")
+    assert rel_l2(s.get_x(), ref) < F64_TOL
+    # fused ADMM outer update (v, w, next right-hand side) in 1-D
+    v = torch.from_numpy(rng.standard_normal(n)).cuda()
+    wv = torch.from_numpy(rng.standard_normal(n)).cuda()
+    rhs = torch.empty_like(v)
+    t = ops.grad(x, (n,), (1.0, 1.0, 1.0)) + wv
+    v_ref = ops.vector_shrink(t, 1, 0.3)
+    ops.admm_vw_update(x, v, wv, None, rhs, (n,), (1.0, 1.0, 1.0), 0.3, 1.0)
+    assert torch.equal(v, v_ref)
+    assert torch.equal(wv, ops.lincomb2(1.0, t, -1.0, v_ref))
+
+
 def test_more_than_two_to_the_31_voxels(nsol):
     """A volume whose voxel count does not fit 32 bits (1040 x 1440 x 1440 =
     2.16e9 voxels, 8.6 GB per float32 field, 95 GB of solver state): the
