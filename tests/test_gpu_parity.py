@@ -1056,6 +1056,36 @@ def test_loss_with_fused_residual(nsol, n, dtype, loss):
     assert g2 is own and torch.equal(own, g_ref) and c2 == c
 
 
+def test_large_2d_image(nsol):
+    """A 16 384 x 16 384 float32 image (1 GiB per field): the one-iteration
+    kernel against the two-pass form bit for bit, grad / grad_adj adjoint, and
+    the 2-D sigma = 2 blur symmetric."""
+    import torch
+    from nsol_amd import ops
+    n = 16384
+    shape = (n, n)
+    flags = ops.PD_REG_HUBER | ops.PD_DATA_L1
+    a = _run_pd_raw(shape, np.float32, 3, flags, enable2=1)
+    b = _run_pd_raw(shape, np.float32, 3, flags, enable2=0, two_pass=1)
+    for u, v in zip(a[:3], b[:3]):
+        assert torch.equal(u, v)
+    assert bool(torch.isfinite(a[0][-4096:]).all())
+    del a, b
+    torch.cuda.empty_cache()
+    w = (1.0, 0.5, 1.0)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(n * n, device="cuda", generator=gen)
+    p = torch.rand(2 * n * n, device="cuda", generator=gen)
+    lhs = ops.dot(ops.grad(x, shape, w), p)
+    rhs = ops.dot(x, ops.grad_adj(p, shape, w))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    A, _ = _lo(2).get_gaussian_blurring_operators(np.diag([4.0, 4.0]))
+    y = p[:n * n]
+    lhs = ops.dot(A(x.view(shape)).reshape(-1), y)
+    rhs = ops.dot(x, A(y.view(shape)).reshape(-1))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+
+
 @pytest.mark.parametrize("n", [3000017, 4000000])
 def test_long_1d_signal(nsol, n):
     """A 1-D signal of millions of samples: one row far longer than a grid row
