@@ -111,7 +111,7 @@ int nsol_corr_axis_f64(const double *x, double *out, int axis, int64_t nz,
  * of `ntaps` doubles (odd, centre in the middle, the same count on every axis).
  * Passes run x, y, z.  Returns -2 (nothing launched) when the kernel does not
  * apply (even tap counts or more than 17, nx not a multiple of 16 bytes,
- * unaligned pointers, volumes of more than 3 GiB): use the per-axis passes
+ * unaligned pointers, planes of more than 3 GiB): use the per-axis passes
  * then. */
 int nsol_corr3_wrap_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const double *taps_z, const double *taps_y,

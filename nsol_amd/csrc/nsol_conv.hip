@@ -395,8 +395,13 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
   const int64_t y0 = (int64_t)by * tyr;
   const bool owner = xv < nxv && (y0 + row < ny);
   const uint32_t plane_bytes = (uint32_t)(ny * nx * sizeof(T));
-  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T *>(x), 0, (uint32_t)(nz * plane_bytes), 0x00020000);
+  const int64_t plane = ny * nx;
+  // one descriptor per plane (base = the plane, 32-bit offsets inside it): no
+  // limit on the size of the volume
+  auto plane_rsrc = [&](const T *base, int64_t z) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base + z * plane), 0,
+                                             plane_bytes, 0x00020000);
+  };
   // wrapped byte offsets of the x window (loop invariant)
   uint32_t xo[NB];
 #pragma unroll
@@ -428,22 +433,20 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
   const int nsteps = (int)(zend - zbeg) + 2 * R;
   const uint32_t own_off =
       (uint32_t)((y0 + row) * nx * sizeof(T)) + (uint32_t)xv * (uint32_t)(VEC * sizeof(T));
-  const rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(nz * plane_bytes),
-                                                      0x00020000);
   // (A window with compile-time slots -- the step loop unrolled NT times -- is no
   // faster at 13 taps and spills from 15 taps on.)
 #pragma unroll 1
   for (int st = 0; st < nsteps; ++st) {
     T *buf = smem + (size_t)(st & 1) * frows * rowlen;
-    const uint32_t so = (uint32_t)zw * plane_bytes;
+    const rsrc_t rs = plane_rsrc(x, zw);
     {
       W w;
-      w.load(rs, xo, yo[0], so);
+      w.load(rs, xo, yo[0], 0);
       *reinterpret_cast<V *>(buf + (size_t)row * rowlen + lx * VEC) = w.filter(tx);
     }
     if (second_wave) {
       W w;
-      w.load(rs, xo, yo[1], so);
+      w.load(rs, xo, yo[1], 0);
       const V r1 = w.filter(tx);
       if (second) *reinterpret_cast<V *>(buf + (size_t)(row + tyr) * rowlen + lx * VEC) = r1;
     }
@@ -461,9 +464,9 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
 #pragma unroll
       for (int t = 1; t + 1 < NT; ++t) acc += tz.w[t] * ring[t];
       acc += tz.w[NT - 1] * v;
-      const uint32_t z = (uint32_t)(zbeg + (st - 2 * R));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), ws,
-                                             own_off + z * plane_bytes, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc),
+                                             plane_rsrc(out, zbeg + (st - 2 * R)),
+                                             own_off, 0, 0);
       asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
     }
 #pragma unroll
@@ -504,8 +507,13 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
   const int64_t y0 = (int64_t)by * tyr;
   const bool owner = xv < nxv && (y0 + row < ny);
   const uint32_t plane_bytes = (uint32_t)(ny * nx * sizeof(T));
-  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T *>(x), 0, (uint32_t)(nz * plane_bytes), 0x00020000);
+  const int64_t plane = ny * nx;
+  // one descriptor per plane (base = the plane, 32-bit offsets inside it): no
+  // limit on the size of the volume
+  auto plane_rsrc = [&](const T *base, int64_t z) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base + z * plane), 0,
+                                             plane_bytes, 0x00020000);
+  };
   // wrapped byte offsets of the x window (loop invariant)
   uint32_t xo[NB];
 #pragma unroll
@@ -537,8 +545,6 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
   const int nsteps = (int)(zend - zbeg) + 2 * R;
   const uint32_t own_off =
       (uint32_t)((y0 + row) * nx * sizeof(T)) + (uint32_t)xv * (uint32_t)(VEC * sizeof(T));
-  const rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(nz * plane_bytes),
-                                                      0x00020000);
   // (A window with compile-time slots -- the step loop unrolled NT times -- is no
   // faster at 13 taps and spills from 15 taps on.)
   // PP planes per step (and per barrier): with two, their loads travel together
@@ -547,16 +553,16 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
 #pragma unroll 1
   for (int st = 0; st < nsteps; st += PP) {
     T *buf = smem + (size_t)((st / PP) & 1) * PP * tile;
-    uint32_t so[PP];
+    rsrc_t rs[PP];
 #pragma unroll
     for (int q = 0; q < PP; ++q) {
-      so[q] = (uint32_t)zw * plane_bytes;
+      rs[q] = plane_rsrc(x, zw);
       if (++zw == (int)nz) zw = 0;     // (a step may read one valid plane too many)
     }
     {
       W w[PP];
 #pragma unroll
-      for (int q = 0; q < PP; ++q) w[q].load(rs, xo, yo[0], so[q]);
+      for (int q = 0; q < PP; ++q) w[q].load(rs[q], xo, yo[0], 0);
 #pragma unroll
       for (int q = 0; q < PP; ++q)
         *reinterpret_cast<V *>(buf + q * tile + (size_t)row * rowlen + lx * VEC) =
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
     if (second_wave) {
       W w[PP];
 #pragma unroll
-      for (int q = 0; q < PP; ++q) w[q].load(rs, xo, yo[1], so[q]);
+      for (int q = 0; q < PP; ++q) w[q].load(rs[q], xo, yo[1], 0);
 #pragma unroll
       for (int q = 0; q < PP; ++q) {
         const V r1 = w[q].filter(tx);
@@ -597,9 +603,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
           if (t + q < NT - 1) acc += tz.w[t] * ring[t + q < NT - 1 ? t + q : 0];
           else acc += tz.w[t] * v[t + q - (NT - 1) < PP ? t + q - (NT - 1) : 0];
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), ws,
-                                               own_off + (uint32_t)z * plane_bytes, 0,
-                                               0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc),
+                                               plane_rsrc(out, z), own_off, 0, 0);
         asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
       }
     }
@@ -636,7 +641,7 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   while (lxb > 8 && lxb / 2 >= nxv) lxb /= 2;
   const int tyr = (NW * 64) / lxb;
   if (tyr < 2 * R) return -2;
-  if ((uint64_t)nz * ny * nx * sizeof(T) > kBlur3MaxBytes) return -2;   // 32-bit offsets
+  if ((uint64_t)ny * nx * sizeof(T) > kBlur3MaxBytes) return -2;   // 32-bit offsets in a plane
   const int64_t ntx = (nxv + lxb - 1) / lxb;
   const int64_t nty = (ny + tyr - 1) / tyr;
   // z chunks: one 16-wave workgroup runs per CU, so a launch takes
