@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Primal-dual iterations/s (TV-L2, float32, kernels only) for volumes whose
+extents are not multiples of the vector width, next to 512^3."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from nsol_amd import ops
+from nsol_amd.primal_dual_solver import step_schedule
+
+shapes = [(512, 512, 512), (511, 511, 511), (512, 512, 510), (512, 510, 512), (513, 513, 516)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(t) for t in a.split("x")) for a in sys.argv[1:]]
+for shape in shapes:
+    n = int(np.prod(shape))
+    bt = torch.rand(n, device="cuda")
+    x = bt.clone(); xa = torch.empty_like(bt)
+    xb = [bt.clone(), torch.empty_like(bt)]
+    p = [torch.zeros(3 * n, device="cuda") for _ in range(2)]
+    iters = 120
+    sig, ta, th = step_schedule("ALG2", 16.0, 1 / 0.03, iters)
+    flags = ops.PD_REG_TV | ops.PD_DATA_L2
+    ts = []
+    for r in range(4):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, (1.0, 1.0, 1.0), 1 / 0.03,
+                   sig, ta, th, r == 0, 0.05, flags, x_alt=xa)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters)
+    ms = float(np.median(ts[1:]))
+    print(json.dumps({"shape": shape, "ms_per_iteration": round(ms, 4),
+                      "ns_per_voxel": round(ms * 1e6 / n, 4),
+                      "depth3_launches": ops.pd_fusedk_launches(3)}), flush=True)
+    del bt, x, xa, xb, p
+    torch.cuda.empty_cache()
