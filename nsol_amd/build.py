@@ -28,17 +28,37 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile the HIP sources into csrc/libnsol_hip.so; returns its path."""
+def build_library(force=False, verbose=False, jobs=None):
+    """Compile the HIP sources into csrc/libnsol_hip.so; returns its path.
+    The translation units are compiled side by side (objects in a temporary
+    directory outside the tree) and linked once."""
     if not force and not _stale():
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-I", INCLUDE] + \
-        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) // 2))
+    tmp = tempfile.mkdtemp(prefix="nsol_build_")
+    try:
+        def one(src):
+            obj = os.path.join(tmp, src.replace(".hip", ".o"))
+            cmd = [hipcc] + compile_flags + ["-I", INCLUDE, "-c",
+                                             os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            return obj
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            objs = list(pool.map(one, SOURCES))
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + \
+            ["-o", LIB + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        os.replace(LIB + ".tmp", LIB)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return LIB
 
 
