@@ -134,6 +134,24 @@ __device__ __forceinline__ void bst(rsrc_t r, uint32_t vo, const T (&v)[V]) {
   asm volatile("s_nop 1");
 }
 
+// the first n elements only (the last vector of a row that is not a multiple of
+// the vector width); same rules for the offsets as bst()
+template <typename T, int V>
+__device__ __forceinline__ void bst_part(rsrc_t r, uint32_t vo, const T (&v)[V], int n) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    if (j < n) {
+      if constexpr (sizeof(T) == 4)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v[j]), r,
+                                              vo + (uint32_t)(j * sizeof(T)), 0, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[j]), r,
+                                              vo + (uint32_t)(j * sizeof(T)), 0, 0);
+    }
+  }
+  asm volatile("s_nop 1");
+}
+
 // Element-wise dual update of a whole vector, out[j] = clamp((p_old[j] + sigma *
 // (hi[j] - lo[j]) * w) / hden), with the float arithmetic issued as packed pairs
 // (v_pk_add_f32 / v_pk_mul_f32).  There is no packed subtract and the compiler
@@ -183,7 +201,7 @@ struct PlaneLoads {          // registers one prefetched plane lands in
 };
 
 template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1, bool PF2,
-          bool UNIT>
+          bool UNIT, bool RAG>
 __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out,
     const T *__restrict__ x_in, T *__restrict__ x_out,
@@ -310,6 +328,32 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   const uint32_t v_right = (rin && row_end && x0 + VEC < G.nx) ? o0 + 16u : kInvalid;
   const uint32_t v_left = (rin && row_beg && x0 > 0) ? o0 - (uint32_t)sizeof(T) : kInvalid;
   const uint32_t v_st = rvalid ? o0 : kInvalid;
+  // RAG: rows are not a multiple of the vector width, so the row's last vector
+  // sticks out by VEC - nval elements (they belong to the next row).  Their xbar
+  // must read as zero -- the zero padding of K -- wherever a valid neighbour looks
+  // at it, and they are left out of the stores; whatever else is computed for
+  // them is read by nobody.  (Accesses are 4-byte aligned then: legal, 90 % of the
+  // aligned rate, tools/micro/unaligned_b128.hip.)
+  int nval = VEC;
+  if constexpr (RAG) {
+    const int64_t left = G.nx - x0;
+    nval = left >= VEC ? VEC : (left > 0 ? (int)left : 0);
+  }
+  auto cut_tail = [&](T (&v)[VEC]) {
+    if constexpr (RAG) {
+#pragma unroll
+      for (int j = 1; j < VEC; ++j) v[j] = j < nval ? v[j] : T(0);
+    }
+  };
+  auto store_vec = [&](rsrc_t r, uint32_t vo, const T (&v)[VEC]) {
+    if constexpr (RAG) {
+      if (nval < VEC) {
+        bst_part<T, VEC>(r, vo, v, nval);
+        return;
+      }
+    }
+    bst<T, VEC>(r, vo, v);
+  };
   // stages >= 2: neighbours inside the footprint come from LDS; beyond it the
   // value is zero (the zero padding of K / K^T at the volume edge) or belongs
   // to a voxel whose result is recomputed by the next footprint and not stored
@@ -378,6 +422,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   }
   uint32_t adv = (uint32_t)(s_first - pz0) * szb;   // scalar offset of plane s
   bld<T, VEC>(r_xb, v_own, adv, CA.xc);
+  cut_tail(CA.xc);
   {
     // p'_z of the plane below the first one (zero at the bottom of the volume)
     T xm[VEC], pm[VEC];
@@ -461,6 +506,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) N.xc[j] = L.xn[j];
+      cut_tail(N.xc);
+      if constexpr (K > 1) cut_tail(fr_xb[0]);
       if constexpr (!PF2) issue_loads(L, more ? s + 1 : s, more ? adv + szb : adv);
     } else {
       zero(fr_xb[0]); zero(fr_x[0]); zero(fr_bt[0]); zero(pzn[0]);
@@ -497,11 +544,12 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         fr_bt[k - 1][j] = P.c_bt[k - 1][j];
         pzn[k - 1][j] = pkz[j];
       }
+      if (k < K) cut_tail(fr_xb[k - 1]);
       if (k == K && f >= zbeg && f < zend) {      // uniform
         const uint32_t vo = v_st + (adv - (uint32_t)(K - 1) * szb);
-        bst<T, VEC>(w_pz, vo, pkz);
-        bst<T, VEC>(w_x, vo, fr_x[K - 1]);
-        bst<T, VEC>(w_xb, vo, fr_xb[K - 1]);
+        store_vec(w_pz, vo, pkz);
+        store_vec(w_x, vo, fr_x[K - 1]);
+        store_vec(w_xb, vo, fr_xb[K - 1]);
       }
     }
 
@@ -569,8 +617,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         const int a = s - (K - 2);
         if (a >= zbeg && a < zend) {              // uniform
           const uint32_t vo = v_st + (adv - (uint32_t)(K - 2) * szb);
-          bst<T, VEC>(w_px, vo, pkx);
-          bst<T, VEC>(w_py, vo, pky);
+          store_vec(w_px, vo, pkx);
+          store_vec(w_py, vo, pky);
         }
       }
     }
@@ -666,7 +714,7 @@ inline bool make_tiling(int64_t nx, int64_t ny, int nt, int vec, int h, int hx,
   Tiling q;
   if (ntx == 1) {
     q.xv = 0;
-    q.lxb = (int)(nx / vec);
+    q.lxb = (int)((nx + vec - 1) / vec);
   } else {
     int64_t xv = xv_fixed > 0 ? xv_fixed : (nx + ntx - 1) / ntx;
     xv = (xv + vec - 1) / vec * vec;
@@ -741,7 +789,7 @@ inline bool al16(const T *a) {
 }
 
 template <typename T, int VEC, int NW, int K, int WPE, bool HUBER, bool L1, bool PF2,
-          bool UNIT>
+          bool UNIT, bool RAG>
 int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
              const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
              const StageScalars<T, K> &S, hipStream_t st) {
@@ -760,21 +808,21 @@ int launch_f(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x
             "zchunk=%lld blocks=%lld slab=%lld model=%.3f GB\n", K, NW, (int)PF2, Q.split, Q.lxb, Q.rows,
             Q.xv, Q.ntx, Q.nty, (long long)c.zchunk, (long long)blocks,
             (long long)slab, c.cost * 1e-9);
-  hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1, PF2, UNIT>),
+  hipLaunchKernelGGL((k_pd_fusedk<T, VEC, NW, K, WPE, HUBER, L1, PF2, UNIT, RAG>),
                      dim3((unsigned)blocks), dim3(NW * 64), 0, st, xbar_in, xbar_out,
                      x_in, x_out, bt, p_in, p_out, G, S, Q, (int)c.zchunk, (int)slab);
   g_launches[K == 3 ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
   return launch_status();
 }
 
-template <typename T, int VEC, int NW, int K, int WPE, bool PF2>
+template <typename T, int VEC, int NW, int K, int WPE, bool PF2, bool RAG>
 int launch_k(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in, T *x_out,
              const T *bt, const T *p_in, T *p_out, const Geom<T> &G,
              const StageScalars<T, K> &S, int flags, hipStream_t st) {
 #define NSOL_F(HB, L)                                                           \
-  (unit ? launch_f<T, VEC, NW, K, WPE, HB, L, PF2, true>(                       \
+  (unit ? launch_f<T, VEC, NW, K, WPE, HB, L, PF2, true, RAG>(                  \
               c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S, st)     \
-        : launch_f<T, VEC, NW, K, WPE, HB, L, PF2, false>(                      \
+        : launch_f<T, VEC, NW, K, WPE, HB, L, PF2, false, RAG>(                 \
               c, xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, S, st))
   const bool unit = G.wx == T(1) && G.wy == T(1) && G.wz == T(1);
   const bool huber = (flags & NSOL_PD_REG_HUBER) != 0;
@@ -796,8 +844,15 @@ int launch_cfg(const Config &c, const T *xbar_in, T *xbar_out, const T *x_in,
                const StageScalars<T, K> &S, int flags, hipStream_t st) {
   constexpr int VW = 16 / sizeof(T);
 #define NSOL_W(NWV, WPE, PF)                                                      \
-  launch_k<T, VW, NWV, K, WPE, PF>(c, xbar_in, xbar_out, x_in, x_out, bt, p_in,     \
-                                   p_out, G, S, flags, st)
+  launch_k<T, VW, NWV, K, WPE, PF, false>(c, xbar_in, xbar_out, x_in, x_out, bt,    \
+                                          p_in, p_out, G, S, flags, st)
+  // rows that are not a multiple of the vector width: 12-wave workgroups only
+  // (candidates() offers nothing else for such shapes)
+  if (G.nx % VW != 0) {
+    if (c.nw != 12) return NSOL_EINVAL;
+    return launch_k<T, VW, 12, K, 3, false, true>(c, xbar_in, xbar_out, x_in, x_out, bt,
+                                                  p_in, p_out, G, S, flags, st);
+  }
   // two prefetch register sets where the register file has room for them
   if (c.nw == 8) return c.pf2 ? NSOL_W(8, 2, true) : NSOL_W(8, 2, false);
   if constexpr (K == 2) {
@@ -827,6 +882,7 @@ std::vector<Config> candidates(const Geom<T> &G) {
   for (int wi = 0; wi < Waves<K>::n; ++wi) {
     const int nw = Waves<K>::v[wi];
     if (g_tunek.nw > 0 && g_tunek.nw != nw) continue;
+    if (G.nx % VW != 0 && nw != 12) continue;     // see launch_cfg
     const int nt = nw * 64;
     const int lxm = nt / (2 * K);
     // tile counts 1..64 with nx spread evenly, plus tiles whose interior is exactly
@@ -1064,11 +1120,15 @@ int fusedk_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T 
       x_in == x_out || k < 2 || k > 3)
     return NSOL_EINVAL;
   constexpr int VW = 16 / sizeof(T);
-  if (!g_tunek.enable || k > g_tunek.kmax || ndim != 3 || nx % VW != 0 ||
+  // (rows that are not a multiple of 16 bytes take the RAG instantiation: their
+  // accesses are 4-byte aligned anyway, so only the element size matters then)
+  const bool rag = nx % VW != 0;
+  if (!g_tunek.enable || k > g_tunek.kmax || ndim != 3 ||
       nz * ny * nx < ((int64_t)g_tunek.min_kvox << 10) ||
-      nx / VW < 8 || ny < 8 || nz < 8 || nz >= ((int64_t)1 << 30) || !al16(xbar_in) || !al16(xbar_out) ||
-      !al16(x_in) || !al16(x_out) || !al16(bt) || !al16(p_out) ||
-      (p_in && !al16(p_in)) || (nz * ny * nx) % VW != 0)
+      nx / VW < 8 || ny < 8 || nz < 8 || nz >= ((int64_t)1 << 30) ||
+      (!rag && (!al16(xbar_in) || !al16(xbar_out) || !al16(x_in) || !al16(x_out) ||
+                !al16(bt) || !al16(p_out) || (p_in && !al16(p_in)) ||
+                (nz * ny * nx) % VW != 0)))
     return -2;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   hipStream_t st = as_stream(stream);

@@ -62,5 +62,9 @@ def test_no_store_data_hazard_in_k_pd_fusedk(tmp_path):
     names = re.findall(r"\.name:\s+(\S+)", text)
     scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
     head = [int(p) for n, p in zip(names, scratch)
-            if "k_pd_fusedkIfLi4ELi12ELi3ELi3ELb0ELb0ELb0ELb1" in n]
+            if "k_pd_fusedkIfLi4ELi12ELi3ELi3ELb0ELb0ELb0ELb1ELb0E" in n]
     assert head == [0], head
+    # its counterpart for rows that are not a multiple of 16 bytes
+    ragged = [int(p) for n, p in zip(names, scratch)
+              if "k_pd_fusedkIfLi4ELi12ELi3ELi3ELb0ELb0ELb0ELb1ELb1E" in n]
+    assert ragged == [0], ragged
