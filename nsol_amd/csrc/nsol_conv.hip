@@ -354,6 +354,22 @@ struct XWindow {
       for (int k = 0; k < VEC; ++k) v[b * VEC + k] = t[k];
     }
   }
+  // the same window element by element with the periodic wrap applied per
+  // element: lanes at the ends of a row whose length is not a multiple of VEC
+  // (ix0 = x index of v[0]; |ix0| < nx)
+  __device__ __forceinline__ void load_edge(rsrc_t r, int ix0, int nx, uint32_t yo) {
+#pragma unroll
+    for (int i = NBH * VEC - R; i <= NBH * VEC + VEC - 1 + R; ++i) {
+      int ix = ix0 + i;
+      ix = ix < 0 ? ix + nx : (ix >= nx ? ix - nx : ix);
+      if constexpr (sizeof(T) == 4)
+        v[i] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(
+                                         r, (uint32_t)ix * 4u + yo, 0, 0));
+      else
+        v[i] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(
+                                         r, (uint32_t)ix * 8u + yo, 0, 0));
+    }
+  }
   __device__ __forceinline__ typename VecOf<T, VEC>::type filter(const Taps<T> &tx) const {
     typename VecOf<T, VEC>::type res;
 #pragma unroll
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap(
 // travel together and the z window moves by PP planes at a time (half the
 // register moves per plane).  124 registers at 13 taps and PP = 2 -- used up to
 // 13 taps (8-byte elements: 11); 0.39 instead of 0.43 ms at 512^3.
-template <typename T, int VEC, int NT, int NW, int PP>
+template <typename T, int VEC, int NT, int NW, int PP, bool RAGX>
 __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
     const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
     Taps<T> tz, Taps<T> ty, Taps<T> tx, int lxb, int ntx, int nty, int zchunk) {
@@ -502,10 +518,25 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
   const int bx = bid % ntx; bid /= ntx;
   const int by = bid % nty;
   const int bz = bid / nty;
-  const int nxv = (int)(nx / VEC);
+  // RAGX: rows are not a multiple of VEC.  Vectors then start at 4-byte aligned
+  // addresses (legal), the row's last vector holds nval < VEC valid elements,
+  // and the lanes whose window crosses an end of the row load it element by
+  // element with the wrap applied per element.
+  const int nxv = RAGX ? (int)((nx + VEC - 1) / VEC) : (int)(nx / VEC);
   const int xv = bx * lxb + lx;                        // own vector along x
   const int64_t y0 = (int64_t)by * tyr;
   const bool owner = xv < nxv && (y0 + row < ny);
+  int nval = VEC;
+  bool edge = false;
+  if constexpr (RAGX) {
+    const int64_t left = nx - (int64_t)xv * VEC;
+    nval = left >= VEC ? VEC : (left > 0 ? (int)left : 0);
+    edge = xv < NBH || (int64_t)(xv + NBH + 1) * VEC > nx;
+  }
+  int ix0 = (xv - NBH) * VEC;                          // x index of the window's v[0]
+  if constexpr (RAGX) {
+    if (ix0 >= (int)nx) ix0 %= (int)nx;                // lanes past the row: any valid window
+  }
   const uint32_t plane_bytes = (uint32_t)(ny * nx * sizeof(T));
   const int64_t plane = ny * nx;
   // one descriptor per plane (base = the plane, 32-bit offsets inside it): no
@@ -518,9 +549,12 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
   uint32_t xo[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    int j = (xv + b - NBH) % nxv;
-    if (j < 0) j += nxv;
-    xo[b] = (uint32_t)j * (uint32_t)(VEC * sizeof(T));
+    int j = xv + b - NBH;
+    if constexpr (!RAGX) {
+      j %= nxv;
+      if (j < 0) j += nxv;
+    }
+    xo[b] = (uint32_t)j * (uint32_t)(VEC * sizeof(T));   // (RAGX: edge lanes do not use it)
   }
   // footprint rows this lane filters along x: `row` (round 0) and `tyr + row`
   // (round 1: the 2R halo rows, the first waves of the workgroup)
@@ -562,7 +596,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
     {
       W w[PP];
 #pragma unroll
-      for (int q = 0; q < PP; ++q) w[q].load(rs[q], xo, yo[0], 0);
+      for (int q = 0; q < PP; ++q) {
+        if (RAGX && edge) w[q].load_edge(rs[q], ix0, (int)nx, yo[0]);
+        else w[q].load(rs[q], xo, yo[0], 0);
+      }
 #pragma unroll
       for (int q = 0; q < PP; ++q)
         *reinterpret_cast<V *>(buf + q * tile + (size_t)row * rowlen + lx * VEC) =
@@ -571,7 +608,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
     if (second_wave) {
       W w[PP];
 #pragma unroll
-      for (int q = 0; q < PP; ++q) w[q].load(rs[q], xo, yo[1], 0);
+      for (int q = 0; q < PP; ++q) {
+        if (RAGX && edge) w[q].load_edge(rs[q], ix0, (int)nx, yo[1]);
+        else w[q].load(rs[q], xo, yo[1], 0);
+      }
 #pragma unroll
       for (int q = 0; q < PP; ++q) {
         const V r1 = w[q].filter(tx);
@@ -603,8 +643,25 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
           if (t + q < NT - 1) acc += tz.w[t] * ring[t + q < NT - 1 ? t + q : 0];
           else acc += tz.w[t] * v[t + q - (NT - 1) < PP ? t + q - (NT - 1) : 0];
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc),
-                                               plane_rsrc(out, z), own_off, 0, 0);
+        if (RAGX && nval < VEC) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const T ae = acc[e];   // (bit_cast of a vector element reads element 0)
+            if (e < nval) {
+              if constexpr (sizeof(T) == 4)
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(unsigned int, ae), plane_rsrc(out, z),
+                    own_off + (uint32_t)(e * sizeof(T)), 0, 0);
+              else
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    __builtin_bit_cast(u32x2, ae), plane_rsrc(out, z),
+                    own_off + (uint32_t)(e * sizeof(T)), 0, 0);
+            }
+          }
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc),
+                                                 plane_rsrc(out, z), own_off, 0, 0);
+        }
         asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
       }
     }
@@ -635,7 +692,7 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                  hipStream_t st) {
   constexpr int NW = 16;
   constexpr int R = NT / 2;
-  const int64_t nxv = nx / VEC;
+  const int64_t nxv = (nx + VEC - 1) / VEC;
   // lanes per row: a power of two up to 32 that covers the row in few tiles
   int lxb = g_blur3_lxb;
   while (lxb > 8 && lxb / 2 >= nxv) lxb /= 2;
@@ -668,8 +725,13 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   if (lds > 150 * 1024) return -2;
   void (*kern)(const T *, T *, int64_t, int64_t, int64_t, Taps<T>, Taps<T>, Taps<T>, int,
                int, int, int);
-  if constexpr (PP == 2) kern = k_blur3_wrap_pp<T, VEC, NT, NW, 2>;
-  else kern = k_blur3_wrap<T, VEC, NT, NW>;
+  if constexpr (PP == 2) {
+    if (nx % VEC != 0) kern = k_blur3_wrap_pp<T, VEC, NT, NW, 2, true>;
+    else kern = k_blur3_wrap_pp<T, VEC, NT, NW, 2, false>;
+  } else {
+    if (nx % VEC != 0) return -2;
+    kern = k_blur3_wrap<T, VEC, NT, NW>;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -692,7 +754,9 @@ int corr3_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   constexpr int VEC = 16 / sizeof(T);
   // longer windows do not pay (the z window alone is ntaps vectors per lane)
   constexpr int kMaxFused = 17;   // 0.60 ms against 0.65 for three passes at 512^3; spills beyond
-  if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > kMaxFused || nx % VEC != 0 ||
+  // (ragged rows: the element-wise wrap of the edge lanes corrects by one period)
+  if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > kMaxFused ||
+      (nx % VEC != 0 && nx < 2 * ntaps + 2 * VEC) ||
       (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return -2;
   Taps<T> tz, ty, tx;

@@ -74,7 +74,11 @@ def test_blur_matches_reference_goldens(nsol, golden):
 @pytest.mark.parametrize("shape,sigma2,dtype", [
     ((20, 37, 64), 2.0, np.float64), ((9, 5, 16), 4.0, np.float64),
     ((33, 70, 132), 1.0, np.float32), ((64, 64, 64), 4.0, np.float32),
-    ((40, 48, 512), 4.0, np.float32), ((7, 100, 24), 0.5, np.float64)])
+    ((40, 48, 512), 4.0, np.float32), ((7, 100, 24), 0.5, np.float64),
+    # rows that are not a multiple of 16 bytes (one and several tiles along x)
+    ((20, 37, 63), 4.0, np.float32), ((24, 70, 131), 4.0, np.float32),
+    ((33, 20, 517), 4.0, np.float32), ((18, 40, 65), 1.0, np.float64),
+    ((12, 30, 41), 2.0, np.float32)])
 def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
     """nsol_corr3_wrap_* (x, y, z passes fused, periodic) against the three
     nsol_corr_axis_* launches and against the oracle's dense convolution:
