@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_final_big(const double *ws,
 }
 
 // u_top = c_av*Av + c_u*u_top ; u_bot = c_bv*B(v) + c_u*u_bot ; sum of squares
-template <typename T, int VEC, int ROWS>
+template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_lsmr_u(
     const T *__restrict__ Av, const T *__restrict__ v, T *__restrict__ u_top,
     T *__restrict__ u_bot, Geom<T> G, int bmode, T c_av, T c_bv, T c_u,
@@ -98,46 +98,46 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
     if (!c.ok) continue;
     {
     T a[VEC], u[VEC];
-    vload<T, VEC>(Av + c.i, a);
-    vload<T, VEC>(u_top + c.i, u);
+    vl<RAG, T, VEC>(c.nval, Av + c.i, a);
+    vl<RAG, T, VEC>(c.nval, u_top + c.i, u);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       u[k] = c_av * a[k] + c_u * u[k];
-      acc += (double)u[k] * (double)u[k];
+      if (!RAG || k < c.nval) acc += (double)u[k] * (double)u[k];
     }
-    vstore<T, VEC>(u_top + c.i, u);
+    vs<RAG, T, VEC>(c.nval, u_top + c.i, u);
     if (bmode == kBIdentity) {
-      vload<T, VEC>(v + c.i, a);
-      vload<T, VEC>(u_bot + c.i, u);
+      vl<RAG, T, VEC>(c.nval, v + c.i, a);
+      vl<RAG, T, VEC>(c.nval, u_bot + c.i, u);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         u[k] = c_bv * a[k] + c_u * u[k];
-        acc += (double)u[k] * (double)u[k];
+        if (!RAG || k < c.nval) acc += (double)u[k] * (double)u[k];
       }
-      vstore<T, VEC>(u_bot + c.i, u);
+      vs<RAG, T, VEC>(c.nval, u_bot + c.i, u);
     } else if (bmode == kBGrad) {
       T vc[VEC], hi[VEC], d[VEC];
-      vload<T, VEC>(v + c.i, vc);
+      vl<RAG, T, VEC>(c.nval, v + c.i, vc);
       for (int dir = 0; dir < G.ndim; ++dir) {
         if (dir == 0) {
           const T right = (c.ix + VEC < G.nx) ? v[c.i + VEC] : T(0);
           fwd_diff_x<T, VEC>(vc, right, G.wx, d);
         } else if (dir == 1) {
           vzero(hi);
-          if (c.iy + 1 < G.ny) vload<T, VEC>(v + c.i + G.sy, hi);
+          if (c.iy + 1 < G.ny) vl<RAG, T, VEC>(c.nval, v + c.i + G.sy, hi);
           fwd_diff<T, VEC>(vc, hi, G.wy, d);
         } else {
           vzero(hi);
-          if (c.iz + 1 < G.nz) vload<T, VEC>(v + c.i + G.sz, hi);
+          if (c.iz + 1 < G.nz) vl<RAG, T, VEC>(c.nval, v + c.i + G.sz, hi);
           fwd_diff<T, VEC>(vc, hi, G.wz, d);
         }
-        vload<T, VEC>(u_bot + dir * G.n + c.i, u);
+        vl<RAG, T, VEC>(c.nval, u_bot + dir * G.n + c.i, u);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           u[k] = c_bv * d[k] + c_u * u[k];
-          acc += (double)u[k] * (double)u[k];
+          if (!RAG || k < c.nval) acc += (double)u[k] * (double)u[k];
         }
-        vstore<T, VEC>(u_bot + dir * G.n + c.i, u);
+        vs<RAG, T, VEC>(c.nval, u_bot + dir * G.n + c.i, u);
       }
     }
     }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
 }
 
 // v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v ; sum of squares
-template <typename T, int VEC, int ROWS>
+template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_lsmr_v(
     const T *__restrict__ Atu, const T *__restrict__ u_bot, T *__restrict__ v,
     Geom<T> G, int bmode, T c_atu, T c_btu, T c_v, double *ws) {
@@ -157,16 +157,16 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_v(
     if (!c.ok) continue;
     {
     T val[VEC], t[VEC], lo[VEC];
-    vload<T, VEC>(Atu + c.i, t);
+    vl<RAG, T, VEC>(c.nval, Atu + c.i, t);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) val[k] = c_atu * t[k];
     if (bmode == kBIdentity) {
-      vload<T, VEC>(u_bot + c.i, t);
+      vl<RAG, T, VEC>(c.nval, u_bot + c.i, t);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) val[k] += c_btu * t[k];
     } else if (bmode == kBGrad) {
       T kt[VEC];
-      vload<T, VEC>(u_bot + c.i, t);
+      vl<RAG, T, VEC>(c.nval, u_bot + c.i, t);
       const T left = (c.ix > 0) ? u_bot[c.i - 1] : T(0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -175,30 +175,30 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_v(
       }
       if (G.ndim >= 2) {
         const T *py = u_bot + G.n;
-        vload<T, VEC>(py + c.i, t);
+        vl<RAG, T, VEC>(c.nval, py + c.i, t);
         vzero(lo);
-        if (c.iy > 0) vload<T, VEC>(py + c.i - G.sy, lo);
+        if (c.iy > 0) vl<RAG, T, VEC>(c.nval, py + c.i - G.sy, lo);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) kt[k] += t[k] * (-G.wy) + lo[k] * G.wy;
       }
       if (G.ndim >= 3) {
         const T *pz = u_bot + 2 * G.n;
-        vload<T, VEC>(pz + c.i, t);
+        vl<RAG, T, VEC>(c.nval, pz + c.i, t);
         vzero(lo);
-        if (c.iz > 0) vload<T, VEC>(pz + c.i - G.sz, lo);
+        if (c.iz > 0) vl<RAG, T, VEC>(c.nval, pz + c.i - G.sz, lo);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) kt[k] += t[k] * (-G.wz) + lo[k] * G.wz;
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) val[k] += c_btu * kt[k];
     }
-    vload<T, VEC>(v + c.i, t);
+    vl<RAG, T, VEC>(c.nval, v + c.i, t);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       val[k] += c_v * t[k];
-      acc += (double)val[k] * (double)val[k];
+      if (!RAG || k < c.nval) acc += (double)val[k] * (double)val[k];
     }
-    vstore<T, VEC>(v + c.i, val);
+    vs<RAG, T, VEC>(c.nval, v + c.i, val);
     }
   }
   store_partial3(acc, ws);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_hx(T *__restrict__ hbar,
 // robust-loss objective (tikhonov_linear_solver.py:201-208 with B = grad).
 // Every difference is rounded as k_grad stores it and combined in the order of
 // k_grad_adj and nsol_lincomb2, so grad equals the three-kernel result bit for bit.
-template <typename T, int VEC, int ROWS>
+template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
                                                      const T *g, T *grad, Geom<T> G,
                                                      T alpha, double *ws) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
     T v[VEC], nb[VEC], d[VEC], dp[VEC], out[VEC];
-    vload<T, VEC>(x + c.i, v);
+    vl<RAG, T, VEC>(c.nval, x + c.i, v);
     // x: forward differences at the lane's voxels and at the voxel to the left
     const T right = (c.ix + VEC < G.nx) ? x[c.i + VEC] : T(0);
     fwd_diff_x<T, VEC>(v, right, G.wx, d);
@@ -252,42 +252,42 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     for (int k = 0; k < VEC; ++k) {
       const T l = (k > 0) ? d[(k + VEC - 1) % VEC] : dleft;
       out[k] = d[k] * (-G.wx) + l * G.wx;
-      acc += (double)d[k] * (double)d[k];
+      if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
     }
     if (G.ndim >= 2) {
       vzero(nb);
-      if (c.iy + 1 < G.ny) vload<T, VEC>(x + c.i + G.sy, nb);
+      if (c.iy + 1 < G.ny) vl<RAG, T, VEC>(c.nval, x + c.i + G.sy, nb);
       fwd_diff<T, VEC>(v, nb, G.wy, d);
       vzero(dp);
       if (c.iy > 0) {
-        vload<T, VEC>(x + c.i - G.sy, nb);
+        vl<RAG, T, VEC>(c.nval, x + c.i - G.sy, nb);
         fwd_diff<T, VEC>(nb, v, G.wy, dp);
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         out[k] += d[k] * (-G.wy) + dp[k] * G.wy;
-        acc += (double)d[k] * (double)d[k];
+        if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
       }
     }
     if (G.ndim >= 3) {
       vzero(nb);
-      if (c.iz + 1 < G.nz) vload<T, VEC>(x + c.i + G.sz, nb);
+      if (c.iz + 1 < G.nz) vl<RAG, T, VEC>(c.nval, x + c.i + G.sz, nb);
       fwd_diff<T, VEC>(v, nb, G.wz, d);
       vzero(dp);
       if (c.iz > 0) {
-        vload<T, VEC>(x + c.i - G.sz, nb);
+        vl<RAG, T, VEC>(c.nval, x + c.i - G.sz, nb);
         fwd_diff<T, VEC>(nb, v, G.wz, dp);
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         out[k] += d[k] * (-G.wz) + dp[k] * G.wz;
-        acc += (double)d[k] * (double)d[k];
+        if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
       }
     }
-    vload<T, VEC>(g + c.i, nb);
+    vl<RAG, T, VEC>(c.nval, g + c.i, nb);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) out[k] = T(1) * nb[k] + alpha * out[k];
-    vstore<T, VEC>(grad + c.i, out);
+    vs<RAG, T, VEC>(c.nval, grad + c.i, out);
   }
   store_partial3(acc, ws);
 }
@@ -319,10 +319,11 @@ int u_impl(const T *Av, const T *v, T *u_top, T *u_bot, int bmode, int ndim,
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool al = ptr16(Av) && ptr16(u_top) && (!v || ptr16(v)) &&
                   (!u_bot || ptr16(u_bot)) && G.n % 4 == 0;
-  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
     const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
-    hipLaunchKernelGGL((k_lsmr_u<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+    hipLaunchKernelGGL((k_lsmr_u<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), Av, v, u_top, u_bot, G,
                        bmode, (T)c_av, (T)c_bv, (T)c_u, ws);
     hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
@@ -343,10 +344,11 @@ int v_impl(const T *Atu, const T *u_bot, T *v, int bmode, int ndim, int64_t nz,
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool al = ptr16(Atu) && ptr16(v) && (!u_bot || ptr16(u_bot)) &&
                   G.n % 4 == 0;
-  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
     const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
-    hipLaunchKernelGGL((k_lsmr_v<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+    hipLaunchKernelGGL((k_lsmr_v<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), Atu, u_bot, v, G, bmode,
                        (T)c_atu, (T)c_btu, (T)c_v, ws);
     hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
@@ -379,10 +381,11 @@ int tk1_reg_impl(const T *x, const T *g, T *grad, int ndim, int64_t nz, int64_t 
   if (!x || !g || !grad || !result || !ws || x == grad) return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool al = ptr16(x) && ptr16(g) && ptr16(grad) && G.n % 4 == 0;
-  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
     const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
-    hipLaunchKernelGGL((k_tk1_reg<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+    hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), x, g, grad, G, (T)alpha, ws);
     hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
                        nb, result);

@@ -14,7 +14,7 @@ namespace {
 
 // ---------------------------------------------------------------- grad ----
 // reference: linear_operators.py:98-106 (D_a = convolve(x, [1,-1]/h, "constant"))
-template <typename T, int VEC, int ROWS>
+template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_grad(const T *__restrict__ x,
                                                   T *__restrict__ g, Geom<T> G) {
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
@@ -22,33 +22,33 @@ __global__ __launch_bounds__(kBlock) void k_grad(const T *__restrict__ x,
   const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
   if (!c.ok) continue;
   T v[VEC], hi[VEC], d[VEC];
-  vload<T, VEC>(x + c.i, v);
+  vl<RAG, T, VEC>(c.nval, x + c.i, v);
   const T right = (c.ix + VEC < G.nx) ? x[c.i + VEC] : T(0);
   fwd_diff_x<T, VEC>(v, right, G.wx, d);
-  vstore<T, VEC>(g + c.i, d);
+  vs<RAG, T, VEC>(c.nval, g + c.i, d);
   if (G.ndim >= 2) {
     vzero(hi);
-    if (c.iy + 1 < G.ny) vload<T, VEC>(x + c.i + G.sy, hi);
+    if (c.iy + 1 < G.ny) vl<RAG, T, VEC>(c.nval, x + c.i + G.sy, hi);
     fwd_diff<T, VEC>(v, hi, G.wy, d);
-    vstore<T, VEC>(g + G.n + c.i, d);
+    vs<RAG, T, VEC>(c.nval, g + G.n + c.i, d);
   }
   if (G.ndim >= 3) {
     vzero(hi);
-    if (c.iz + 1 < G.nz) vload<T, VEC>(x + c.i + G.sz, hi);
+    if (c.iz + 1 < G.nz) vl<RAG, T, VEC>(c.nval, x + c.i + G.sz, hi);
     fwd_diff<T, VEC>(v, hi, G.wz, d);
-    vstore<T, VEC>(g + 2 * G.n + c.i, d);
+    vs<RAG, T, VEC>(c.nval, g + 2 * G.n + c.i, d);
   }
   }
 }
 
 // K^T at the lane's VEC voxels: sum over a of p_a[i]*(-w_a) + p_a[i-e_a]*w_a,
 // accumulated x, y, z as linear_operators.py:158-169 does (`D_adj_x += ...`)
-template <typename T, int VEC>
+template <bool RAG, typename T, int VEC>
 __device__ __forceinline__ void grad_adj_vec(const T *__restrict__ p,
                                              const Geom<T> &G, const Voxel &c,
                                              T (&acc)[VEC]) {
   T v[VEC], lo[VEC];
-  vload<T, VEC>(p + c.i, v);
+  vl<RAG, T, VEC>(c.nval, p + c.i, v);
   const T left = (c.ix > 0) ? p[c.i - 1] : T(0);
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
@@ -57,23 +57,23 @@ __device__ __forceinline__ void grad_adj_vec(const T *__restrict__ p,
   }
   if (G.ndim >= 2) {
     const T *py = p + G.n;
-    vload<T, VEC>(py + c.i, v);
+    vl<RAG, T, VEC>(c.nval, py + c.i, v);
     vzero(lo);
-    if (c.iy > 0) vload<T, VEC>(py + c.i - G.sy, lo);
+    if (c.iy > 0) vl<RAG, T, VEC>(c.nval, py + c.i - G.sy, lo);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k] * (-G.wy) + lo[k] * G.wy;
   }
   if (G.ndim >= 3) {
     const T *pz = p + 2 * G.n;
-    vload<T, VEC>(pz + c.i, v);
+    vl<RAG, T, VEC>(c.nval, pz + c.i, v);
     vzero(lo);
-    if (c.iz > 0) vload<T, VEC>(pz + c.i - G.sz, lo);
+    if (c.iz > 0) vl<RAG, T, VEC>(c.nval, pz + c.i - G.sz, lo);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k] * (-G.wz) + lo[k] * G.wz;
   }
 }
 
-template <typename T, int VEC, int ROWS>
+template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
                                                       T *__restrict__ out,
                                                       Geom<T> G) {
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
     T acc[VEC];
-    grad_adj_vec<T, VEC>(p, G, c, acc);
-    vstore<T, VEC>(out + c.i, acc);
+    grad_adj_vec<RAG, T, VEC>(p, G, c, acc);
+    vs<RAG, T, VEC>(c.nval, out + c.i, acc);
   }
 }
 
@@ -187,7 +187,7 @@ inline int reduce_grid(int64_t n) {
 
 // ------------------------------------------------------------------ ADMM ----
 // admm_linear_solver.py:208-216 with grad fused in
-template <typename T, int VEC, int ROWS>
+template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
                                                      T *__restrict__ v,
                                                      T *__restrict__ w,
@@ -201,25 +201,25 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
   if (!q.ok) continue;
   T xc[VEC], hi[VEC];
   T t[3][VEC], cc[3][VEC];
-  vload<T, VEC>(x + q.i, xc);
+  vl<RAG, T, VEC>(q.nval, x + q.i, xc);
   const T right = (q.ix + VEC < G.nx) ? x[q.i + VEC] : T(0);
   fwd_diff_x<T, VEC>(xc, right, G.wx, t[0]);
   if (G.ndim >= 2) {
     vzero(hi);
-    if (q.iy + 1 < G.ny) vload<T, VEC>(x + q.i + G.sy, hi);
+    if (q.iy + 1 < G.ny) vl<RAG, T, VEC>(q.nval, x + q.i + G.sy, hi);
     fwd_diff<T, VEC>(xc, hi, G.wy, t[1]);
   }
   if (G.ndim >= 3) {
     vzero(hi);
-    if (q.iz + 1 < G.nz) vload<T, VEC>(x + q.i + G.sz, hi);
+    if (q.iz + 1 < G.nz) vl<RAG, T, VEC>(q.nval, x + q.i + G.sz, hi);
     fwd_diff<T, VEC>(xc, hi, G.wz, t[2]);
   }
   T n2[VEC];
   for (int a = 0; a < G.ndim; ++a) {
     T wv[VEC];
     vzero(cc[a]);
-    if (c) vload<T, VEC>(c + a * G.n + q.i, cc[a]);
-    vload<T, VEC>(w + a * G.n + q.i, wv);
+    if (c) vl<RAG, T, VEC>(q.nval, c + a * G.n + q.i, cc[a]);
+    vl<RAG, T, VEC>(q.nval, w + a * G.n + q.i, wv);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       t[a][k] = t[a][k] + wv[k] - cc[a][k];
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
       wa[k] = t[a][k] - va[k];
       ra[k] = rhs_scale * (va[k] - wa[k] + cc[a][k]);
     }
-    vstore<T, VEC>(v + a * G.n + q.i, va);
-    vstore<T, VEC>(w + a * G.n + q.i, wa);
-    if (rhs) vstore<T, VEC>(rhs + a * G.n + q.i, ra);
+    vs<RAG, T, VEC>(q.nval, v + a * G.n + q.i, va);
+    vs<RAG, T, VEC>(q.nval, w + a * G.n + q.i, wa);
+    if (rhs) vs<RAG, T, VEC>(q.nval, rhs + a * G.n + q.i, ra);
   }
   }
 }
@@ -477,9 +477,10 @@ int grad_impl(const T *x, T *g, int ndim, int64_t nz, int64_t ny, int64_t nx,
   if (!x || !g) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   return dispatch_stencil<T>(nz, ny, nx, ptr16(x) && ptr16(g) && G.n % 4 == 0,
-                             [&](auto vec, auto rows) {
+                             [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
-    hipLaunchKernelGGL((k_grad<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+    constexpr bool RG = decltype(rag)::value;
+    hipLaunchKernelGGL((k_grad<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), x, g, G);
     return launch_status();
   });
@@ -492,9 +493,10 @@ int grad_adj_impl(const T *p, T *out, int ndim, int64_t nz, int64_t ny,
   if (!p || !out) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   return dispatch_stencil<T>(nz, ny, nx, ptr16(p) && ptr16(out) && G.n % 4 == 0,
-                             [&](auto vec, auto rows) {
+                             [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
-    hipLaunchKernelGGL((k_grad_adj<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+    constexpr bool RG = decltype(rag)::value;
+    hipLaunchKernelGGL((k_grad_adj<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), p, out, G);
     return launch_status();
   });
@@ -532,9 +534,10 @@ int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool al = ptr16(x) && ptr16(v) && ptr16(w) && (!c || ptr16(c)) &&
                   (!rhs || ptr16(rhs)) && G.n % 4 == 0;
-  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows) {
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
-    hipLaunchKernelGGL((k_admm_vw<T, V, R>), (stencil_grid<V, R>(nz, ny, nx)),
+    constexpr bool RG = decltype(rag)::value;
+    hipLaunchKernelGGL((k_admm_vw<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), x, v, w, c, rhs, G,
                        (T)thr, (T)rhs_scale);
     return launch_status();

@@ -51,7 +51,48 @@ __device__ __forceinline__ void vzero(T (&v)[V]) {
 struct Voxel {
   int64_t ix, iy, iz, i;
   bool ok;
+  int nval;   // elements of the lane's vector that lie inside the row (VEC unless ragged)
 };
+
+// Rows that are not a multiple of the vector width (RAG kernels): vectors start
+// at addresses that are only element-aligned (legal for global accesses) and the
+// row's last vector holds n < V valid elements -- those are moved one by one, the
+// rest reads as zero and is not written.
+template <bool RAG, typename T, int V>
+__device__ __forceinline__ void vl(int n, const T *p, T (&v)[V]) {
+  if constexpr (!RAG) {
+    vload<T, V>(p, v);
+  } else {
+    if (n >= V) {
+      typedef T P __attribute__((ext_vector_type(V), aligned(sizeof(T))));
+      const P t = *reinterpret_cast<const P *>(p);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = t[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = k < n ? p[k] : T(0);
+    }
+  }
+}
+
+template <bool RAG, typename T, int V>
+__device__ __forceinline__ void vs(int n, T *p, const T (&v)[V]) {
+  if constexpr (!RAG) {
+    vstore<T, V>(p, v);
+  } else {
+    if (n >= V) {
+      typedef T P __attribute__((ext_vector_type(V), aligned(sizeof(T))));
+      P t;
+#pragma unroll
+      for (int k = 0; k < V; ++k) t[k] = v[k];
+      *reinterpret_cast<P *>(p) = t;
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k)
+        if (k < n) p[k] = v[k];
+    }
+  }
+}
 
 // Row groups (ROWS consecutive rows of one z-plane) are dealt to blockIdx.y
 // grid-stride: rg = blockIdx.y, blockIdx.y + gridDim.y, ...  A row longer than
@@ -87,6 +128,8 @@ __device__ __forceinline__ Voxel voxel_at(const Geom<T> &G, int64_t rg) {
   c.ix = (((int64_t)xo * gridDim.x + blockIdx.x) * XT + (threadIdx.x % XT)) * VEC;
   c.ok = c.ix < G.nx && c.iy < G.ny;
   c.i = (c.iz * G.ny + c.iy) * G.nx + c.ix;
+  const int64_t left = G.nx - c.ix;
+  c.nval = left >= VEC ? VEC : (int)left;
   return c;
 }
 
@@ -123,13 +166,21 @@ inline int dispatch_stencil(int64_t nz, int64_t ny, int64_t nx, bool aligned,
                             F f) {
   if (!stencil_grid_ok(nz, ny, nx)) return NSOL_EINVAL;
   constexpr int VW = 16 / sizeof(T);
+  typedef std::integral_constant<bool, false> No;
+  typedef std::integral_constant<bool, true> Yes;
+  // `aligned`: every array starts 16-byte aligned.  Otherwise, and for rows that
+  // are not a multiple of the vector width, the RAG instantiation runs
+  // (element-aligned vectors, ragged tail)
   const bool vec = aligned && (nx % VW == 0);
+  const bool rag = !vec && VW > 1 && nx >= 4 * VW;
   if (ny == 1) {
-    if (vec) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 1>());
-    return f(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+    if (vec) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 1>(), No());
+    if (rag) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 1>(), Yes());
+    return f(std::integral_constant<int, 1>(), std::integral_constant<int, 1>(), No());
   }
-  if (vec) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 4>());
-  return f(std::integral_constant<int, 1>(), std::integral_constant<int, 4>());
+  if (vec) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 4>(), No());
+  if (rag) return f(std::integral_constant<int, VW>(), std::integral_constant<int, 4>(), Yes());
+  return f(std::integral_constant<int, 1>(), std::integral_constant<int, 4>(), No());
 }
 
 // forward difference of the lane's VEC voxels along x/y/z, reference order

@@ -1018,7 +1018,8 @@ def test_full_size_512_properties(nsol):
 
 @pytest.mark.parametrize("shape", [(1000,), (7,), (33, 20), (64, 256),
                                    (7, 10, 13), (24, 20, 64), (5, 3, 260),
-                                   (1, 1, 8), (2, 1, 4), (40, 33, 132)])
+                                   (1, 1, 8), (2, 1, 4), (40, 33, 132),
+                                   (9, 11, 131), (6, 50, 259), (3, 1031)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fused_tk1_regulariser_is_bit_identical(nsol, shape, dtype):
     """nsol_tk1_reg_cost_grad_* (one pass) against grad -> dot -> grad_adj ->
@@ -1096,6 +1097,56 @@ def test_unaligned_mid_size_volumes(nsol, shape):
     lhs = ops.dot(A(x.view(shape)).reshape(-1), y)
     rhs = ops.dot(x, A(y.view(shape)).reshape(-1))
     assert abs(lhs - rhs) / abs(lhs) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(30, 41, 131), (12, 20, 517), (64, 259)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ragged_rows_in_the_stencil_kernels(nsol, shape, dtype):
+    """Rows that are not a multiple of 16 bytes run the stencil kernels with
+    element-aligned vectors and a ragged tail: grad / grad_adj and the fused ADMM
+    update against the scalar kernels' semantics (NumPy), the fused LSMR solve
+    against the generic vector kernels."""
+    import torch
+    import nsol_amd.tikhonov_linear_solver as tk
+    from nsol_amd import ops
+    from oracle import nsol_oracle as orc
+    nd = len(shape)
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(n)
+    xh = rng.standard_normal(shape).astype(dtype)
+    ph = rng.standard_normal((nd * shape[0],) + shape[1:]).astype(dtype)
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    x = torch.from_numpy(xh.reshape(-1)).cuda()
+    p = torch.from_numpy(ph.reshape(-1)).cuda()
+    w = (1.0, 1.0, 1.0)
+    assert np.array_equal(ops.grad(x, shape, w).cpu().numpy(),
+                          orc.grad(xh).reshape(-1).astype(dtype))
+    ga = ops.grad_adj(p, shape, w)
+    ga_ref = orc.grad_adj(ph.astype(np.float64)).reshape(-1)
+    if dtype == np.float64:
+        assert np.array_equal(ga.cpu().numpy(), ga_ref)
+    else:
+        assert rel_l2(ga.cpu().numpy(), ga_ref) < 2e-7
+    # fused LSMR (k_lsmr_u / k_lsmr_v on the ragged rows) vs the generic kernels
+    lo = _lo(nd)
+    grad, grad_adj = lo.get_gradient_operators()
+    Z = (nd * shape[0],) + tuple(shape[1:])
+    ident = lambda v: v.flatten()
+    D_ = lambda v: grad(v.reshape(*shape)).flatten()
+    Da_ = lambda v: grad_adj(v.reshape(*Z)).flatten()
+    b = torch.rand(n, device="cuda", dtype=td)
+    outs = []
+    for fused in (True, False):
+        tk.USE_FUSED_LSMR = fused
+        try:
+            s = tk.TikhonovLinearSolver(A=ident, A_adj=ident, B=D_, B_adj=Da_, b=b,
+                                        x0=b, alpha=0.3, iter_max=8, dtype=dtype)
+            s.run()
+            outs.append(s.get_x_device())
+        finally:
+            tk.USE_FUSED_LSMR = True
+    d = ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, outs[1])) / ops.norm2(outs[1])
+    assert d < (2e-6 if dtype == np.float32 else 1e-12)
 
 
 def test_large_2d_image(nsol):
