@@ -721,12 +721,14 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   if (blocks > 0x7fffffff) return -2;
   // two planes per step where the registers allow it
   constexpr int PP = (NT >= 5 && NT <= (sizeof(T) == 4 ? 13 : 11)) ? 2 : 1;
-  const size_t lds = 2 * PP * (size_t)(tyr + 2 * R) * lxb * VEC * sizeof(T);
+  // (ragged rows: one plane per step, the element-wise edge path needs the registers)
+  const int pp = (PP == 2 && nx % VEC != 0) ? 1 : PP;
+  const size_t lds = 2 * pp * (size_t)(tyr + 2 * R) * lxb * VEC * sizeof(T);
   if (lds > 150 * 1024) return -2;
   void (*kern)(const T *, T *, int64_t, int64_t, int64_t, Taps<T>, Taps<T>, Taps<T>, int,
                int, int, int);
   if constexpr (PP == 2) {
-    if (nx % VEC != 0) kern = k_blur3_wrap_pp<T, VEC, NT, NW, 2, true>;
+    if (nx % VEC != 0) kern = k_blur3_wrap_pp<T, VEC, NT, NW, 1, true>;
     else kern = k_blur3_wrap_pp<T, VEC, NT, NW, 2, false>;
   } else {
     if (nx % VEC != 0) return -2;
