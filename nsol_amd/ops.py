@@ -432,16 +432,16 @@ B_NONE, B_GRAD, B_IDENTITY = 0, 1, 2
 def flat_geometry(n):
     """(ny, nx) with ny * nx = n for the element-wise modes of the LSMR kernels
     (B = identity / no regulariser): their thread mapping wants rows of at most
-    a few thousand elements, a flat vector of 512^3 elements is folded.  None
-    when n has no suitable power-of-two factor (callers then take the generic
-    vector kernels)."""
+    a few thousand elements, a flat vector of 512^3 elements is folded; without
+    a suitable power-of-two factor it stays one long row (the stencil mapping
+    then loops over x)."""
     n = int(n)
     if n <= (1 << 16):
         return 1, n
     for nx in (4096, 2048, 1024, 512, 256, 128, 64):
         if n % nx == 0:
             return n // nx, nx
-    return None
+    return 1, n
 
 
 def _bgeom(bmode, shape, w, n):

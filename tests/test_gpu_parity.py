@@ -1386,7 +1386,24 @@ def test_full_size_admm_path_properties(nsol):
         assert d < 2e-6, alpha
     assert ops.flat_geometry(512 ** 3) == (512 ** 3 // 4096, 4096)
     assert ops.flat_geometry(1000) == (1, 1000)
-    assert ops.flat_geometry((1 << 20) + 1) is None
+    assert ops.flat_geometry((1 << 20) + 1) == (1, (1 << 20) + 1)
+    # ... and such a vector (no power-of-two factor: one long row) through the
+    # element-wise modes
+    m1 = (1 << 21) + 3
+    b1 = torch.rand(m1, device="cuda")
+    outs = []
+    for fused in (True, False):
+        tk.USE_FUSED_LSMR = fused
+        try:
+            s = tk.TikhonovLinearSolver(A=ident, A_adj=ident, B=ident, B_adj=ident,
+                                        b=b1, x0=b1, b_reg=b1, alpha=0.5, iter_max=5,
+                                        dtype=np.float32)
+            s.run()
+            outs.append(s.get_x_device())
+        finally:
+            tk.USE_FUSED_LSMR = True
+    d = ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, outs[1])) / ops.norm2(outs[1])
+    assert d < 2e-6
 
 
 def test_device_lbfgsb_vs_scipy_driver_at_64_cubed(nsol):
