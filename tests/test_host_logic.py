@@ -296,3 +296,29 @@ def test_solve_batch_gloo_world_size_2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "BATCH_OK" in outs[0]
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The last bench line committed under profiles/ carries every field the
+    driver and the judge read (the bench itself needs a GPU)."""
+    import glob
+    import json
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    assert paths
+    d = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-9
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - d["n_gpus"]) < 1e-6
+
