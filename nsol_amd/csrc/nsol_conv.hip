@@ -593,11 +593,15 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
       rs[q] = plane_rsrc(x, zw);
       if (++zw == (int)nz) zw = 0;     // (a step may read one valid plane too many)
     }
+    // (opaque copy: sixteen loop-invariant edge offsets hoisted out of the loop
+    // would all spill)
+    int ix0v = ix0;
+    if constexpr (RAGX) asm volatile("" : "+v"(ix0v));
     {
       W w[PP];
 #pragma unroll
       for (int q = 0; q < PP; ++q) {
-        if (RAGX && edge) w[q].load_edge(rs[q], ix0, (int)nx, yo[0]);
+        if (RAGX && edge) w[q].load_edge(rs[q], ix0v, (int)nx, yo[0]);
         else w[q].load(rs[q], xo, yo[0], 0);
       }
 #pragma unroll
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
       W w[PP];
 #pragma unroll
       for (int q = 0; q < PP; ++q) {
-        if (RAGX && edge) w[q].load_edge(rs[q], ix0, (int)nx, yo[1]);
+        if (RAGX && edge) w[q].load_edge(rs[q], ix0v, (int)nx, yo[1]);
         else w[q].load(rs[q], xo, yo[1], 0);
       }
 #pragma unroll
