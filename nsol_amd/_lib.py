@@ -92,8 +92,31 @@ def check(rc, what):
         raise NsolHipError("%s failed with hipError_t %d" % (what, rc))
 
 
+# every experiment knob of the library with the default it is built with
+# (nsol_pd.hip PdTuning, nsol_pd2.hip / nsol_pdk.hip Tuning, nsol_conv.hip globals)
+PARAM_DEFAULTS = {
+    "pd_zchunk": 0, "pd_ry": 0, "pd_two_pass": 0, "pd_xcd_map": 1,
+    "max_grid_blocks": 2048,
+    "pd2_zchunk": 0, "pd2_enable": 1, "pd2_variant": 0, "pd2_xcd_map": 1,
+    "pdk_enable": 1, "pdk_kmax": 3, "pdk_nw": 0, "pdk_zchunk": 0, "pdk_ntx": 0,
+    "pdk_xcd_map": 1, "pdk_verbose": 0, "pdk_autotune": 1, "pdk_pf2": -1,
+    "pdk_split": -1, "pdk_min_kvox": 1024, "pdk_tune_min_mvox": 16,
+    "corr_ra": 8, "corr_xv": 1, "corr_blur3_lxb": 16, "corr_blur3_zchunk": 0,
+}
+_touched = set()
+
+
+def reset_params():
+    """Put every knob a caller changed back to its built-in default."""
+    for name in sorted(_touched):
+        set_param(name, PARAM_DEFAULTS[name])
+    _touched.clear()
+
+
 def set_param(name, value):
     lib = load()
+    if name in PARAM_DEFAULTS:
+        _touched.add(name)
     if name.startswith("pd2_"):
         fn = lib.nsol_hip_set_param_pd2
     elif name.startswith("pdk_"):

@@ -621,6 +621,102 @@ def admm(A, A_adj, B, B_adj, b, x0, dimension, b_reg=0., alpha=0.01,
 
 
 # --------------------------------------------------------------------------
+# Generic primal-dual loop with caller-supplied proxes (PD deconvolution:
+# prox_f = prox_linear_least_squares, interface :257-280, solvers_test.py:146-158)
+# --------------------------------------------------------------------------
+def prox_linear_least_squares(x, tau, A, A_adj, b, x0, iter_max=10,
+                              x_scale=1., bounds=(0, np.inf)):
+    """proximal_operators.py:43-78: Tikhonov solve with B = I, b_reg = x,
+    alpha = 1/tau.  As in the reference, data and start are divided by x_scale
+    here AND x_scale is handed on to the solver, which divides b, x0 and b_reg
+    once more and multiplies its result by x_scale (:62-78)."""
+    ident = lambda v: v.reshape(-1)
+    x_scale = float(x_scale)
+    return tikhonov(A, A_adj, ident, ident, np.asarray(b) / x_scale,
+                    np.asarray(x0) / x_scale, alpha=1. / tau, b_reg=x,
+                    iter_max=iter_max, x_scale=x_scale, bounds=bounds)
+
+
+def primal_dual(prox_f, prox_g_conj, B, B_conj, L2, x0, alpha=0.01,
+                iterations=10, x_scale=1., alg_type="ALG2"):
+    """primal_dual_solver.py:215-263 with flat callables; returns x * x_scale."""
+    x_scale = float(x_scale)
+    lmbda = 1. / float(alpha)
+    sig, ta, th = pd_schedule(alg_type, L2, lmbda, iterations)
+    x = np.array(x0, dtype=np.float64) / x_scale
+    xbar = x.copy()
+    p = 0
+    for n in range(iterations):
+        p = prox_g_conj(p + sig[n] * B(xbar), sig[n])
+        xn = prox_f(x - ta[n] * B_conj(p), ta[n] * lmbda)
+        xbar = xn + th[n] * (xn - x)
+        x = xn
+    return x * x_scale
+
+
+# --------------------------------------------------------------------------
+# Regulariser values and similarity measures (observer side, SURVEY 8(f3))
+# --------------------------------------------------------------------------
+def _sum_sq_split(Dx, dimension):
+    parts = np.array_split(Dx, dimension)
+    acc = parts[0] ** 2
+    for i in range(1, len(parts)):
+        acc = acc + parts[i] ** 2
+    return acc
+
+
+def prior_tk0(x):
+    return 0.5 * np.sum(np.square(x))                 # prior_measures.py:19-21
+
+
+def prior_tk1(x, D):
+    return 0.5 * np.sum(np.square(D(x)))              # prior_measures.py:23-25
+
+
+def prior_tv(x, D, dimension):
+    return np.sum(np.sqrt(_sum_sq_split(D(x), dimension)))   # :27-38
+
+
+def prior_huber(x, D, dimension, gamma=0.05):
+    # prior_measures.py:40-52 -> LossFunctions.huber(f2, gamma),
+    # loss_functions.py:148-158 with f_scale = 1: f2 below gamma^2 stays,
+    # above it 2*gamma*sqrt(f2) - gamma^2; divided by 2*gamma
+    f2 = _sum_sq_split(D(x), dimension)
+    h = np.where(f2 < gamma * gamma, f2, 2. * gamma * np.sqrt(f2) - gamma ** 2)
+    return np.sum(h / (2. * gamma))
+
+
+def sim_sad(x, x_ref):                                # similarity_measures.py:26-29
+    return np.sum(np.abs(x - x_ref))
+
+
+def sim_mae(x, x_ref):                                # :40-44
+    return sim_sad(x, x_ref) / float(x.size)
+
+
+def sim_ssd(x, x_ref):                                # :55-59
+    return np.sum(np.square(x - x_ref))
+
+
+def sim_mse(x, x_ref):                                # :70-74
+    return sim_ssd(x, x_ref) / float(x.size)
+
+
+def sim_rmse(x, x_ref):                               # :85-87
+    return np.sqrt(sim_mse(x, x_ref))
+
+
+def sim_psnr(x, x_ref):                               # :98-101 (unguarded mse = 0)
+    with np.errstate(divide="ignore"):
+        return 10 * np.log10(np.max(x_ref) ** 2 / sim_mse(x, x_ref))
+
+
+def sim_ncc(x, x_ref):                                # :112-120
+    ncc = np.sum((x - x.mean()) * (x_ref - x_ref.mean()))
+    return ncc / float(x.size * x.std(ddof=1) * x_ref.std(ddof=1))
+
+
+# --------------------------------------------------------------------------
 # Flat-callable factories (mirror how run_denoising.py:104-107 and
 # run_deconvolution.py:120-129 wrap the N-D operators)
 # --------------------------------------------------------------------------

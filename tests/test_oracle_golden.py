@@ -142,6 +142,43 @@ def test_primal_dual_cli_L2_and_spacing(golden):
     assert rel_l2(out, g["pd_3d_ALG2_TVL2_spacing"]) < TIGHT
 
 
+@pytest.mark.parametrize("k,alg,reg,data", PD_CASES)
+def test_c_oracle_matches_reference_and_numpy_restatement(golden, k, alg, reg,
+                                                          data):
+    """oracle/pd_oracle.c (the fast form the deep-iteration GPU tests and
+    bench.py's cpu_baseline use) is held to the same reference goldens and is
+    bit-identical to the NumPy restatement."""
+    from oracle import c_oracle
+    g = golden("pd")
+    obs = g["obs_" + k]
+    L2 = {"1d": 4.0, "2d": 8.0, "3d": 16.0}[k]
+    alpha = 0.05 if data == "L2" else 0.6
+    out = c_oracle.primal_dual_denoise(obs.flatten(), obs.shape, reg, data,
+                                       alpha, 25, L2, alg)
+    assert rel_l2(out, g["pd_%s_%s_%s%s" % (k, alg, reg, data)]) < TIGHT
+    assert np.array_equal(out, orc.primal_dual_denoise(
+        obs.flatten(), obs.shape, reg, data, alpha, 25, L2, alg))
+
+
+def test_c_oracle_spacing_and_configs(golden):
+    from oracle import c_oracle
+    g = golden("pd")
+    obs = g["obs_3d"]
+    out = c_oracle.primal_dual_denoise(obs.flatten(), obs.shape, "TV", "L2",
+                                       0.05, 25, 64.0, "ALG2",
+                                       spacing=g["pd_spacing"])
+    assert rel_l2(out, g["pd_3d_ALG2_TVL2_spacing"]) < TIGHT
+    c = golden("configs")
+    lena = c["lena_noise_u8"].astype(np.float64)
+    out = c_oracle.primal_dual_denoise(lena.flatten(), lena.shape, "TV", "L2",
+                                       0.03, 50, 8.0, "ALG2")
+    assert rel_l2(out, c["cfg1_lena_TVL2_50it_L2eq8"]) < 2e-7  # f32 storage
+    ph = c["phantom64"].astype(np.float64)
+    out = c_oracle.primal_dual_denoise(ph.flatten(), ph.shape, "TV", "L2", 0.03,
+                                       200, 16.0, "ALG2")
+    assert rel_l2(out, c["cfg2_phantom_TVL2_200it_L2eq16"]) < 2e-7
+
+
 def test_refstyle_iteration_equals_restatement(golden):
     obs = golden("pd")["obs_3d"]
     a = orc.pd_tvl2_refstyle(obs.flatten(), obs.shape, 0.05, 25, 16.0,
@@ -293,3 +330,80 @@ def test_synth_volume_is_deterministic():
     assert np.array_equal(a, b) and a.shape == (16, 16, 16)
     s = orc.synth_volume(16, 3, "sp")
     assert set(np.unique(s)).issubset({0.0, 50.0, 100.0, 150.0})
+
+
+# ------------------------------------------- SURVEY 8(f3) and x_scale (measures.npz)
+def _xs_ops(x_gt):
+    d = x_gt.ndim
+    cov = 1.5 if d == 1 else np.diag(np.ones(d)) * 1.5
+    D, Da, A, Aa = orc.flat_operators(x_gt.shape, None, cov)
+    return A, Aa, D, Da
+
+
+@pytest.mark.parametrize("k", ["1d", "2d", "3d"])
+def test_prior_measures_match_reference(golden, k):
+    """nsol/prior_measures.py:19-52 on the obs_* arrays of pd.npz."""
+    g = golden("measures")
+    obs = golden("pd")["obs_" + k]
+    d = obs.ndim
+    x = obs.flatten()
+    assert np.isclose(orc.prior_tk0(x), g["prior_tk0_" + k], rtol=1e-14, atol=0)
+    for tag, sp in (("unit", None), ("sp", g["prior_spacing_" + k])):
+        D = lambda v: orc.grad(v.reshape(obs.shape), sp).reshape(-1)
+        for name, val in (
+                ("tk1", orc.prior_tk1(x, D)), ("tv", orc.prior_tv(x, D, d)),
+                ("huber", orc.prior_huber(x, D, d)),
+                ("huber_g2", orc.prior_huber(x, D, d, gamma=2.0))):
+            ref = g["prior_%s_%s_%s" % (name, k, tag)]
+            assert np.isclose(val, ref, rtol=1e-13, atol=0), (name, tag)
+
+
+@pytest.mark.parametrize("k", ["1d", "2d"])
+def test_x_scale_goldens_tikhonov_admm_pd(golden, k):
+    """The set-up of tests/solvers_test.py:102-352 (Tikhonov, ADMM, PD with
+    prox_linear_least_squares; x_scale = max and data divided by it)."""
+    g = golden("measures")
+    x_gt = g["xs_gt_1d"] if k == "1d" else g["brainweb_u8"].astype(np.float64)
+    A, Aa, D, Da = _xs_ops(x_gt)
+    xs = float(x_gt.max())
+    for tag, s in (("unit", 1.), ("scaled", xs)):
+        b = g["xs_b_%s_%s" % (k, tag)]
+        out = orc.tikhonov(A, Aa, D, Da, b, b, x_scale=s)
+        assert rel_l2(out, g["xs_tk_%s_%s" % (k, tag)]) < 1e-10
+        out = orc.admm(A, Aa, D, Da, b, b, x_gt.ndim, x_scale=s)
+        assert rel_l2(out, g["xs_admm_%s_%s" % (k, tag)]) < 1e-9
+        pf = lambda x, tau: orc.prox_linear_least_squares(
+            x, tau, A, Aa, b, b, x_scale=s)
+        out = orc.primal_dual(pf, orc.prox_tv_conj, D, Da, 8, b, x_scale=s)
+        assert rel_l2(out, g["xs_pd_%s_%s" % (k, tag)]) < 1e-9
+
+
+def test_pd_deconvolution_golden(golden):
+    g = golden("admm")
+    shape = DEC["2d"]
+    D, Da, A, Aa = orc.flat_operators(shape, None, g["cov_2d"])
+    y = g["y_2d"]
+    xs = float(y.max())
+    pf = lambda x, tau: orc.prox_linear_least_squares(x, tau, A, Aa, y, y,
+                                                      x_scale=xs)
+    out = orc.primal_dual(pf, orc.prox_tv_conj, D, Da, 8, y, alpha=0.05,
+                          iterations=8, x_scale=xs)
+    assert rel_l2(out, g["pd_deconv_2d"]) < 1e-9
+
+
+def test_similarity_identities_of_the_reference_test(golden):
+    """tests/similarity_measures_test.py:20-94 on data/2D_BrainWeb.png, 4
+    decimals as there (nsol.similarity_measures itself needs skimage, absent
+    here: the formulas are restated from similarity_measures.py:26-120)."""
+    img = golden("measures")["brainweb_u8"].astype(np.float64)
+    x, x2, xo = img.flatten(), (img * 2).flatten(), (img + 2).flatten()
+    assert abs(orc.sim_mae(x, xo) - np.abs(x - xo).mean()) < 1e-4
+    assert abs(orc.sim_ssd(x, xo) - np.sum(np.square(x - xo))) < 1e-4
+    assert abs(orc.sim_mse(x, xo) - np.square(x - xo).mean()) < 1e-4
+    assert round(orc.sim_ssd(x, x), 4) == 0
+    assert round(abs(orc.sim_ssd(x, xo) - x.size * 4), 4) == 0
+    assert orc.sim_psnr(x, x) == np.inf
+    assert round(abs(orc.sim_ncc(x, x) - 1), 4) == 0
+    assert round(abs(orc.sim_ncc(x, -x) + 1), 4) == 0
+    assert round(abs(orc.sim_ncc(x, xo) - 1), 4) == 0
+    assert round(abs(orc.sim_ncc(x, x2) - 1), 4) == 0

@@ -58,7 +58,7 @@ def read_nifti_f64(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="all", choices=["all", "extra"],
+    ap.add_argument("--only", default="all", choices=["all", "extra", "measures"],
                     help="'extra' writes only tests/golden/extra.npz (own RNG "
                          "seed, so the other fixtures stay byte-stable)")
     args = ap.parse_args()
@@ -78,6 +78,9 @@ def main():
 
     if args.only == "extra":
         make_extra(OUT, LO, TK, ADMM, PD, prox)
+        return
+    if args.only == "measures":
+        make_measures(OUT, args.ref, LO, TK, ADMM, PD, prox)
         return
 
     rng = np.random.default_rng(20261003)
@@ -408,6 +411,99 @@ def make_extra(out, LO, TK, ADMM, PD, prox):
     np.savez_compressed(os.path.join(out, "extra.npz"), **g)
     print("wrote extra.npz (%.1f KiB)" %
           (os.path.getsize(os.path.join(out, "extra.npz")) / 1024.0))
+
+
+def make_measures(out, ref, LO, TK, ADMM, PD, prox):
+    """SURVEY section 8(f3) and the x_scale property of tests/solvers_test.py:
+    * nsol.prior_measures (prior_measures.py:19-52: TK0, TK1, TV, Huber) on the
+      obs_* arrays of pd.npz, unit and non-unit spacing;
+    * the set-up of tests/solvers_test.py:102-352 (1-D spike signal and
+      data/2D_BrainWeb.png, sigma^2 = 1.5 blur, Poisson noise, seed 1) run
+      through the reference's Tikhonov, ADMM and primal-dual
+      (prox_linear_least_squares) solvers with x_scale = max and with data
+      divided by it.  The BrainWeb image itself is stored too: the
+      similarity-measure identities of tests/similarity_measures_test.py:20-94
+      are stated on it (nsol.similarity_measures cannot be imported here:
+      skimage is absent)."""
+    from PIL import Image
+    import nsol.prior_measures as PM
+    import nsol.noise as Noise
+    g = {}
+    pd_g = np.load(os.path.join(out, "pd.npz"))
+    LOs = {1: LO.LinearOperators1D, 2: LO.LinearOperators2D,
+           3: LO.LinearOperators3D}
+    spac = {1: 1.5, 2: np.array([2.0, 0.5]), 3: np.array([2.0, 4.0, 0.5])}
+    for k in ("1d", "2d", "3d"):
+        obs = pd_g["obs_" + k]
+        d = obs.ndim
+        for tag, sp in (("unit", None), ("sp", spac[d])):
+            lo = LOs[d]() if sp is None else LOs[d](spacing=sp)
+            grad, _ = lo.get_gradient_operators()
+            D = lambda x: grad(x.reshape(*obs.shape)).flatten()
+            x = obs.flatten()
+            g["prior_tk0_%s" % k] = np.array(
+                PM.PriorMeasures.zeroth_order_tikhonov(x))
+            g["prior_tk1_%s_%s" % (k, tag)] = np.array(
+                PM.PriorMeasures.first_order_tikhonov(x, D))
+            g["prior_tv_%s_%s" % (k, tag)] = np.array(
+                PM.PriorMeasures.total_variation(x, D, d))
+            g["prior_huber_%s_%s" % (k, tag)] = np.array(
+                PM.PriorMeasures.huber(x, D, d))
+            g["prior_huber_g2_%s_%s" % (k, tag)] = np.array(
+                PM.PriorMeasures.huber(x, D, d, gamma=2.0))
+        if d > 1:
+            g["prior_spacing_%s" % k] = np.asarray(spac[d], dtype=float)
+    g["prior_spacing_1d"] = np.array([1.5])
+
+    brain = np.array(Image.open(os.path.join(ref, "data", "2D_BrainWeb.png")))
+    assert brain.ndim == 2 and brain.dtype == np.uint8
+    g["brainweb_u8"] = brain
+    x1 = np.ones(50) * 50
+    x1[5], x1[16], x1[23], x1[30] = 10, 100, 150, 20
+    g["xs_gt_1d"] = x1
+    sigma2 = 1.5
+    for k, x_gt in (("1d", x1), ("2d", brain.astype(np.float64))):
+        d = x_gt.ndim
+        lo = LOs[d]()
+        A, A_adj = lo.get_gaussian_blurring_operators(
+            sigma2 if d == 1 else np.diag(np.ones(d)) * sigma2)
+        grad, grad_adj = lo.get_gradient_operators()
+        X = x_gt.shape
+        Z = grad(x_gt).shape
+        A_ = lambda x: A(x.reshape(*X)).flatten()
+        Aa_ = lambda x: A_adj(x.reshape(*X)).flatten()
+        D_ = lambda x: grad(x.reshape(*X)).flatten()
+        Da_ = lambda x: grad_adj(x.reshape(*Z)).flatten()
+        x_scale = x_gt.max()
+        for tag, x_, s in (("unit", x_gt / x_scale, 1), ("scaled", x_gt, x_scale)):
+            noise = Noise.Noise(A_(x_), seed=1)
+            noise.add_poisson_noise(noise_level=0.05)
+            b = noise.get_noisy_data().flatten()
+            x0 = np.array(b)
+            g["xs_b_%s_%s" % (k, tag)] = b
+            sol = TK.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=D_, B_adj=Da_,
+                                          b=b, x0=x0, x_scale=s)
+            sol.run()
+            g["xs_tk_%s_%s" % (k, tag)] = sol.get_x()
+            sol = ADMM.ADMMLinearSolver(A=A_, A_adj=Aa_, B=D_, B_adj=Da_, b=b,
+                                        x0=x0, x_scale=s, dimension=d)
+            sol.run()
+            g["xs_admm_%s_%s" % (k, tag)] = sol.get_x()
+            sol = PD.PrimalDualSolver(
+                prox_f=lambda x, tau: prox.prox_linear_least_squares(
+                    x=x, tau=tau, A=A_, A_adj=Aa_, b=b, x0=x0, x_scale=s),
+                prox_g_conj=prox.prox_tv_conj, B=D_, B_conj=Da_, L2=8, x0=x0,
+                x_scale=s)
+            sol.run()
+            g["xs_pd_%s_%s" % (k, tag)] = sol.get_x()
+        for nm in ("tk", "admm", "pd"):
+            dev = np.linalg.norm(g["xs_%s_%s_scaled" % (nm, k)] -
+                                 x_scale * g["xs_%s_%s_unit" % (nm, k)])
+            print("x_scale property, reference, %s %s: %.3e" % (nm, k, dev))
+    g["xs_scale_2d"] = np.array(float(brain.max()))
+    np.savez_compressed(os.path.join(out, "measures.npz"), **g)
+    print("wrote measures.npz (%.1f KiB)" %
+          (os.path.getsize(os.path.join(out, "measures.npz")) / 1024.0))
 
 
 if __name__ == "__main__":
