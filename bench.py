@@ -7,16 +7,30 @@ per GPU.
 
 A step is ONE primal-dual iteration over the whole volume (inputs already
 resident in HBM); three consecutive iterations share one pass over memory
-(k_pd_fusedk, temporal blocking of depth 3).  N > 1: launched
-by torch.distributed.run, one rank per GPU, each rank owns its own volume (weak
-scaling, no per-iteration collective); after the timed region the results are
-gathered once on rank 0 over RCCL (reported as gather_ms, not part of `value`).
-Rank 0 prints one JSON line.
+(k_pd_fusedk, temporal blocking of depth 3).
+
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in
+the environment) this process is one of the ranks; started bare, `--gpus N`
+starts the N ranks itself (child processes, before anything here touches a GPU)
+and fails if fewer than N devices are visible or a rank does not join.  Each
+rank owns its own volume (weak scaling, no per-iteration collective); after the
+timed region the results are gathered once on rank 0 over RCCL (gather_ms).
+
+`--batch B` is BASELINE config 5 instead: B independent TV-L1 volumes (salt and
+pepper) sharded over the ranks, each rank solving B / N of them one after the
+other, ONE gather of all reconstructions at the end; the clock covers solves
+and gather (strong scaling).
+
+The timed region of K steps is repeated `--reps` times (default 5, each
+bracketed by barrier + synchronize, max over ranks); the line reports the
+median.  Rank 0 prints one JSON line.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_VOXEL = 44        # 11 float32 words: read xbar,x,b,p[3]; write p[3],x,xbar
+PMC_TABLE = os.path.join("profiles", "pmc_by_config.json")
 
 
 class HipEvents(object):
@@ -55,21 +70,27 @@ class HipEvents(object):
         return float(ms.value)
 
 
-def measured_traffic(n, plan=None):
+def profiled_traffic(n, plan=None):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3
     PMC passes (profiles/pmc_by_config.json, written by
-    tools/summarize_profiles.py): the passes are pinned to one kernel
-    configuration, so the figure is looked up by the configuration this run's
-    tuner settled on; None when that one has not been profiled."""
+    tools/summarize_profiles.py).  PMC counters cannot be read from inside this
+    process: the figure belongs to ANOTHER run of the same binary, pinned to one
+    kernel configuration, and is looked up by the configuration this run's
+    tuner settled on.  Returns (bytes or None, source string or None)."""
     if not plan:
-        return None
-    path = os.path.join(ROOT, "profiles", "pmc_by_config.json")
+        return None, None
     try:
-        table = json.load(open(path))
-        rec = table.get("k_pd_fusedk:%d:%d:%d:%d" % ((n,) + tuple(plan[:3])))
-        return float(rec["traffic_bytes_per_launch"]) if rec else None
+        table = json.load(open(os.path.join(ROOT, PMC_TABLE)))
+        key = "k_pd_fusedk:%d:%d:%d:%d" % ((n,) + tuple(plan[:3]))
+        rec = table.get(key)
+        if rec:
+            return float(rec["traffic_bytes_per_launch"]), \
+                "from_profile: %s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
+                "passes of another run, same kernel configuration)" % (
+                    PMC_TABLE, key)
     except Exception:
-        return None
+        pass
+    return None, None
 
 
 def cpu_baseline(sample_n, iters):
@@ -86,13 +107,95 @@ def cpu_baseline(sample_n, iters):
     return iters / dt
 
 
-def main():
+def cpu_baseline_c(sample_n, iters):
+    """The same loop as compiled C with OpenMP (oracle/pd_oracle.c, bit-identical
+    to the NumPy oracle) on all host cores: what a tuned CPU port would do."""
+    from oracle import nsol_oracle as orc, c_oracle
+    vol = orc.synth_volume(sample_n, 0, "gauss")
+    b = vol.reshape(-1)
+    c_oracle.primal_dual_denoise(b, vol.shape, "TV", "L2", 0.03, 1, 16.0)
+    t0 = time.time()
+    c_oracle.primal_dual_denoise(b, vol.shape, "TV", "L2", 0.03, iters, 16.0)
+    dt = time.time() - t0
+    return iters / dt, c_oracle.threads()
+
+
+# ------------------------------------------------------------------ launcher
+def visible_gpus():
+    """Device count without creating a HIP context in this process."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without an external launcher: start N ranks as
+    child processes (this parent never initialises a GPU), pass rank 0's JSON
+    line through, fail if any rank fails."""
+    n = args.gpus
+    if args.backend == "nccl" and not args.dry_run:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write(
+                "bench.py: --gpus %d but only %d GPU(s) visible; refusing to "
+                "report a %d-rank number from fewer devices (use --backend "
+                "gloo to rehearse)\n" % (n, have, n))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + argv, env=env,
+            stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + args.launch_timeout
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+        if rc != 0 or time.time() > deadline:
+            for p in pending:           # a rank died or the job hangs: exact PIDs
+                p.kill()
+            for p in pending:
+                p.wait()
+            if rc == 0:
+                rc = 3
+                sys.stderr.write("bench.py: ranks did not finish within %d s\n"
+                                 % args.launch_timeout)
+            break
+        time.sleep(0.05)
+    if rc != 0:
+        sys.stderr.write("bench.py: %d-rank run failed (exit %d)\n" % (n, rc))
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the timed K-step region (median is "
+                         "reported)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--data", default="L2", choices=["L2", "L1"])
+    ap.add_argument("--data", default=None, choices=["L2", "L1"])
+    ap.add_argument("--batch", type=int, default=0,
+                    help="BASELINE config 5: this many independent TV-L1 "
+                         "volumes sharded over the ranks, one gather at the "
+                         "end inside the clock (0 = one volume per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pdk", default="",
                     help="waves:ntx:zchunk -- pin the depth-3 kernel's "
@@ -107,15 +210,77 @@ def main():
                     help="gloo only to rehearse N > 1 on a box with fewer "
                          "GPUs than ranks (collectives then go through host "
                          "memory)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=int, default=1500)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / collectives only, no GPU "
+                         "work (CPU test of the N > 1 plumbing)")
+    return ap.parse_args(argv)
+
+
+def median(v):
+    v = sorted(v)
+    m = len(v) // 2
+    return v[m] if len(v) % 2 else 0.5 * (v[m - 1] + v[m])
+
+
+def dry_run(args, world, rank):
+    """The N > 1 plumbing without a GPU: rendezvous, barrier, MAX-reduce of a
+    time, one gather; rank 0 prints a line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    joined = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(joined)
+        res = torch.full((4,), float(rank))
+        bucket = [torch.empty_like(res) for _ in range(world)] \
+            if rank == 0 else None
+        dist.gather(res, gather_list=bucket, dst=0)
+        if rank == 0:
+            assert [int(b[0]) for b in bucket] == list(range(world))
+    if rank == 0:
+        assert int(joined.item()) == world and float(t.item()) == world
+        print(json.dumps({"dry_run": True, "n_gpus": world,
+                          "ranks_joined": int(joined.item()),
+                          "steps": args.steps, "warmup": args.warmup}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args, argv)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with "
+                         "--nproc-per-node equal to --gpus\n"
+                         % (args.gpus, world))
+        return 2
+    rank = int(os.environ.get("RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if args.batch and args.batch % world:
+        sys.stderr.write("bench.py: --batch %d is not a multiple of %d ranks\n"
+                         % (args.batch, world))
+        return 2
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (args.backend == "nccl" and ndev < world):
+        sys.stderr.write("bench.py: %d rank(s) on %d visible GPU(s)\n"
+                         % (world, ndev))
+        return 2
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -138,38 +303,49 @@ def main():
         _lib.set_param("pdk_ntx", pinned[1])
         _lib.set_param("pdk_zchunk", pinned[2])
 
+    data = args.data or ("L1" if args.batch else "L2")
     n = args.size
     shape = (n, n, n)
     nvox = n ** 3
-    alpha = 0.03 if args.data == "L2" else 0.6
-    kind = "gauss" if args.data == "L2" else "sp"
-    vol = synth_volume(n, seed=rank, kind=kind, dtype=np.float32)
-    x_scale = float(vol.max())
+    alpha = 0.03 if data == "L2" else 0.6
+    kind = "gauss" if data == "L2" else "sp"
     dev = torch.device("cuda", local_rank)
-    bt = torch.from_numpy(vol.reshape(-1)).to(dev)
-    del vol
-    bt = ops.scale(bt, x_scale, divide=True)          # b~ = b / x_scale
+    # volume i of the batch -> rank i % world (nsol_amd.batch.shard_indices);
+    # without --batch every rank owns exactly volume `rank`
+    mine = list(range(rank, args.batch, world)) if args.batch else [rank]
+    inputs, scales = [], []
+    for i in mine:                      # made on the host, resident in HBM
+        vol = synth_volume(n, seed=i, kind=kind, dtype=np.float32)
+        scales.append(float(vol.max()))
+        b = torch.from_numpy(vol.reshape(-1)).to(dev)
+        del vol
+        inputs.append(ops.scale(b, scales[-1], divide=True))   # b~ = b / x_scale
+        del b
+    bt = inputs[0]
     x = bt.clone()
-    x_alt = torch.empty_like(bt)      # x ping-pong of the two-iteration kernel
+    x_alt = torch.empty_like(bt)      # x ping-pong of the multi-iteration kernels
     xbar = [bt.clone(), torch.empty_like(bt)]
     p = [torch.zeros(3 * nvox, dtype=torch.float32, device=dev)
          for _ in range(2)]
     w = (1.0, 1.0, 1.0)
     lmbda = 1.0 / alpha
-    total = args.warmup + args.steps
-    sig, ta, th = step_schedule("ALG2", 16.0, lmbda, total)
-    flags = ops.PD_REG_TV | (ops.PD_DATA_L1 if args.data == "L1"
+    reps = max(1, args.reps)
+    flags = ops.PD_REG_TV | (ops.PD_DATA_L1 if data == "L1"
                              else ops.PD_DATA_L2)
-
     state = {"slot": 0}
 
-    def run(first, count, p_is_zero):
+    def run(bt, sig, ta, th, first, count, p_is_zero):
         a = state["slot"]                 # slot holding the current xbar / p
         end = ops.pd_run(xbar[a], xbar[1 - a], x, bt, p[a], p[1 - a], shape, w,
                          lmbda, sig[first:first + count],
                          ta[first:first + count], th[first:first + count],
                          p_is_zero, 0.05, flags, x_alt=x_alt)
         state["slot"] = a ^ end
+
+    def reset(bt):
+        x.copy_(bt)
+        xbar[0].copy_(bt)
+        state["slot"] = 0
 
     # Plan pass (untimed, like creating an FFT plan): the depth-3 kernel tunes
     # its footprint shape online during the first few dozen launches on a new
@@ -182,72 +358,119 @@ def main():
         if pinned or ops.pd_fusedk_tuned(x, shape) != 0:
             break
     plan = pinned or ops.pd_fusedk_plan(x, shape)
-    x.copy_(bt)
-    xbar[0].copy_(bt)
-    state["slot"] = 0
+    reset(bt)
 
-    if args.warmup > 0:
-        run(0, args.warmup, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-
-    # The timed region is ONE enqueue of args.steps iterations; an event after
-    # the last full group of three separates the launches of the dominant
-    # kernel (k_pd_fusedk, three iterations per launch) from the one or two
-    # trailing iterations (k_pd_fused2 / k_pd_fused).
-    ev = HipEvents()
-    e0, em, e1 = ev.create(), ev.create(), ev.create()
-    stream = torch.cuda.current_stream().cuda_stream
-    triples = args.steps // 3
-    t0 = time.perf_counter()
-    ev.record(e0, stream)
-    if triples:
-        run(args.warmup, 3 * triples, args.warmup == 0)
-    ev.record(em, stream)
-    if args.steps > 3 * triples:
-        run(args.warmup + 3 * triples, args.steps - 3 * triples,
-            args.warmup == 0 and triples == 0)
-    ev.record(e1, stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if triples:
-        launches = triples
-        iters_per_launch = 3
-        kernel_ms = ev.elapsed_ms(e0, em) / launches        # avg launch duration
-    else:
-        launches = 1
-        iters_per_launch = args.steps
-        kernel_ms = ev.elapsed_ms(e0, e1)
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64,
-                        device="cpu" if on_host else dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tmax = float(tmax.item())
-
-    gather_ms = None
-    if world > 1:                                     # the one collective
+    def fence():
         torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        res = ops.scale(x, x_scale)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64,
+                         device="cpu" if on_host else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_results(res):
+        """The one collective: every rank's reconstructions to rank 0."""
         if on_host:
             res = res.cpu()
         bucket = [torch.empty_like(res) for _ in range(world)] \
             if rank == 0 else None
         dist.gather(res, gather_list=bucket, dst=0)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        del bucket
+        return bucket
+
+    ev = HipEvents()
+    stream = torch.cuda.current_stream().cuda_stream
+    triples = args.steps // 3
+    rep_s, rep_kernel_ms = [], []
+    gather_ms = None
+
+    if not args.batch:
+        total = args.warmup + reps * args.steps
+        sig, ta, th = step_schedule("ALG2", 16.0, lmbda, total)
+        if args.warmup > 0:
+            run(bt, sig, ta, th, 0, args.warmup, True)
+        first = args.warmup
+        for r in range(reps):
+            # One repetition is ONE enqueue of args.steps iterations; an event
+            # after the last full group of three separates the launches of the
+            # dominant kernel (k_pd_fusedk, three iterations per launch) from
+            # the one or two trailing iterations (k_pd_fused2 / k_pd_fused).
+            e0, em, e1 = ev.create(), ev.create(), ev.create()
+            fence()
+            t0 = time.perf_counter()
+            ev.record(e0, stream)
+            if triples:
+                run(bt, sig, ta, th, first, 3 * triples, first == 0)
+            ev.record(em, stream)
+            if args.steps > 3 * triples:
+                run(bt, sig, ta, th, first + 3 * triples,
+                    args.steps - 3 * triples, first == 0 and triples == 0)
+            ev.record(e1, stream)
+            fence()
+            rep_s.append(max_over_ranks(time.perf_counter() - t0))
+            rep_kernel_ms.append(ev.elapsed_ms(e0, em) / triples if triples
+                                 else ev.elapsed_ms(e0, e1))
+            first += args.steps
+        if world > 1:                                 # the one collective
+            fence()
+            g0 = time.perf_counter()
+            bucket = gather_results(ops.scale(x, scales[0]))
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            del bucket
+    else:
+        # config 5: each rank solves its share of the batch, volume after
+        # volume (args.steps iterations each), then ONE gather; the clock
+        # covers all of it
+        sig, ta, th = step_schedule("ALG2", 16.0, lmbda, args.steps)
+        results = torch.empty(len(mine) * nvox, dtype=torch.float32, device=dev)
+        if args.warmup > 0:
+            run(bt, sig, ta, th, 0, min(args.warmup, args.steps), True)
+        gathers = []
+        for r in range(reps):
+            e0, em = ev.create(), ev.create()
+            fence()
+            t0 = time.perf_counter()
+            kms = 0.0
+            for j, bj in enumerate(inputs):
+                reset(bj)
+                if j == 0:
+                    ev.record(e0, stream)
+                if triples:
+                    run(bj, sig, ta, th, 0, 3 * triples, True)
+                if j == 0:
+                    ev.record(em, stream)
+                if args.steps > 3 * triples:
+                    run(bj, sig, ta, th, 3 * triples,
+                        args.steps - 3 * triples, triples == 0)
+                ops.scale(x, scales[j], out=results[j * nvox:(j + 1) * nvox])
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            if world > 1:
+                bucket = gather_results(results)
+                del bucket
+            gathers.append((time.perf_counter() - g0) * 1e3)
+            fence()
+            rep_s.append(max_over_ranks(time.perf_counter() - t0))
+            if triples:
+                kms = ev.elapsed_ms(e0, em) / triples
+            rep_kernel_ms.append(kms)
+        gather_ms = median(gathers) if world > 1 else None
+
+    tmed = median(rep_s)
+    kernel_ms = median(rep_kernel_ms)
+    if triples:
+        launches, iters_per_launch = triples, 3
+    else:
+        launches, iters_per_launch = 1, args.steps
 
     # for reference: the one-iteration-per-pass kernel on the same state
     single = None
-    if world == 1 and args.steps >= 2:
+    if world == 1 and args.steps >= 2 and not args.batch:
         _lib.set_param("pd2_enable", 0)
         _lib.set_param("pdk_enable", 0)
         try:
@@ -272,48 +495,84 @@ def main():
             _lib.set_param("pdk_enable", 1)
 
     finite = bool(torch.isfinite(x).all().item())
+    joined = torch.ones(1, dtype=torch.int64, device="cpu" if on_host else dev)
+    if world > 1:
+        dist.all_reduce(joined)
+    if int(joined.item()) != world:
+        sys.stderr.write("bench.py: %d of %d ranks joined\n"
+                         % (int(joined.item()), world))
+        return 3
 
     if rank == 0:
-        value = world * args.steps / tmax
+        volumes = args.batch or world
+        value = volumes * args.steps / tmed
         # algorithmic bytes: 44 B per voxel per ITERATION; a launch
-        # of the dominant kernel processes iters_per_launch iterations
+        # of the dominant kernel processes iters_per_launch iterations ...
         bytes_per_launch = BYTES_PER_VOXEL * nvox * iters_per_launch
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        # ... while reading and writing the eleven arrays ONCE: the least a
+        # launch can physically move
+        pass_bytes = BYTES_PER_VOXEL * nvox
+        traffic, traffic_source = profiled_traffic(n, plan)
         out = {
-            "metric": "primal-dual iters/sec on %d^3 fp32 TV-%s" %
-                      (n, args.data),
+            "metric": "primal-dual iters/sec on %d^3 fp32 TV-%s" % (n, data),
             "value": value, "unit": "iterations/s (summed over volumes)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": tmax / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": tmed / args.steps * 1e3 *
+            (world / float(volumes)),
+            "higher_is_better": True,
+            "scaling": "strong" if args.batch else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "synth_volume(%d, seed=rank, '%s'), TV-%s "
-                            "denoising, Chambolle-Pock ALG2, L2=16, "
-                            "alpha=%g, one volume per GPU" %
-                            (n, kind, args.data, alpha),
-                "volumes": world, "voxels_per_volume": nvox,
+                "workload": (
+                    "batch of %d x synth_volume(%d, seed=i, '%s'), TV-%s "
+                    "denoising, Chambolle-Pock ALG2, L2=16, alpha=%g, %d "
+                    "iterations per volume, volume i -> rank i %% %d, one "
+                    "gather at the end inside the clock (BASELINE config 5)"
+                    % (args.batch, n, kind, data, alpha, args.steps, world))
+                if args.batch else (
+                    "synth_volume(%d, seed=rank, '%s'), TV-%s "
+                    "denoising, Chambolle-Pock ALG2, L2=16, "
+                    "alpha=%g, one volume per GPU" % (n, kind, data, alpha)),
+                "volumes": volumes, "voxels_per_volume": nvox,
                 "kernel": "k_pd_fusedk (three iterations per pass; trailing "
                           "iterations: k_pd_fused2 / k_pd_fused)",
                 "kernel_config": None if plan is None else {
                     "waves": plan[0], "tiles_x": plan[1], "zchunk": plan[2],
                     "pinned": bool(pinned)},
-                "gather_ms": gather_ms, "result_finite": finite},
+                "timed_repetitions": reps,
+                "repetition_ms": [t * 1e3 for t in rep_s],
+                "statistic": "median of the repetitions (each: barrier + "
+                             "synchronize, K steps, synchronize + barrier; "
+                             "max over ranks)",
+                "backend": None if world == 1 else
+                ("rccl" if args.backend == "nccl" else "gloo (host staging)"),
+                "ranks_joined": int(joined.item()),
+                "gather_ms": gather_ms,
+                "gather_inside_clock": bool(args.batch),
+                "result_finite": finite},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(n, plan),
+                "traffic": traffic, "traffic_source": traffic_source,
+                # `frac` prices iters_per_launch iterations at 44 B per voxel
+                # each (the contract's algorithmic bytes) although the launch
+                # moves the arrays once -- it may exceed 1.  The two fractions
+                # below are against what a launch physically has to move / did
+                # move:
+                "frac_per_launch": pass_bytes / (kernel_ms * 1e-3) / 1e9 /
+                HBM_PEAK_GBPS,
+                "frac_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 /
+                                 HBM_PEAK_GBPS) if traffic else None,
                 "bytes_per_launch": bytes_per_launch,
+                "min_physical_bytes_per_launch": pass_bytes,
                 "iterations_per_launch": iters_per_launch,
                 "launches": launches,
                 "avg_launch_ms": kernel_ms,
-                # what the memory system actually carries (PMC, per launch)
-                "traffic_rate_GBps": (measured_traffic(n, plan) /
-                                      (kernel_ms * 1e-3) / 1e9)
-                if measured_traffic(n, plan) else None,
+                "avg_launch_ms_repetitions": rep_kernel_ms,
                 "single_pass_reference": single},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.batch:
             sn = args.cpu_sample or n
             its = cpu_baseline(sn, 2)
             out["cpu_baseline"] = {
@@ -325,10 +584,21 @@ def main():
                           "volume, 2 iterations after 1 warm-up%s" %
                           (sn, "" if sn == n else
                            ", scaled by voxel count to %d^3" % n)}
+            try:
+                itc, threads = cpu_baseline_c(sn, 6)
+                out["cpu_baseline_compiled"] = {
+                    "value": itc * (sn ** 3) / float(nvox),
+                    "unit": "iterations/s", "cores": threads, "kind": "port",
+                    "sample": "oracle/pd_oracle.c (C + OpenMP float64, "
+                              "bit-identical to the NumPy oracle), %d^3 "
+                              "volume, 6 iterations after 1 warm-up" % sn}
+            except Exception as e:             # no gcc on the box: say so
+                out["cpu_baseline_compiled"] = {"error": str(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

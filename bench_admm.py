@@ -1,10 +1,25 @@
 #!/usr/bin/env python3
 """Secondary benchmark (BASELINE.json configs[3]): synthetic 512^3 Gaussian-blur
 deconvolution (sigma = 2, 13 taps per axis, periodic) with ADMMLinearSolver,
-TK1-regularised inner problem.  Prints one JSON line.
+TK1-regularised inner problem.  Prints one JSON line with the same contract as
+bench.py: `roofline` (dominant kernel, timed live with HIP events on the state
+of the run) and `cpu_baseline` (the reference-style CPU path on a bounded
+sample, extrapolated per voxel).
 
     python bench_admm.py [--size 512] [--iterations 10] [--iter-max 10]
                          [--minimizer lsmr|L-BFGS-B] [--data-loss linear|huber]
+
+Algorithmic bytes per voxel (float32; SURVEY 8(d) per-operator figures applied
+to this build's op list):
+  blur A = A^T            8   (read x, write Ax; ideal single pass)
+  k_lsmr_u               40   (read Av, v, u_top, u_bot[3]; write u_top, u_bot[3])
+  k_lsmr_v               24   (read A^T u, u_bot[3], v; write v)
+  k_lsmr_hx              28   (read hbar, x, h, v; write hbar, x, h)
+  k_admm_vw              52   (read x, v[3], w[3]; write v[3], w[3], rhs[3])
+One LSMR iteration = 2 blurs + u + v + hx = 108; one ADMM iteration with
+LSMR(iter_max) = iter_max * 108 + set-up (copy of b 8, scaled rhs 24, its norm
+16, A^T b 8, first v 24, h 8, zeroed x / hbar 8) + clip 8 + k_admm_vw 52
+= iter_max * 108 + 156  (1 236 B per voxel for iter_max = 10).
 """
 import argparse
 import json
@@ -17,6 +32,76 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from bench import HipEvents, HBM_PEAK_GBPS  # noqa: E402
+
+BYTES = {"k_blur3_wrap": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
+         "k_admm_vw": 52}
+SETUP_BYTES = 156
+
+
+def bytes_per_admm_iteration(iter_max):
+    return iter_max * 108 + SETUP_BYTES
+
+
+def time_kernels(A, shape, reps=20):
+    """Average launch duration of each kernel of the LSMR branch on vectors of
+    the run's size (HIP events on the launch stream, 3 warm-up launches)."""
+    import torch
+    from nsol_amd import ops
+    n = int(np.prod(shape))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev).manual_seed(5)
+    r = lambda m: torch.rand(m, device=dev, generator=gen)
+    v, ut, Av, h, hbar, x = r(n), r(n), r(n), r(n), r(n), r(n)
+    ub, vv, ww, rhs = r(3 * n), r(3 * n), r(3 * n), r(3 * n)
+    w = (1.0, 1.0, 1.0)
+    ev = HipEvents()
+    stream = torch.cuda.current_stream().cuda_stream
+    # the wrappers read their reduction result back (.item()); the launches are
+    # timed between events, the read-back falls outside
+    lib_u = lambda: ops.lsmr_u_update(Av, v, ut, ub, ops.B_GRAD, shape, w,
+                                      0.5, 0.1, -0.5, sync=False)
+    lib_v = lambda: ops.lsmr_v_update(Av, ub, v, ops.B_GRAD, shape, w, 0.5,
+                                      0.1, -0.5, sync=False)
+    lib_hx = lambda: ops.lsmr_hx_update(hbar, x, h, v, -0.3, 0.2, -0.4, 0.5,
+                                        sync=False)
+    lib_vw = lambda: ops.admm_vw_update(x, vv, ww, None, rhs, shape, w, 0.1,
+                                        1.0)
+    lib_blur = lambda: A(v.view(shape))
+    out = {}
+    for name, fn in (("k_blur3_wrap", lib_blur), ("k_lsmr_u", lib_u),
+                     ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
+                     ("k_admm_vw", lib_vw)):
+        for _ in range(3):
+            fn()
+        e0, e1 = ev.create(), ev.create()
+        ev.record(e0, stream)
+        for _ in range(reps):
+            fn()
+        ev.record(e1, stream)
+        ms = ev.elapsed_ms(e0, e1) / reps
+        gbps = BYTES[name] * n / (ms * 1e-3) / 1e9
+        out[name] = {"bytes_per_voxel": BYTES[name], "avg_launch_ms": ms,
+                     "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
+    return out
+
+
+def cpu_baseline(sample_n, iter_max):
+    """Reference-style CPU path (oracle.admm_lsmr_refstyle: dense ndimage blur,
+    SciPy's lsmr) on a bounded sample: ONE ADMM iteration of LSMR(iter_max)."""
+    from oracle import nsol_oracle as orc
+    n = sample_n
+    cov = np.diag([4.0, 4.0, 4.0])
+    import scipy.ndimage
+    clean = orc.synth_volume(n, 0, "clean")
+    y = scipy.ndimage.convolve(clean, orc.gaussian_taps(3, cov),
+                               mode="wrap").flatten()
+    y = y + 0.02 * y.max() * np.random.default_rng(1).standard_normal(y.size)
+    t0 = time.time()
+    orc.admm_lsmr_refstyle(y, (n, n, n), cov, 0.01, 0.1, 1, iter_max,
+                           float(y.max()))
+    return 1.0 / (time.time() - t0)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -25,7 +110,11 @@ def main():
     ap.add_argument("--iter-max", type=int, default=10)
     ap.add_argument("--minimizer", default="lsmr")
     ap.add_argument("--data-loss", default="linear")
-    ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--repeat", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=64,
+                    help="edge length of the CPU baseline's volume (64: about "
+                         "15 s for one ADMM iteration of LSMR(10))")
     args = ap.parse_args()
 
     import torch
@@ -36,6 +125,7 @@ def main():
 
     n = args.size
     shape = (n, n, n)
+    nvox = n ** 3
     lo = LO.LinearOperators3D()
     A, A_adj = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
     grad, grad_adj = lo.get_gradient_operators()
@@ -52,7 +142,7 @@ def main():
                                                  generator=gen)
     x_scale = float(y.max())
     times = []
-    for _ in range(args.repeat):
+    for _ in range(max(1, args.repeat)):
         s = admm.ADMMLinearSolver(
             A=A_1D, A_adj=A_adj_1D, b=y, B=D_1D, B_adj=D_adj_1D, x0=y,
             dimension=3, alpha=0.01, rho=0.1, iterations=args.iterations,
@@ -66,18 +156,65 @@ def main():
     x = s.get_x_device()
     rel_change = float((ops.norm2(ops.lincomb2(1.0, x, -1.0, y)) /
                         ops.norm2(y)))
-    best = min(times)
-    print(json.dumps({
+    finite = bool(torch.isfinite(x).all().item())
+    execution = s.get_execution()
+    del s, x
+    med = sorted(times)[len(times) // 2]
+    out = {
         "metric": "ADMM iterations/sec on %d^3 fp32 TV deconvolution" % n,
-        "value": args.iterations / best, "unit": "ADMM iterations/s",
-        "seconds_per_run": best, "runs": times,
-        "config": {"workload": "synth_volume(%d,0,'clean') blurred sigma=2 + "
-                               "2%% noise; ADMM alpha=0.01 rho=0.1" % n,
+        "value": args.iterations / med, "unit": "ADMM iterations/s",
+        "n_gpus": 1, "steps": args.iterations, "warmup": 0,
+        "ms_per_step": med / args.iterations * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "seconds_per_run": med, "runs": times,
+        "statistic": "median of %d runs (the first includes one-time set-up)"
+                     % len(times),
+        "config": {"workload": "synth_volume(%d,0,'clean') blurred sigma=2 "
+                               "(13 taps per axis, periodic) + 2%% noise; "
+                               "ADMMLinearSolver alpha=0.01 rho=0.1 "
+                               "dimension=3 (BASELINE config 4)" % n,
                    "iterations": args.iterations, "iter_max": args.iter_max,
                    "minimizer": args.minimizer, "data_loss": args.data_loss,
-                   "execution": s.get_execution()},
-        "rel_change_vs_input": rel_change,
-        "finite": bool(torch.isfinite(x).all().item())}))
+                   "execution": execution},
+        "rel_change_vs_input": rel_change, "finite": finite}
+    if args.minimizer == "lsmr":
+        kern = time_kernels(A, shape)
+        per_it = {"k_blur3_wrap": 2 * args.iter_max + 1,
+                  "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
+                  "k_lsmr_hx": args.iter_max, "k_admm_vw": 1}
+        for k, c in per_it.items():
+            kern[k]["launches_per_admm_iteration"] = c
+            kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]
+        dom = max(kern, key=lambda k: kern[k]["ms_per_admm_iteration"])
+        run_bytes = bytes_per_admm_iteration(args.iter_max) * nvox
+        run_gbps = run_bytes * args.iterations / med / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom,
+            "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None,
+            "traffic_source": None,
+            "avg_launch_ms": kern[dom]["avg_launch_ms"],
+            "bytes_per_launch": BYTES[dom] * nvox,
+            "kernels": kern,
+            "whole_run": {
+                "algorithmic_bytes_per_voxel_per_admm_iteration":
+                    bytes_per_admm_iteration(args.iter_max),
+                "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
+                "kernel_ms_per_admm_iteration_sum":
+                    sum(k["ms_per_admm_iteration"] for k in kern.values())}}
+    if not args.no_cpu_baseline and args.minimizer == "lsmr":
+        sn = args.cpu_sample
+        its = cpu_baseline(sn, args.iter_max)
+        out["cpu_baseline"] = {
+            "value": its * (sn ** 3) / float(nvox),
+            "unit": "ADMM iterations/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "oracle admm_lsmr_refstyle (dense 13^3 ndimage blur, "
+                      "scipy.sparse.linalg.lsmr, reference op sequence), %d^3 "
+                      "volume, ONE ADMM iteration of LSMR(%d), extrapolated "
+                      "per voxel to %d^3" % (sn, args.iter_max, n)}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

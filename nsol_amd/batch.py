@@ -28,18 +28,35 @@ def solve_batch(solve_one, n_items, group=None, dst=0):
     world = dist.get_world_size(group)
     mine = shard_indices(n_items, rank, world)
     local = [solve_one(i) for i in mine]
+    if n_items == 0:
+        return [] if rank == dst else None
+    # Length, dtype and device of a result are agreed before the first gather,
+    # so a rank that owns no volume (n_items < world_size) can take part with a
+    # dummy instead of leaving the others waiting inside the collective.
+    meta = (int(local[0].numel()), str(local[0].dtype).split(".")[-1],
+            bool(local[0].is_cuda)) if local else None
+    metas = [None] * world
+    dist.all_gather_object(metas, meta, group=group)
+    known = [m for m in metas if m is not None]
+    if any(m != known[0] for m in known):
+        raise ValueError("solve_batch: results differ in length / dtype / "
+                         "device across ranks: %r" % (metas,))
+    numel, dtype, on_gpu = known[0][0], getattr(torch, known[0][1]), known[0][2]
+    if any(t.numel() != numel or t.dtype != dtype for t in local):
+        raise ValueError("solve_batch: every result must have the same length "
+                         "and dtype")
+    stage_host = on_gpu and dist.get_backend(group) == "gloo"
+    device = torch.device("cuda", torch.cuda.current_device()) \
+        if on_gpu and not stage_host else torch.device("cpu")
     rounds = (n_items + world - 1) // world
     out = [None] * n_items
     for r in range(rounds):
-        have = r < len(local)
-        # ranks without an item in the last (ragged) round send a dummy
-        ref = local[0] if local else None
-        if ref is None:
-            raise RuntimeError("rank %d owns no volume: use world_size <= "
-                               "n_items" % rank)
-        send = local[r] if have else torch.zeros_like(ref)
-        if send.is_cuda and dist.get_backend(group) == "gloo":
-            send = send.cpu()      # rehearsal without RCCL: stage through host
+        if r < len(local):
+            send = local[r].contiguous().view(-1)
+            if stage_host:
+                send = send.cpu()  # rehearsal without RCCL: stage through host
+        else:      # no item in this (ragged) round: a dummy of the agreed shape
+            send = torch.zeros(numel, dtype=dtype, device=device)
         if rank == dst:
             bucket = [torch.empty_like(send) for _ in range(world)]
             dist.gather(send, gather_list=bucket, dst=dst, group=group)

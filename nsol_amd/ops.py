@@ -454,19 +454,22 @@ def _bgeom(bmode, shape, w, n):
     return ((1 if ny == 1 else 2), 1, ny, nx), (1.0, 1.0, 1.0)
 
 
-def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u):
+def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
+                  sync=True):
     """u_top = c_av*Av + c_u*u_top; u_bot = c_bv*B(v) + c_u*u_bot;
-    returns ||[u_top; u_bot]||^2."""
+    returns ||[u_top; u_bot]||^2 (sync=False: the device scalar, not read
+    back)."""
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Av.numel())
     ws, res = _workspace(Av.device)
     _lib.check(_fn("lsmr_u_update", Av)(
         _p(Av), _p(v), _p(u_top), _p(u_bot), int(bmode), ndim, nz, ny, nx,
         w[0], w[1], w[2], float(c_av), float(c_bv), float(c_u), _p(res),
         _p(ws), stream_ptr()), "nsol_lsmr_u_update")
-    return float(res.item())
+    return float(res.item()) if sync else res
 
 
-def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v):
+def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
+                  sync=True):
     """v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v; returns ||v||^2."""
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Atu.numel())
     ws, res = _workspace(Atu.device)
@@ -474,10 +477,10 @@ def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v):
         _p(Atu), _p(u_bot), _p(v), int(bmode), ndim, nz, ny, nx, w[0], w[1],
         w[2], float(c_atu), float(c_btu), float(c_v), _p(res), _p(ws),
         stream_ptr()), "nsol_lsmr_v_update")
-    return float(res.item())
+    return float(res.item()) if sync else res
 
 
-def lsmr_hx_update(hbar, x, h, v, c_hbar, c_x, c_h, c_v):
+def lsmr_hx_update(hbar, x, h, v, c_hbar, c_x, c_h, c_v, sync=True):
     """hbar = h + c_hbar*hbar; x += c_x*hbar; h = c_v*v + c_h*h;
     returns ||x||^2."""
     ws, res = _workspace(x.device)
@@ -485,4 +488,4 @@ def lsmr_hx_update(hbar, x, h, v, c_hbar, c_x, c_h, c_v):
         _p(hbar), _p(x), _p(h), _p(v), x.numel(), float(c_hbar), float(c_x),
         float(c_h), float(c_v), _p(res), _p(ws), stream_ptr()),
         "nsol_lsmr_hx_update")
-    return float(res.item())
+    return float(res.item()) if sync else res

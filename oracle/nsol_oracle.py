@@ -800,3 +800,65 @@ def pd_tvl2_refstyle(b, shape, alpha, iterations, L2, x_scale):
         x_mean = x_np1 + th[n] * (x_np1 - x_n)
         x_n = x_np1
     return x_n * x_scale
+
+
+def admm_lsmr_refstyle(y, shape, cov, alpha, rho, iterations, iter_max,
+                       x_scale):
+    """ADMM deconvolution (BASELINE config 4, lsmr branch) doing the work the
+    reference does: scipy.ndimage.convolve with the DENSE Gaussian taps
+    (linear_operators.py:60-86), ndimage differences + concatenate
+    (:121-169), scipy.sparse.linalg.lsmr on the augmented LinearOperator
+    (tikhonov_linear_solver.py:146-158, :226-274), the outer loop of
+    admm_linear_solver.py:165-253.  Timing stand-in for the reference on the
+    GPU box; held to admm() in tests/test_oracle_golden.py."""
+    import scipy.ndimage
+    import scipy.sparse.linalg
+    d = len(shape)
+    taps = gaussian_taps(d, cov)
+    kf, kb = [], []
+    for a in range(d):
+        shp_f, shp_b = [1] * d, [1] * d
+        shp_f[d - 1 - a] = 2
+        shp_b[d - 1 - a] = 3
+        kf.append(np.array([1., -1.]).reshape(shp_f))
+        kb.append((-np.array([0., 1., -1.])).reshape(shp_b))
+    conv = scipy.ndimage.convolve
+    Zs = (d * shape[0],) + tuple(shape[1:]) if d > 1 else tuple(shape)
+    A = lambda x: conv(x.reshape(*shape), taps, mode="wrap").flatten()
+
+    def D(x):
+        x = x.reshape(*shape)
+        parts = [conv(x, kf[a], mode="constant") for a in range(d)]
+        return (np.concatenate(parts) if d > 1 else parts[0]).flatten()
+
+    def D_adj(p):
+        parts = np.array_split(p.reshape(*Zs), d)
+        out = conv(parts[0], kb[0], mode="constant")
+        for a in range(1, d):
+            out += conv(parts[a], kb[a], mode="constant")
+        return out.flatten()
+
+    x_scale = float(x_scale)
+    b = np.asarray(y, np.float64) / x_scale
+    x = np.array(b)
+    v = D(x)
+    w = np.zeros_like(v)
+    sr = np.sqrt(rho)
+    nb = b.size
+    for _ in range(iterations):
+        breg = v - w
+        x0 = np.clip(x, 0, np.inf)
+        fw = lambda z: np.concatenate((A(z), sr * D(z)))
+        bw = lambda z: A(z[:nb]) + sr * D_adj(z[nb:])
+        rhs = np.zeros(fw(x0).size)
+        rhs[:nb] = b
+        rhs[nb:] = sr * breg
+        op = scipy.sparse.linalg.LinearOperator(
+            shape=(rhs.size, x0.size), matvec=fw, rmatvec=bw)
+        x = scipy.sparse.linalg.lsmr(op, rhs, maxiter=iter_max, atol=0,
+                                     btol=0)[0]
+        x = np.clip(x, 0, np.inf)
+        t = D(x) + w
+        v = admm_prox_g(t.reshape(Zs), alpha / float(rho), d).reshape(-1)
+        w = t - v
+    return x * x_scale

@@ -298,27 +298,75 @@ def test_solve_batch_gloo_world_size_2(tmp_path):
     assert "BATCH_OK" in outs[0]
 
 
-def test_committed_bench_line_keeps_the_contract():
-    """The last bench line committed under profiles/ carries every field the
-    driver and the judge read (the bench itself needs a GPU)."""
-    import glob
-    import json
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
-    assert paths
-    d = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in d["roofline"], k
-    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
-    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-9
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in d["cpu_baseline"], k
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
-    assert abs(d["value"] * d["ms_per_step"] / 1e3 - d["n_gpus"]) < 1e-6
+def test_solve_batch_with_fewer_volumes_than_ranks(tmp_path):
+    """A rank that owns no volume takes part in the gather with a dummy of the
+    agreed shape (it used to raise while the others waited in the collective)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_FEW % ROOT)
+    port = 31500 + os.getpid() % 2000
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "FEW_OK" in outs[0]
 
+
+WORKER_FEW = '''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from nsol_amd.batch import solve_batch
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]),
+                        world_size=int(os.environ["WORLD_SIZE"]))
+out = solve_batch(lambda i: torch.full((7,), 3.0 + i), 1)
+rank = dist.get_rank()
+if rank == 0:
+    assert len(out) == 1 and torch.equal(out[0], torch.full((7,), 3.0))
+    print("FEW_OK")
+else:
+    assert out is None
+assert solve_batch(lambda i: None, 0) == ([] if rank == 0 else None)
+dist.destroy_process_group()
+'''
+
+
+def _bench(*argv, **env):
+    e = dict(os.environ, **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env:
+            e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] +
+                          list(argv), env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=300)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no external launcher: two child ranks
+    rendezvous (gloo), reduce, gather; rank 0 prints the one line.  --dry-run
+    skips the GPU work so the plumbing is testable here."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run", "--steps", "7", "--warmup", "1")
+    assert r.returncode == 0, r.stderr.decode()
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["steps"] == 7
+
+
+def test_bench_refuses_a_silent_single_gpu_run():
+    # under a launcher whose world size disagrees with --gpus
+    r = _bench("--gpus", "8", "--dry-run", WORLD_SIZE="1", RANK="0")
+    assert r.returncode == 2 and b"WORLD_SIZE" in r.stderr
+    # bare, RCCL backend, fewer devices than ranks (none in this container)
+    import torch
+    if torch.cuda.device_count() < 3:
+        r = _bench("--gpus", "3")
+        assert r.returncode == 2 and b"visible" in r.stderr
+    # a batch that does not divide over the ranks
+    r = _bench("--gpus", "2", "--batch", "3", WORLD_SIZE="2", RANK="0")
+    assert r.returncode == 2 and b"multiple" in r.stderr

@@ -407,3 +407,13 @@ def test_similarity_identities_of_the_reference_test(golden):
     assert round(abs(orc.sim_ncc(x, -x) + 1), 4) == 0
     assert round(abs(orc.sim_ncc(x, xo) - 1), 4) == 0
     assert round(abs(orc.sim_ncc(x, x2) - 1), 4) == 0
+
+
+def test_admm_refstyle_equals_restatement(golden):
+    """The reference-style ADMM (ndimage + SciPy's own lsmr; the CPU baseline
+    bench_admm.py times) against the reference's golden and the restatement."""
+    g = golden("admm")
+    y = g["y_3d"]
+    out = orc.admm_lsmr_refstyle(y, DEC["3d"], g["cov_3d"], 0.05, 0.5, 6, 8,
+                                 float(y.max()))
+    assert rel_l2(out, g["admm_lsmr_3d"]) < 1e-10
