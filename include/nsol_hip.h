@@ -19,11 +19,20 @@
  *  - wx, wy, wz are the INVERSE spacings 1/h of the x, y, z axes
  *    (reference kernels.py:102-112,160-190,240-286 scale taps by 1/spacing);
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
- *  - functions keep no state between calls, never allocate, never synchronise,
- *    never throw; they return 0 on success, a positive hipError_t on a HIP
- *    failure and NSOL_EINVAL (-1) on bad arguments.  (The only process-wide
- *    state are the experiment knobs of nsol_hip_set_param / _pd2(name, value)
- *    -- tile shapes, z-chunk length -- which never change results.);
+ *  - functions never allocate device memory, never synchronise, never throw;
+ *    they return 0 on success, a positive hipError_t on a HIP failure and
+ *    NSOL_EINVAL (-1) on bad arguments.  They keep no state between calls with
+ *    two exceptions, neither of which changes results: (1) the experiment
+ *    knobs of nsol_hip_set_param / _pd2 / _pdk / _conv (name, value) -- tile
+ *    shapes, z-chunk lengths; (2) nsol_pd_fusedk_iter_* / nsol_pd_run_* keep a
+ *    process-wide, mutex-protected table of footprint plans keyed by (current
+ *    device ordinal, element size, depth K, nz, ny, nx), each holding a few
+ *    hipEvents of launches still in flight (created on that device, read back
+ *    with hipEventQuery, destroyed when read or by the knob "pdk_forget").
+ *    The kernel variants of one shape (TV / Huber, l1 / l2, unit / non-unit
+ *    spacing) share a plan: it fixes the footprint geometry only.  The
+ *    package is written for one process per GPU; a process that drives several
+ *    devices gets one plan per device;
  *  - suffix _f32 / _f64 = element type of all volume arguments.  Scalars are
  *    always passed as double and rounded to the element type inside.
  */

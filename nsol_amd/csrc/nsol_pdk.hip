@@ -935,13 +935,23 @@ std::vector<Config> candidates(const Geom<T> &G) {
   return out;
 }
 
+// A plan belongs to one device (its events live there and boxes differ), one
+// element size, one depth and one volume shape.  The kernel variants of a shape
+// (TV / Huber, l1 / l2, unit / non-unit spacing) share it on purpose: they differ
+// in arithmetic per voxel, not in the footprint geometry the plan chooses.
 struct PlanKey {
-  int esize, k;
+  int device, esize, k;
   int64_t nz, ny, nx;
   bool operator<(const PlanKey &o) const {
-    return std::tie(esize, k, nz, ny, nx) < std::tie(o.esize, o.k, o.nz, o.ny, o.nx);
+    return std::tie(device, esize, k, nz, ny, nx) <
+           std::tie(o.device, o.esize, o.k, o.nz, o.ny, o.nx);
   }
 };
+inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return dev;
+}
 // Online autotuner.  A plan holds the model's best few configurations; while a
 // plan is exploring, every REAL launch of the run uses the next candidate and
 // is bracketed by two events that are read back later with hipEventQuery -- no
@@ -1027,7 +1037,7 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     if (cand.empty()) return -2;
     return NSOL_GO(cand[0]);
   }
-  const PlanKey key{(int)sizeof(T), K, G.nz, G.ny, G.nx};
+  const PlanKey key{current_device(), (int)sizeof(T), K, G.nz, G.ny, G.nx};
   std::lock_guard<std::mutex> lock(g_plans_mutex);
   auto it = g_plans.find(key);
   if (it == g_plans.end()) {
@@ -1172,7 +1182,8 @@ int nsol_hip_set_param_pdk(const char *name, int value) {
 
 int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx) {
   std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
-  auto it = nsol_pdk::g_plans.find(nsol_pdk::PlanKey{elem_size, k, nz, ny, nx});
+  auto it = nsol_pdk::g_plans.find(
+      nsol_pdk::PlanKey{nsol_pdk::current_device(), elem_size, k, nz, ny, nx});
   if (it == nsol_pdk::g_plans.end()) return -1;
   nsol_pdk::plan_poll(it->second, k);
   return it->second.chosen >= 0 ? 1 : 0;
@@ -1186,7 +1197,8 @@ int nsol_pd_fusedk_launches(int k) {
 int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,
                         int *waves, int *ntx, int64_t *zchunk) {
   std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
-  auto it = nsol_pdk::g_plans.find(nsol_pdk::PlanKey{elem_size, k, nz, ny, nx});
+  auto it = nsol_pdk::g_plans.find(
+      nsol_pdk::PlanKey{nsol_pdk::current_device(), elem_size, k, nz, ny, nx});
   if (it == nsol_pdk::g_plans.end() || it->second.chosen < 0) return NSOL_EINVAL;
   const nsol_pdk::Config &c = it->second.cand[it->second.chosen];
   if (waves) *waves = c.nw;

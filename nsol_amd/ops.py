@@ -29,6 +29,21 @@ def _chk(t):
     return t
 
 
+def _same(x, *others):
+    """Multi-operand kernels take their launch geometry and element type from
+    the first operand: every other operand must be a contiguous device tensor
+    of the same dtype and length, or the kernel would read out of bounds /
+    reinterpret the bytes."""
+    _chk(x)
+    for t in others:
+        _chk(t)
+        if t.dtype != x.dtype or t.numel() != x.numel():
+            raise ValueError(
+                "operand mismatch: %s[%d] against %s[%d]" %
+                (str(t.dtype), t.numel(), str(x.dtype), x.numel()))
+    return x
+
+
 def dims3(shape):
     """(ndim, nz, ny, nx) of an N-D volume shape (N = 1, 2, 3)."""
     shape = tuple(int(s) for s in shape)
@@ -131,18 +146,22 @@ def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
 
 # --------------------------------------------------------- element-wise ----
 def lincomb2(a, x, b, y, out=None):
-    _chk(x), _chk(y)
+    _same(x, y)
     if out is None:
         out = empty_like(x)
+    else:
+        _same(x, out)
     _lib.check(_fn("lincomb2", x)(_p(out), float(a), _p(x), float(b), _p(y),
                                   x.numel(), stream_ptr()), "nsol_lincomb2")
     return out
 
 
 def lincomb3(a, x, b, y, c, z, out=None):
-    _chk(x), _chk(y), _chk(z)
+    _same(x, y, z)
     if out is None:
         out = empty_like(x)
+    else:
+        _same(x, out)
     _lib.check(_fn("lincomb3", x)(_p(out), float(a), _p(x), float(b), _p(y),
                                   float(c), _p(z), x.numel(), stream_ptr()),
                "nsol_lincomb3")
@@ -183,7 +202,7 @@ def prox_dual_clamp(x, den=1.0, out=None):
 
 
 def prox_ell2(x, bt, tau, out=None):
-    _chk(x), _chk(bt)
+    _same(x, bt)
     if out is None:
         out = empty_like(x)
     _lib.check(_fn("prox_ell2", x)(_p(out), _p(x), _p(bt), float(tau),
@@ -192,7 +211,7 @@ def prox_ell2(x, bt, tau, out=None):
 
 
 def prox_ell1(x, bt, tau, out=None):
-    _chk(x), _chk(bt)
+    _same(x, bt)
     if out is None:
         out = empty_like(x)
     _lib.check(_fn("prox_ell1", x)(_p(out), _p(x), _p(bt), float(tau),
@@ -215,7 +234,7 @@ def _workspace(dev):
 
 def dot(x, y):
     """sum(x*y) accumulated in float64; returns a Python float (syncs)."""
-    _chk(x), _chk(y)
+    _same(x, y)
     ws, res = _workspace(x.device)
     _lib.check(_fn("dot", x)(_p(x), _p(y), x.numel(), _p(res), _p(ws),
                              stream_ptr()), "nsol_dot")
@@ -239,7 +258,7 @@ def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None, minus=None):
             _p(r), _p(g), r.numel(), LOSSES[loss], float(f_scale), _p(res),
             _p(ws), stream_ptr()), "nsol_loss_cost_grad")
     else:
-        _chk(minus)
+        _same(r, minus)
         _lib.check(_fn("loss_residual_cost_grad", r)(
             _p(r), _p(minus), _p(g), r.numel(), LOSSES[loss], float(f_scale),
             _p(res), _p(ws), stream_ptr()), "nsol_loss_residual_cost_grad")
@@ -250,7 +269,7 @@ def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None):
     """(sum |grad x|^2, g + alpha * grad_adj(grad x)) in one pass over x
     (the regulariser's share of tikhonov_linear_solver.py:201-208 with
     B = gradient).  out may be g."""
-    _chk(x), _chk(g)
+    _same(x, g)
     ndim, nz, ny, nx = dims3(shape)
     if out is None:
         out = empty_like(g)
@@ -266,7 +285,7 @@ _ws8 = {}
 
 def pair_stats(x, y, mx=0.0, my=0.0):
     """NumPy array of the 8 sums documented at nsol_pair_stats_* (syncs)."""
-    _chk(x), _chk(y)
+    _same(x, y)
     ws, _ = _workspace(x.device)
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     if key not in _ws8:
@@ -459,6 +478,13 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
     """u_top = c_av*Av + c_u*u_top; u_bot = c_bv*B(v) + c_u*u_bot;
     returns ||[u_top; u_bot]||^2 (sync=False: the device scalar, not read
     back)."""
+    _same(Av, v, u_top)
+    if u_bot is not None:
+        _chk(u_bot)
+        rows = (len(tuple(shape)) if bmode == B_GRAD else 1) * Av.numel()
+        if u_bot.dtype != Av.dtype or u_bot.numel() != rows:
+            raise ValueError("lsmr_u_update: lower block has %d elements, "
+                             "expected %d" % (u_bot.numel(), rows))
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Av.numel())
     ws, res = _workspace(Av.device)
     _lib.check(_fn("lsmr_u_update", Av)(
@@ -471,6 +497,13 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
 def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
                   sync=True):
     """v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v; returns ||v||^2."""
+    _same(Atu, v)
+    if u_bot is not None:
+        _chk(u_bot)
+        rows = (len(tuple(shape)) if bmode == B_GRAD else 1) * Atu.numel()
+        if u_bot.dtype != Atu.dtype or u_bot.numel() != rows:
+            raise ValueError("lsmr_v_update: lower block has %d elements, "
+                             "expected %d" % (u_bot.numel(), rows))
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Atu.numel())
     ws, res = _workspace(Atu.device)
     _lib.check(_fn("lsmr_v_update", Atu)(
@@ -483,6 +516,7 @@ def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
 def lsmr_hx_update(hbar, x, h, v, c_hbar, c_x, c_h, c_v, sync=True):
     """hbar = h + c_hbar*hbar; x += c_x*hbar; h = c_v*v + c_h*h;
     returns ||x||^2."""
+    _same(x, hbar, h, v)
     ws, res = _workspace(x.device)
     _lib.check(_fn("lsmr_hx_update", x)(
         _p(hbar), _p(x), _p(h), _p(v), x.numel(), float(c_hbar), float(c_x),

@@ -14,8 +14,20 @@ from .symbolic import Sym, TraceAbort, TauSym
 
 # small cache of b/x_scale on the device, keyed by the identity of the host
 # array the caller's lambda closes over (run_denoising.py:109-131 pass x0=b on
-# every call).  Mutating that array in place between calls is not supported.
+# every call) AND by a fingerprint of its contents, so that an array the caller
+# changed in place between runs is uploaded again instead of served stale.
 _bt_cache = []
+
+
+def _fingerprint(arr):
+    """Cheap content signature: up to 4096 evenly spaced elements plus the
+    ends.  Catches in-place rescaling, re-noising, refilling; a change confined
+    to elements between the samples is not seen (copy the array instead)."""
+    flat = arr.reshape(-1)
+    if flat.size <= 4096:
+        return flat.tobytes()
+    step = flat.size // 4096
+    return flat[::step].tobytes() + flat[-1:].tobytes()
 
 
 def scaled_data_on_device(x0, x_scale, like):
@@ -25,7 +37,7 @@ def scaled_data_on_device(x0, x_scale, like):
         return ops.scale(src, float(x_scale), divide=True)
     arr = np.asarray(x0)
     key = (id(x0), arr.__array_interface__["data"][0], arr.size,
-           float(x_scale), like.dtype, like.device.index)
+           float(x_scale), like.dtype, like.device.index, _fingerprint(arr))
     for k, ref, val in _bt_cache:
         if k == key and ref is x0:
             return val

@@ -797,6 +797,44 @@ def test_x_scale_invariance(nsol, golden, k):
                         decimals=7) == 0, name
 
 
+def test_misuse_fails_loudly_instead_of_reading_out_of_bounds(nsol):
+    """ops.* take launch geometry and element type from the first operand; a
+    caller operator that answers in another dtype, operands of different
+    length and GPU failures inside a callable raise instead of being papered
+    over by the host bridge."""
+    import torch
+    from nsol_amd import ops
+    from nsol_amd._lib import NsolHipError
+    from nsol_amd.bridge import BridgedCallable
+    a = torch.ones(100, device="cuda")
+    with pytest.raises(ValueError):
+        ops.lincomb2(1.0, a, 1.0, torch.ones(50, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.dot(a, torch.ones(100, device="cuda", dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ops.lsmr_hx_update(a, a.clone(), a.clone(), torch.ones(7, device="cuda"),
+                           0.1, 0.1, 0.1, 0.1)
+    wrong = BridgedCallable(lambda t: t.double(), np.float32)
+    with pytest.raises(ValueError):
+        wrong(a)
+
+    def failing(t):
+        raise NsolHipError("nsol_grad failed with hipError_t 719")
+    with pytest.raises(NsolHipError):
+        BridgedCallable(failing, np.float32)(a)
+    # a NumPy-only callable still takes the host bridge
+    host = BridgedCallable(lambda t: np.asarray(t) * 2.0, np.float32)
+    out = host(a)
+    assert host.on_device is False and float(out.sum()) == 200.0
+    # the data-term cache notices an array changed in place between runs
+    from nsol_amd.proximal_operators import scaled_data_on_device
+    b = np.arange(5000, dtype=np.float64)
+    first = scaled_data_on_device(b, 2.0, a).clone()
+    b += 1.0
+    second = scaled_data_on_device(b, 2.0, a)
+    assert float((second - first).abs().max()) == 0.5
+
+
 # ------------------------------------------------- observer side, SURVEY 8(f3)
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
 def test_prior_measures_match_reference_goldens(nsol, golden, k):

@@ -370,3 +370,30 @@ def test_bench_refuses_a_silent_single_gpu_run():
     # a batch that does not divide over the ranks
     r = _bench("--gpus", "2", "--batch", "3", WORLD_SIZE="2", RANK="0")
     assert r.returncode == 2 and b"multiple" in r.stderr
+
+
+def test_bridge_tells_gpu_failures_from_numpy_only_callables():
+    """BridgedCallable falls back to the host round trip only for callables
+    that cannot take a tensor; a failing launch or an out-of-memory error is
+    re-raised (nsol_amd/bridge.py)."""
+    from nsol_amd.bridge import _is_gpu_failure
+    from nsol_amd._lib import NsolHipError
+    assert _is_gpu_failure(NsolHipError("nsol_grad failed with hipError_t 719"))
+    assert _is_gpu_failure(RuntimeError("HIP out of memory. Tried to allocate"))
+    assert _is_gpu_failure(RuntimeError("HIP error: an illegal memory access"))
+    assert not _is_gpu_failure(TypeError("can't convert cuda:0 device type "
+                                         "tensor to numpy"))
+    assert not _is_gpu_failure(AttributeError("'Tensor' has no attribute x"))
+    assert not _is_gpu_failure(ValueError("operands could not be broadcast"))
+
+
+def test_data_term_cache_sees_in_place_changes():
+    from nsol_amd.proximal_operators import _fingerprint
+    a = np.arange(100000, dtype=np.float64)
+    f0 = _fingerprint(a)
+    a *= 2.0
+    assert _fingerprint(a) != f0
+    b = np.arange(10.0)
+    f1 = _fingerprint(b)
+    b[3] = -1.0
+    assert _fingerprint(b) != f1
