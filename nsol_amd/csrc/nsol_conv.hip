@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
 
 int g_blur3_zchunk = 0; // planes per z chunk of the one-pass blur; 0 = by the round model
 int g_blur3_lxb = 16;   // lanes per row of the one-pass blur's tile (experiment knob)
+int g_blur3_dma = 1;    // 1: LDS-DMA staged kernel for 16-byte rows; 0: k_blur3_wrap(_pp)
 int g_corr_ra = 8;   // outputs per lane along a strided axis (experiment knob)
 int g_corr_xv = 1;   // output vectors per lane in the x pass (experiment knob)
 
@@ -677,6 +678,215 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The one-pass blur with the input staged by LDS-DMA (k_blur3_dma).
+//
+// k_blur3_wrap_pp above is bound by two things its structure cannot fix: the x
+// pass pulls five overlapping vectors per output vector through the L1, with the
+// whole workgroup waiting out the HBM latency of every plane (no registers left
+// for a prefetch: the z window holds 48), and its multiply / add pairs keep the
+// SIMDs busy for 0.26 ms at 512^3 (276 vector instructions per wave and plane).
+// Here
+//   * the raw tile of plane s + 2 (rows and columns including the halo, periodic
+//     wrap applied to the per-lane SOURCE address) travels global -> LDS with
+//     global_load_lds_dwordx4 while plane s + 1 is filtered along x and plane s
+//     along y and z: the loads cost no registers, are issued a whole phase ahead
+//     and every input byte crosses the L1 once;
+//   * one barrier per plane: a phase runs the x pass of plane s + 1 (raw tile ->
+//     x-filtered tile, both in LDS) and the y / z passes of plane s; the output of
+//     plane s is stored at the START of the next phase, so that the vmcnt(0) in
+//     front of the barrier finds loads and stores that had a phase to complete;
+//   * taps are applied with fused multiply-adds (v_pk_fma_f32 / v_fma_f64: half
+//     the vector instructions; the blur is held to the reference by tolerance --
+//     a separable evaluation of its dense kernel differs by rounding anyway);
+//     (symmetric taps only -- every Gaussian; others take k_blur3_wrap_pp);
+//   * tiles are dealt so that every XCD works on a run of consecutive tiles
+//     (x fastest, then y): the halo columns and rows neighbouring tiles share are
+//     then hits in that XCD's L2 instead of second trips to HBM.
+// LDS per workgroup at 16 lanes per row, 13 taps, float: 2 raw tiles of 24 KiB +
+// 2 x-filtered tiles of 19 KiB = 86 KiB.
+// ---------------------------------------------------------------------------
+template <typename V, typename T>
+__device__ __forceinline__ V splat(T w) {
+  V r;
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(V) / sizeof(T)); ++k) r[k] = w;
+  return r;
+}
+
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+  return __builtin_fmaf(a, b, c);
+}
+__device__ __forceinline__ double fma1(double a, double b, double c) {
+  return __builtin_fma(a, b, c);
+}
+
+constexpr int kDmaLxb = 16;
+
+template <typename T, int VEC, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_blur3_dma(
+    const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
+    Taps<T> tz, Taps<T> ty, Taps<T> tx, int ntx, int nty, int nzc, int zchunk,
+    int per_xcd) {
+  typedef typename VecOf<T, VEC>::type V;
+  constexpr int lxb = kDmaLxb;                 // lanes per tile row (compile time: the
+                                               // LDS strides fold into the addresses)
+  constexpr int R = NT / 2;
+  constexpr int NBH = (R + VEC - 1) / VEC;     // halo vectors on each side of a row
+  constexpr int NB = 2 * NBH + 1;
+  constexpr int NTHR = NW * 64;
+  constexpr int MAXP = 3;                      // LDS-DMA pieces per wave and plane
+  // the taps are symmetric (checked on the host): tap t is read as w[min(t, NT-1-t)],
+  // which leaves 3 * (R + 1) scalars live instead of 3 * NT (39 of them at 13 taps
+  // overflow the scalar registers and come back as a v_readlane per use)
+  auto sym = [](int t) { return t <= R ? t : NT - 1 - t; };
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // every XCD (block id mod 8) takes a run of per_xcd consecutive tiles
+  const int total = ntx * nty * nzc;
+  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= total) return;
+  const int bx = logical % ntx;
+  const int by = (logical / ntx) % nty;
+  const int bz = logical / (ntx * nty);
+
+  constexpr int tyr = NTHR / lxb;              // rows of the tile = rows of lanes
+  constexpr int frows = tyr + 2 * R;           // rows of the raw / x-filtered tile
+  constexpr int rl = lxb + 2 * NBH;            // vectors per raw row
+  constexpr int raw_vecs = frows * rl;
+  constexpr int npieces = (raw_vecs + 63) >> 6;  // 1 KiB per wave-instruction
+  constexpr int raw_stride = npieces * 64;     // vectors per raw buffer
+  constexpr int xf_stride = frows * lxb;
+  static_assert(npieces <= MAXP * NW, "raw tile needs more LDS-DMA pieces per wave");
+  V *raw = reinterpret_cast<V *>(smem_raw);
+  V *xf = raw + 2 * (size_t)raw_stride;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = tid / lxb;
+  const int lx = tid - row * lxb;
+  const int nxv = (int)(nx / VEC);
+  const int xv = bx * lxb + lx;
+  const int64_t y0 = (int64_t)by * tyr;
+  const bool owner = xv < nxv && (y0 + row < ny);
+  const int64_t plane = ny * nx;
+
+  // LDS-DMA source offsets (elements inside a plane) of this lane's pieces:
+  // piece k = wave + j * NW covers the raw vectors [64 k, 64 k + 64)
+  uint32_t src_off[MAXP];
+#pragma unroll
+  for (int j = 0; j < MAXP; ++j) {
+    // (lanes past the end of the raw tile re-load its first vector into the
+    // padding behind it: no predicate to carry through the loop)
+    int i = (wave + j * NW) * 64 + lane;
+    if (i >= raw_vecs) i = 0;
+    const int rr = i / rl;
+    const int cc = i - rr * rl;
+    int64_t yy = (y0 - R + rr) % ny;
+    if (yy < 0) yy += ny;
+    int xx = (bx * lxb - NBH + cc) % nxv;
+    if (xx < 0) xx += nxv;
+    src_off[j] = (uint32_t)(yy * nx + (int64_t)xx * VEC);
+  }
+  auto stage = [&](int64_t z, int buf) {       // plane z -> raw[buf], asynchronously
+    const T *pl = x + z * plane;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      if (j * NW >= npieces) break;              // (compile time)
+      const int k = wave + j * NW;
+      if ((j + 1) * NW <= npieces || k < npieces)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(pl + src_off[j]),
+            (__attribute__((address_space(3))) void *)(raw + (size_t)buf * raw_stride +
+                                                       (size_t)k * 64),
+            16, 0, 0);
+    }
+  };
+  // x pass: raw[buf] -> xf[buf]; a lane filters footprint row `row` and, in the
+  // first waves, the halo row `tyr + row`
+  const bool second = row < 2 * R;
+  const bool second_wave = __builtin_amdgcn_readfirstlane((int)second) != 0;
+  auto xrow = [&](const V *rb, V *xb, int fr) {
+    const V *w = rb + (size_t)fr * rl + lx;
+    T win[NB * VEC];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const V t = w[b];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) win[b * VEC + k] = t[k];
+    }
+    V res;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      T acc = tx.w[0] * win[NBH * VEC + k - R];
+#pragma unroll
+      for (int t = 1; t < NT; ++t)
+        acc = fma1(tx.w[sym(t)], win[NBH * VEC + k - R + t], acc);
+      res[k] = acc;
+    }
+    xb[(size_t)fr * lxb + lx] = res;
+  };
+  auto xpass = [&](int buf) {
+    const V *rb = raw + (size_t)buf * raw_stride;
+    V *xb = xf + (size_t)buf * xf_stride;
+    xrow(rb, xb, row);
+    if (second_wave) {
+      if (second) xrow(rb, xb, row + tyr);
+    }
+  };
+
+  const int64_t zbeg = (int64_t)bz * zchunk;
+  int64_t zend = zbeg + zchunk;
+  if (zend > nz) zend = nz;
+  const int nsteps = (int)(zend - zbeg) + 2 * R;    // planes zbeg - R .. zend + R - 1
+  int zw = (int)((zbeg - R) % nz);                  // plane of the next stage()
+  if (zw < 0) zw += (int)nz;
+  auto next_plane = [&]() {
+    const int z = zw;
+    if (++zw == (int)nz) zw = 0;
+    return (int64_t)z;
+  };
+  V ring[NT - 1];                                   // xy-filtered planes, oldest first
+#pragma unroll
+  for (int t = 0; t + 1 < NT; ++t) ring[t] = splat<V, T>(T(0));
+  T *own = out + (y0 + row) * nx + (int64_t)xv * VEC;
+
+  // prologue: plane 0 staged and filtered along x, plane 1 staged
+  stage(next_plane(), 0);
+  __syncthreads();
+  if (nsteps > 1) stage(next_plane(), 1);
+  xpass(0);
+  __syncthreads();
+  V pending = splat<V, T>(T(0));
+  int64_t pending_z = -1;
+#pragma unroll 1
+  for (int st = 0; st < nsteps; ++st) {
+    // (raw[(st + 1) & 1] holds plane st + 1, xf[st & 1] the x-filtered plane st)
+    if (pending_z >= 0 && owner) *reinterpret_cast<V *>(own + pending_z * plane) = pending;
+    if (st + 2 < nsteps) stage(next_plane(), st & 1);
+    if (st + 1 < nsteps) xpass((st + 1) & 1);
+    const V *col = xf + (size_t)(st & 1) * xf_stride + (size_t)row * lxb + lx;
+    V v = splat<V, T>(ty.w[0]) * col[0];
+#pragma unroll
+    for (int t = 1; t < NT; ++t)
+      v = __builtin_elementwise_fma(splat<V, T>(ty.w[sym(t)]), col[(size_t)t * lxb], v);
+    pending_z = -1;
+    if (st >= 2 * R) {
+      V acc = splat<V, T>(tz.w[0]) * ring[0];
+#pragma unroll
+      for (int t = 1; t + 1 < NT; ++t)
+        acc = __builtin_elementwise_fma(splat<V, T>(tz.w[sym(t)]), ring[t], acc);
+      pending = __builtin_elementwise_fma(splat<V, T>(tz.w[0]), v, acc);
+      pending_z = zbeg + (st - 2 * R);
+    }
+#pragma unroll
+    for (int t = 0; t + 2 < NT; ++t) ring[t] = ring[t + 1];
+    ring[NT - 2] = v;
+    __syncthreads();                                // vmcnt(0): staged plane and store
+  }
+  if (pending_z >= 0 && owner) *reinterpret_cast<V *>(own + pending_z * plane) = pending;
+}
+
 inline int blur3_cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -692,7 +902,7 @@ inline int blur3_cu_count() {
 
 template <typename T, int VEC, int NT>
 int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
-                 const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
+                 const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, bool symmetric,
                  hipStream_t st) {
   constexpr int NW = 16;
   constexpr int R = NT / 2;
@@ -723,6 +933,32 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t blocks = ntx * nty * nzc;
   if (blocks > 0x7fffffff) return -2;
+  if (g_blur3_dma && symmetric && nx % VEC == 0 && g_blur3_lxb == kDmaLxb) {
+    // LDS-DMA staged kernel (tiles of kDmaLxb lanes per row whatever the row length)
+    constexpr int NBH = (R + VEC - 1) / VEC;
+    constexpr int dl = kDmaLxb;
+    constexpr int dtyr = (NW * 64) / dl;
+    constexpr int frows = dtyr + 2 * R;
+    constexpr int npieces = (frows * (dl + 2 * NBH) + 63) / 64;
+    constexpr size_t lds = (2 * (size_t)npieces * 64 + 2 * (size_t)frows * dl) * 16;
+    static_assert(lds <= 160 * 1024, "LDS-DMA blur tile does not fit");
+    const int64_t dntx = (nxv + dl - 1) / dl, dnty = (ny + dtyr - 1) / dtyr;
+    if (ny * nx < ((int64_t)1 << 31) && dntx * dnty * nzc < ((int64_t)1 << 28)) {
+      const int64_t tiles = dntx * dnty * nzc;
+      const int per_xcd = (int)((tiles + 7) / 8);
+      auto kern = k_blur3_dma<T, VEC, NT, NW>;
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NW * 64), lds, st, x,
+                         out, nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc,
+                         (int)zchunk, per_xcd);
+      return launch_status();
+    }
+  }
   // two planes per step where the registers allow it
   constexpr int PP = (NT >= 5 && NT <= (sizeof(T) == 4 ? 13 : 11)) ? 2 : 1;
   // (ragged rows: one plane per step, the element-wise edge path needs the registers)
@@ -771,9 +1007,13 @@ int corr3_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
     ty.w[t] = t < ntaps ? (T)ty_host[t] : T(0);
     tx.w[t] = t < ntaps ? (T)tx_host[t] : T(0);
   }
+  bool symmetric = true;
+  for (int t = 0; t < ntaps / 2; ++t)
+    symmetric = symmetric && tz.w[t] == tz.w[ntaps - 1 - t] &&
+                ty.w[t] == ty.w[ntaps - 1 - t] && tx.w[t] == tx.w[ntaps - 1 - t];
   hipStream_t st = as_stream(stream);
 #define NSOL_B3_CASE(N) \
-  case N: return launch_blur3<T, VEC, N>(x, out, nz, ny, nx, tz, ty, tx, st);
+  case N: return launch_blur3<T, VEC, N>(x, out, nz, ny, nx, tz, ty, tx, symmetric, st);
   switch (ntaps) {
     NSOL_B3_CASE(3) NSOL_B3_CASE(5) NSOL_B3_CASE(7) NSOL_B3_CASE(9)
     NSOL_B3_CASE(11) NSOL_B3_CASE(13) NSOL_B3_CASE(15) NSOL_B3_CASE(17)
@@ -826,6 +1066,7 @@ int nsol_hip_set_param_conv(const char *name, int value) {
   else if (!strcmp(name, "corr_xv")) g_corr_xv = value;
   else if (!strcmp(name, "corr_blur3_lxb")) g_blur3_lxb = value;
   else if (!strcmp(name, "corr_blur3_zchunk")) g_blur3_zchunk = value;
+  else if (!strcmp(name, "corr_blur3_dma")) g_blur3_dma = value;
   else return NSOL_EINVAL;
   return 0;
 }
