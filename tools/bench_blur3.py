@@ -16,13 +16,16 @@ taps = K.Kernels1D().get_gaussian(cov)
 x = torch.rand(n ** 3, device="cuda", dtype=dt)
 out = torch.empty_like(x)
 esize = x.element_size()
-cfgs = [(1, 0), (0, 0), (1, 64), (1, 171), (1, 256), (1, 43)]
+# (dma, zchunk, waves per workgroup, stagger)
+cfgs = [(1, 0, 16, 0), (0, 0, 16, 0), (1, 64, 16, 0), (1, 171, 16, 0), (1, 0, 8, 0)]
 times = {c: [] for c in cfgs}
 res = {}
 for rnd in range(5):
-    for dma, zc in cfgs:
+    for dma, zc, nw, sg in cfgs:
+        _lib.set_param("corr_blur3_stagger", sg)
         _lib.set_param("corr_blur3_dma", dma)
         _lib.set_param("corr_blur3_zchunk", zc)
+        _lib.set_param("corr_blur3_nw", nw)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
@@ -30,19 +33,19 @@ for rnd in range(5):
                 raise SystemExit("one-pass kernel does not apply")
         e1.record(); torch.cuda.synchronize()
         if rnd > 0:
-            times[(dma, zc)].append(e0.elapsed_time(e1) / 10)
-        if (dma, zc) not in res:
-            res[(dma, zc)] = out.clone()
+            times[(dma, zc, nw, sg)].append(e0.elapsed_time(e1) / 10)
+        if (dma, zc, nw, sg) not in res:
+            res[(dma, zc, nw, sg)] = out.clone()
 _lib.reset_params()
-for (dma, zc), ts in times.items():
+for (dma, zc, nw, sg), ts in times.items():
     ms = float(np.median(ts))
     print(json.dumps({"kernel": "k_blur3_dma" if dma else "k_blur3_wrap_pp",
-                      "taps": len(taps), "zchunk": zc, "ms": round(ms, 4),
+                      "taps": len(taps), "zchunk": zc, "waves": nw, "stagger": sg, "ms": round(ms, 4),
                       "min_ms": round(float(np.min(ts)), 4),
                       "GBps_algorithmic": round(2.0 * esize * n ** 3 / ms / 1e6, 1),
                       "frac_of_8TBps": round(2.0 * esize * n ** 3 / ms / 1e6 / 8000, 3)}),
           flush=True)
-ref = res[(0, 0)]
+ref = res[(0, 0, 16, 0)]
 for c, r in res.items():
     print(json.dumps({"cfg": c, "max_abs_vs_register_kernel":
                       float((r - ref).abs().max())}))
@@ -50,4 +53,4 @@ o3 = x
 for axis in (0, 1, 2):
     o3 = ops.corr_axis(o3, shape, axis, taps, len(taps) // 2, "wrap")
 print(json.dumps({"max_abs_dma_vs_three_passes":
-                  float((o3 - res[(1, 0)]).abs().max())}))
+                  float((o3 - res[(1, 0, 16, 0)]).abs().max())}))
