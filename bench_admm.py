@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--data-loss", default="linear")
     ap.add_argument("--repeat", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[],
+                    help="library knob name=value (A/B runs, e.g. "
+                         "corr_blur3_dma=0 for the register-window blur)")
     ap.add_argument("--cpu-sample", type=int, default=64,
                     help="edge length of the CPU baseline's volume (64: about "
                          "15 s for one ADMM iteration of LSMR(10))")
@@ -123,6 +126,10 @@ def main():
     from nsol_amd import ops
     from nsol_amd.synthetic import synth_volume
 
+    from nsol_amd import _lib
+    for kv in args.param:
+        k, v = kv.split("=")
+        _lib.set_param(k, int(v))
     n = args.size
     shape = (n, n, n)
     nvox = n ** 3
@@ -176,6 +183,7 @@ def main():
                                "dimension=3 (BASELINE config 4)" % n,
                    "iterations": args.iterations, "iter_max": args.iter_max,
                    "minimizer": args.minimizer, "data_loss": args.data_loss,
+                   "knobs": args.param,
                    "execution": execution},
         "rel_change_vs_input": rel_change, "finite": finite}
     if args.minimizer == "lsmr":
