@@ -30,6 +30,7 @@ struct PdTuning {
   int ry = 0;       // rows per lane (1, 2 or 4); 0 = auto
   int force_two_pass = 0;
   int xcd_map = 1;  // 0 = plain block order, 1 = XCD-aware slabs
+  int rag = 1;      // unaligned rows: 1 = element-aligned 16-byte accesses, 0 = 4-byte
 };
 PdTuning g_tune;
 
@@ -100,7 +101,11 @@ __global__ __launch_bounds__(kBlock) void k_primal_step(
 // ---------------------------------------------------------------------------
 // single-pass fused form
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int LX, int RY, int NDIM>
+// RAG: rows that are not a multiple of VEC elements / arrays that are not 16-byte
+// aligned (ldv_rag / stv_rag; the elements of a row's last vector that lie behind
+// the row read as zero -- exactly the "u := 0 past the last index" of the forward
+// difference -- and are never stored).
+template <typename T, int VEC, int LX, int RY, int NDIM, bool RAG = false>
 __global__ __launch_bounds__(kBlock) void k_pd_fused(
     const T *__restrict__ xbar_in, T *__restrict__ xbar_out, T *x,
     const T *__restrict__ bt, const T *__restrict__ p_in,
@@ -139,6 +144,16 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
   const int64_t x0 = ((int64_t)tx * LX + lx) * VEC;
   const int64_t y0 = (int64_t)ty * TY + (int64_t)(wave * LY + ly) * RY;
   const bool xin = x0 < G.nx;
+  // valid elements of this lane's vector (RAG: the row may end inside it)
+  const int nval = !RAG ? VEC : (G.nx - x0 >= VEC ? VEC : (int)(xin ? G.nx - x0 : 0));
+  auto ld = [&](const T *q, T (&v)[VEC]) {
+    if constexpr (RAG) ldv_rag<T, VEC>(q, v, nval);
+    else ldv<T, VEC>(q, v);
+  };
+  auto st = [&](T *q, const T (&v)[VEC]) {
+    if constexpr (RAG) stv_rag<T, VEC>(q, v, nval);
+    else stv<T, VEC>(q, v);
+  };
   bool rin[RY];
 #pragma unroll
   for (int r = 0; r < RY; ++r) rin[r] = xin && (y0 + r < G.ny);
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
   for (int r = 0; r < RY; ++r) {
     zero(xc[r]);
     zero(pzprev[r]);
-    if (rin[r]) ldv<T, VEC>(xbar_in + off + r * G.sy, xc[r]);
+    if (rin[r]) ld(xbar_in + off + r * G.sy, xc[r]);
   }
   if constexpr (NDIM >= 3) {
     if (zbeg > 0) {
@@ -181,8 +196,8 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
         if (rin[r]) {
           T xm[VEC], pm[VEC];
           zero(pm);
-          ldv<T, VEC>(xbar_in + off - G.sz + r * G.sy, xm);
-          if (S.has_p) ldv<T, VEC>(pin_z + off - G.sz + r * G.sy, pm);
+          ld(xbar_in + off - G.sz + r * G.sy, xm);
+          if (S.has_p) ld(pin_z + off - G.sz + r * G.sy, pm);
 #pragma unroll
           for (int k = 0; k < VEC; ++k)
             pzprev[r][k] = dual_update(pm[k], xc[r][k], xm[k], G.wz, S);
@@ -202,13 +217,13 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
       zero(pxo[r]); zero(pyo[r]); zero(pzo[r]);
       if (rin[r]) {
         const int64_t o = off + r * G.sy;
-        if (znext) ldv<T, VEC>(xbar_in + o + G.sz, xn[r]);
-        ldv<T, VEC>(x + o, xv[r]);
-        ldv<T, VEC>(bt + o, bv[r]);
+        if (znext) ld(xbar_in + o + G.sz, xn[r]);
+        ld(x + o, xv[r]);
+        ld(bt + o, bv[r]);
         if (S.has_p) {
-          ldv<T, VEC>(pin_x + o, pxo[r]);
-          if constexpr (NDIM >= 2) ldv<T, VEC>(pin_y + o, pyo[r]);
-          if constexpr (NDIM >= 3) ldv<T, VEC>(pin_z + o, pzo[r]);
+          ld(pin_x + o, pxo[r]);
+          if constexpr (NDIM >= 2) ld(pin_y + o, pyo[r]);
+          if constexpr (NDIM >= 3) ld(pin_z + o, pzo[r]);
         }
       }
     }
@@ -228,10 +243,10 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
     T xdown[VEC], xup[VEC], pyup[VEC];
     zero(xdown); zero(xup); zero(pyup);
     if constexpr (NDIM >= 2) {
-      if (has_down) ldv<T, VEC>(xbar_in + off + RY * G.sy, xdown);
+      if (has_down) ld(xbar_in + off + RY * G.sy, xdown);
       if (has_up) {
-        ldv<T, VEC>(xbar_in + off - G.sy, xup);
-        if (S.has_p) ldv<T, VEC>(pin_y + off - G.sy, pyup);
+        ld(xbar_in + off - G.sy, xup);
+        if (S.has_p) ld(pin_y + off - G.sy, pyup);
       }
     }
 
@@ -314,11 +329,11 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
       }
       if (rin[r]) {
         const int64_t o = off + r * G.sy;
-        stv<T, VEC>(pout_x + o, pxn[r]);
-        if constexpr (NDIM >= 2) stv<T, VEC>(pout_y + o, pyn[r]);
-        if constexpr (NDIM >= 3) stv<T, VEC>(pout_z + o, pzn[r]);
-        stv<T, VEC>(x + o, xo_new);
-        stv<T, VEC>(xbar_out + o, xb_new);
+        st(pout_x + o, pxn[r]);
+        if constexpr (NDIM >= 2) st(pout_y + o, pyn[r]);
+        if constexpr (NDIM >= 3) st(pout_z + o, pzn[r]);
+        st(x + o, xo_new);
+        st(xbar_out + o, xb_new);
       }
       if constexpr (NDIM >= 3) {
 #pragma unroll
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_fused(
   }
 }
 
-template <typename T, int VEC, int LX, int RY, int NDIM>
+template <typename T, int VEC, int LX, int RY, int NDIM, bool RAG = false>
 int launch_fused_t(const T *xbar_in, T *xbar_out, T *x, const T *bt,
                    const T *p_in, T *p_out, const Geom<T> &G,
                    const PdScalars<T> &S, hipStream_t st) {
@@ -358,24 +373,24 @@ int launch_fused_t(const T *xbar_in, T *xbar_out, T *x, const T *bt,
     blocks = 8 * slab * ntx * nzc;
   }
   if (blocks > 0x7fffffff) return NSOL_EINVAL;
-  hipLaunchKernelGGL((k_pd_fused<T, VEC, LX, RY, NDIM>), dim3((unsigned)blocks),
+  hipLaunchKernelGGL((k_pd_fused<T, VEC, LX, RY, NDIM, RAG>), dim3((unsigned)blocks),
                      dim3(kBlock), 0, st, xbar_in, xbar_out, x, bt, p_in, p_out,
                      G, S, (int)ntx, (int)nty, (int)zchunk, (int)slab);
   return launch_status();
 }
 
-template <typename T, int VEC, int LX, int RY>
+template <typename T, int VEC, int LX, int RY, bool RAG = false>
 int launch_fused_nd(const T *xbar_in, T *xbar_out, T *x, const T *bt,
                     const T *p_in, T *p_out, const Geom<T> &G,
                     const PdScalars<T> &S, hipStream_t st) {
   switch (G.ndim) {
-    case 1: return launch_fused_t<T, VEC, LX, 1, 1>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
-    case 2: return launch_fused_t<T, VEC, LX, RY, 2>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
-    default: return launch_fused_t<T, VEC, LX, RY, 3>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    case 1: return launch_fused_t<T, VEC, LX, 1, 1, RAG>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    case 2: return launch_fused_t<T, VEC, LX, RY, 2, RAG>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    default: return launch_fused_t<T, VEC, LX, RY, 3, RAG>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
   }
 }
 
-template <typename T, int VEC, int LX>
+template <typename T, int VEC, int LX, bool RAG = false>
 int launch_fused_ry(const T *xbar_in, T *xbar_out, T *x, const T *bt,
                     const T *p_in, T *p_out, const Geom<T> &G,
                     const PdScalars<T> &S, hipStream_t st) {
@@ -387,9 +402,11 @@ int launch_fused_ry(const T *xbar_in, T *xbar_out, T *x, const T *bt,
     ry = (tiles * ((G.nz + 1) / 2) < 512) ? 1 : 2;
   }
   switch (ry) {
-    case 1: return launch_fused_nd<T, VEC, LX, 1>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
-    case 4: return launch_fused_nd<T, VEC, LX, 4>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
-    default: return launch_fused_nd<T, VEC, LX, 2>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    case 1: return launch_fused_nd<T, VEC, LX, 1, RAG>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    case 4:
+      if constexpr (!RAG)
+        return launch_fused_nd<T, VEC, LX, 4>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    default: return launch_fused_nd<T, VEC, LX, 2, RAG>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
   }
 }
 
@@ -432,6 +449,13 @@ int fused_iter_impl(const T *xbar_in, T *xbar_out, T *x, const T *bt,
     if (nx / VW >= kWave)
       return launch_fused_ry<T, VW, 64>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
     return launch_fused_ry<T, VW, 16>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+  }
+  // rows that are not a multiple of 16 bytes / unaligned arrays: element-aligned
+  // 16-byte accesses (g_tune.rag = 0 restores the 4-byte form, for the tests)
+  if (g_tune.rag && nx >= 2 * VW) {
+    if ((nx + VW - 1) / VW >= kWave)
+      return launch_fused_ry<T, VW, 64, true>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
+    return launch_fused_ry<T, VW, 16, true>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
   }
   if (nx >= kWave)
     return launch_fused_ry<T, 1, 64>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
@@ -595,6 +619,7 @@ int nsol_hip_set_param(const char *name, int value) {
   else if (!strcmp(name, "pd_ry")) g_tune.ry = value;
   else if (!strcmp(name, "pd_two_pass")) g_tune.force_two_pass = value;
   else if (!strcmp(name, "pd_xcd_map")) g_tune.xcd_map = value;
+  else if (!strcmp(name, "pd_rag")) g_tune.rag = value;
   else if (!strcmp(name, "max_grid_blocks"))
     g_max_grid_blocks = value < 1 ? 1 : (value > kMaxGridBlocksLimit ? kMaxGridBlocksLimit : value);
   else return NSOL_EINVAL;

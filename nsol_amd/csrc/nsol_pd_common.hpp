@@ -36,6 +36,39 @@ __device__ __forceinline__ void stv(T *p, const T (&v)[V]) {
   }
 }
 
+// The same accesses for rows whose length is not a multiple of V elements (or
+// whose base is not 16-byte aligned): the vector starts at an element-aligned
+// address (legal for global memory, ~90 % of the aligned rate) and the row's last
+// vector holds nval < V valid elements, moved one by one; what lies behind the row
+// reads as zero and is never written.
+template <typename T, int V>
+__device__ __forceinline__ void ldv_rag(const T *p, T (&v)[V], int nval) {
+  typedef T P __attribute__((ext_vector_type(V), aligned(sizeof(T))));
+  if (nval >= V) {
+    const P t = *reinterpret_cast<const P *>(p);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = t[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = k < nval ? p[k] : T(0);
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void stv_rag(T *p, const T (&v)[V], int nval) {
+  typedef T P __attribute__((ext_vector_type(V), aligned(sizeof(T))));
+  if (nval >= V) {
+    P t;
+#pragma unroll
+    for (int k = 0; k < V; ++k) t[k] = v[k];
+    *reinterpret_cast<P *>(p) = t;
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+      if (k < nval) p[k] = v[k];
+  }
+}
+
 template <typename T, int V>
 __device__ __forceinline__ void zero(T (&v)[V]) {
 #pragma unroll

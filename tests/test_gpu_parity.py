@@ -268,10 +268,14 @@ def test_pd_cli_L2_and_spacing(nsol, golden):
 @pytest.mark.parametrize("ry", [1, 2, 4])
 @pytest.mark.parametrize("shape", [(7, 10, 13), (5, 9, 64), (3, 21, 260),
                                    (20, 6, 516), (33, 17, 8), (1, 1, 5),
-                                   (40, 37), (9, 300), (77,), (1024,)])
+                                   (40, 37), (9, 300), (77,), (1024,),
+                                   (6, 11, 259), (4, 5, 70), (30, 255),
+                                   (13, 1027), (1031,), (9,)])
 def test_pd_fused_ragged_shapes_vs_oracle(nsol, shape, ry):
-    """Tile edges, scalar (nx % 4 != 0) and vector paths, every rows-per-lane
-    variant, z-chunk seams (zchunk forced to 4)."""
+    """Tile edges, ragged (nx % 4 != 0: element-aligned 16-byte accesses with
+    the row's last vector moved element by element) and aligned vector paths,
+    every rows-per-lane variant, z-chunk seams (zchunk forced to 4); the ragged
+    form bit-identical to the 4-byte one it replaced."""
     from oracle import nsol_oracle as orc
     from nsol_amd import _lib
     rng = np.random.default_rng(sum(shape))
@@ -289,9 +293,19 @@ def test_pd_fused_ragged_shapes_vs_oracle(nsol, shape, ry):
                        np.float32)
         s.run()
         out32 = s.get_x()
+        _lib.set_param("pd_rag", 0)
+        s = _pd_solver(obs, "Huber", "L1", 0.5, 7, 4.0 * len(shape), "ALG2",
+                       np.float64)
+        s.run()
+        assert np.array_equal(s.get_x(), out64)
+        s = _pd_solver(obs, "Huber", "L1", 0.5, 7, 4.0 * len(shape), "ALG2",
+                       np.float32)
+        s.run()
+        assert np.array_equal(s.get_x(), out32)
     finally:
         _lib.set_param("pd_ry", 0)
         _lib.set_param("pd_zchunk", 0)
+        _lib.set_param("pd_rag", 1)
     assert rel_l2(out64, ref) < F64_TOL
     assert rel_l2(out32, ref) < F32_TOL
 

@@ -33,3 +33,35 @@ for shape in shapes:
                       "depth3_launches": ops.pd_fusedk_launches(3)}), flush=True)
     del bt, x, xa, xb, p
     torch.cuda.empty_cache()
+# the one-iteration kernel alone on ragged rows (2-D images and trailing
+# iterations): element-aligned 16-byte accesses against the 4-byte form
+from nsol_amd import _lib
+_lib.set_param("pdk_enable", 0)
+_lib.set_param("pd2_enable", 0)
+for shape in [(511, 511, 511), (8191, 8190), (512, 512, 512)]:
+    n = int(np.prod(shape))
+    bt = torch.rand(n, device="cuda")
+    x = bt.clone()
+    xb = [bt.clone(), torch.empty_like(bt)]
+    p = [torch.zeros(len(shape) * n, device="cuda") for _ in range(2)]
+    iters = 40
+    sig, ta, th = step_schedule("ALG2", 16.0, 1 / 0.03, iters)
+    for rag in (1, 0):
+        _lib.set_param("pd_rag", rag)
+        ts = []
+        for r in range(4):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, (1.0, 1.0, 1.0), 1 / 0.03,
+                       sig, ta, th, r == 0, 0.05, ops.PD_REG_TV | ops.PD_DATA_L2)
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters)
+        ms = float(np.median(ts[1:]))
+        print(json.dumps({"kernel": "k_pd_fused", "shape": shape,
+                          "ragged_16_byte_accesses": bool(rag),
+                          "ms_per_iteration": round(ms, 4),
+                          "GBps_algorithmic": round((44 if len(shape) == 3 else 36) * n / ms / 1e6)}),
+              flush=True)
+    del bt, x, xb, p
+    torch.cuda.empty_cache()
+_lib.reset_params()
