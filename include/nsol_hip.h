@@ -23,7 +23,7 @@
  *    they return 0 on success, a positive hipError_t on a HIP failure and
  *    NSOL_EINVAL (-1) on bad arguments.  They keep no state between calls with
  *    two exceptions, neither of which changes results: (1) the experiment
- *    knobs of nsol_hip_set_param / _pd2 / _pdk / _conv (name, value) -- tile
+ *    knobs of nsol_hip_set_param / _pd2 / _pdk / _conv / _lb (name, value) -- tile
  *    shapes, z-chunk lengths; (2) nsol_pd_fusedk_iter_* / nsol_pd_run_* keep a
  *    process-wide, mutex-protected table of footprint plans keyed by (current
  *    device ordinal, element size, depth K, nz, ny, nx), each holding a few

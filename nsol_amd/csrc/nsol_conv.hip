@@ -215,7 +215,6 @@ __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
 int g_blur3_zchunk = 0; // planes per z chunk of the one-pass blur; 0 = by the round model
 int g_blur3_lxb = 16;   // lanes per row of the one-pass blur's tile (experiment knob)
 int g_blur3_nw = 16;    // waves per workgroup of the LDS-DMA staged kernel (16 or 8)
-int g_blur3_stagger = 1; // order of the x and y/z parts of a phase per wave (experiment knob)
 int g_blur3_dma = 1;    // 1: LDS-DMA staged kernel for 16-byte rows; 0: k_blur3_wrap(_pp)
 int g_corr_ra = 8;   // outputs per lane along a strided axis (experiment knob)
 int g_corr_xv = 1;   // output vectors per lane in the x pass (experiment knob)
@@ -1219,7 +1218,6 @@ int nsol_hip_set_param_conv(const char *name, int value) {
   else if (!strcmp(name, "corr_blur3_zchunk")) g_blur3_zchunk = value;
   else if (!strcmp(name, "corr_blur3_dma")) g_blur3_dma = value;
   else if (!strcmp(name, "corr_blur3_nw")) g_blur3_nw = value;
-  else if (!strcmp(name, "corr_blur3_stagger")) g_blur3_stagger = value;
   else return NSOL_EINVAL;
   return 0;
 }

@@ -9,6 +9,8 @@
 // on the host, so the result does not depend on arrival order).
 #include <math.h>
 
+#include <string.h>
+
 #include "nsol_common.hpp"
 
 using namespace nsol;
@@ -441,6 +443,242 @@ __global__ __launch_bounds__(kBlock) void k_gram_final(const double *ws, int nbl
   }
 }
 
+// ---- the same Gram matrix with the tiles staged by LDS-DMA -------------------
+// k_masked_gram above runs one 4-wave workgroup per CU at ten stored pairs (its
+// 86 KiB tile is LDS-limited) and alternates between "load a tile" and "multiply
+// it": 9.2 ms at 512^3 for 1.9 ms worth of traffic.  Here a 16-wave workgroup keeps
+// THREE tiles in LDS (TB bytes per vector and tile: 8 KiB up to 6 vectors, 4 KiB
+// up to 12, 2 KiB up to 24 -- about 144 KiB in all): the tiles of steps t + 1 and
+// t + 2 travel global -> LDS with global_load_lds_dwordx4 (no registers; a counted
+// s_waitcnt vmcnt(N) leaves the newer one in flight across the barrier) while step
+// t is multiplied; a thread owns a 4 x 4 block of pairs for a share of the tile, so
+// eight LDS reads feed sixteen double FMAs per element; the free-variable mask is
+// staged the same way and applied to one side of the products.  Same sums in a
+// different order as k_masked_gram (both fixed; double accumulation).
+constexpr int kGram2B = 4;                       // pair block edge
+constexpr int kGram2Threads = 1024;
+constexpr int kGram2Waves = kGram2Threads / kWave;
+constexpr int kGram2Bufs = 3;
+constexpr int kGram2MaxVec = 24;                 // 6 x 6 blocks -> 21 block pairs
+constexpr int kGram2Ent = 21 * kGram2B * kGram2B;
+
+template <typename T, int TB>
+__global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
+    GramPtrs<T> P, int nvec, const int8_t *iw, int64_t n, int nb, int splits, double *ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_raw[];
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int kTile = TB / (int)sizeof(T);                   // voxels per tile
+  constexpr int kQuads = kTile / VEC;                          // 16-byte groups per row
+  constexpr int kPitch = TB + 16;                              // bytes between rows
+  constexpr int kMaskBytes = kTile;                            // int8 per voxel
+  constexpr int kRowPieces = TB / 1024;                        // 1 KiB per wave-instruction
+  constexpr int kMaskPieces = (kMaskBytes + 1023) / 1024;
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  const int rows = nb * kGram2B;
+  const int buf_bytes = rows * kPitch + ((kMaskBytes + 15) & ~15);
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = nb * (nb + 1) / 2;
+  const int blk = tid / splits, q = tid - blk * splits;
+  const bool worker = blk < nblk;
+  int bi = 0, bj = 0;
+  if (worker) {                                         // blk -> (bi, bj), bi <= bj
+    int r = blk;
+    while (r >= nb - bi) { r -= nb - bi; ++bi; }
+    bj = bi + r;
+  }
+  double acc[kGram2B][kGram2B];
+#pragma unroll
+  for (int u = 0; u < kGram2B; ++u)
+#pragma unroll
+    for (int v = 0; v < kGram2B; ++v) acc[u][v] = 0.0;
+  // rows beyond nvec (padding of the last block) stay zero in every buffer
+  for (int b = 0; b < kGram2Bufs; ++b)
+    for (int v = nvec; v < rows; ++v)
+      for (int e = tid * 16; e < TB; e += kGram2Threads * 16)
+        *reinterpret_cast<uint4 *>(gram_raw + b * buf_bytes + v * kPitch + e) =
+            make_uint4(0, 0, 0, 0);
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  // pieces of one tile: vector v, part h (1 KiB each), then the mask; piece k
+  // belongs to wave k % kGram2Waves
+  const int npieces = kRowPieces * nvec + (iw ? kMaskPieces : 0);
+  const int my_pieces = (npieces - wave + kGram2Waves - 1) / kGram2Waves;   // wave-uniform
+  auto stage = [&](int64_t t, int b) {
+    const int64_t base = t * kTile;
+    unsigned char *dst = gram_raw + b * buf_bytes;
+    for (int k = wave; k < npieces; k += kGram2Waves) {
+      if (k < kRowPieces * nvec) {
+        const int v = k / kRowPieces, h = k - v * kRowPieces;
+        const int64_t e = base + (int64_t)h * (1024 / (int)sizeof(T)) + (int64_t)lane * VEC;
+        if (e < n)                                       // n % VEC == 0 (host check)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(P.p[v] + e),
+              (__attribute__((address_space(3))) void *)(dst + v * kPitch + h * 1024),
+              16, 0, 0);
+      } else {
+        const int h = k - kRowPieces * nvec;
+        const int64_t e = base + (int64_t)h * 1024 + (int64_t)lane * 16;
+        if (h * 1024 + lane * 16 < kMaskBytes && e < n)   // n % 16 == 0 with a mask
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(iw + e),
+              (__attribute__((address_space(3))) void *)(dst + rows * kPitch + h * 1024),
+              16, 0, 0);
+      }
+    }
+  };
+  // a tile whose every piece is issued by every lane-complete instruction: only
+  // then is the number of this wave's operations in flight known
+  auto full = [&](int64_t t) { return (t + 1) * kTile <= n; };
+  // (wave-uniform) barrier that leaves `newer` of this wave's loads in flight
+  auto sync_keep = [&](int newer) {
+    switch (newer) {
+      case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+  };
+  int64_t t = blockIdx.x;
+  const int64_t step = gridDim.x;
+  if (t < ntiles) stage(t, 0);
+  if (t + step < ntiles) stage(t + step, 1);
+  // tile t must have landed; tile t + step may stay in flight if it is a full one
+  // (every piece then is one issued instruction: the count is known)
+  sync_keep((t + step < ntiles && full(t + step)) ? my_pieces : 0);
+  int cur = 0;
+  for (; t < ntiles; t += step) {
+    const int64_t t2 = t + 2 * step;
+    int nxt2 = cur + 2; if (nxt2 >= kGram2Bufs) nxt2 -= kGram2Bufs;
+    if (t2 < ntiles) stage(t2, nxt2);
+    if (worker) {
+      const unsigned char *bufp = gram_raw + cur * buf_bytes;
+      const unsigned char *a = bufp + (bi * kGram2B) * kPitch;
+      const unsigned char *bb = bufp + (bj * kGram2B) * kPitch;
+      const unsigned char *mk = bufp + rows * kPitch;
+      const int64_t base = t * kTile;
+      for (int e = q; e < kQuads; e += splits) {
+        if (base + (int64_t)e * VEC >= n) break;
+        V av[kGram2B], bv[kGram2B];
+#pragma unroll
+        for (int u = 0; u < kGram2B; ++u) {
+          av[u] = *reinterpret_cast<const V *>(a + u * kPitch + e * 16);
+          bv[u] = *reinterpret_cast<const V *>(bb + u * kPitch + e * 16);
+        }
+        bool keep[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) keep[k] = !iw || (int8_t)mk[e * VEC + k] <= 0;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          double ad[kGram2B], bd[kGram2B];
+#pragma unroll
+          for (int u = 0; u < kGram2B; ++u) {
+            ad[u] = (double)(keep[k] ? av[u][k] : T(0));   // (select before widening)
+            bd[u] = (double)bv[u][k];
+          }
+          // one fused multiply-add per product (the library is built without
+          // contraction): for float data the product of two widened values is exact
+          // in double, so this is bit for bit the multiply and add of k_masked_gram
+#pragma unroll
+          for (int u = 0; u < kGram2B; ++u)
+#pragma unroll
+            for (int v = 0; v < kGram2B; ++v) acc[u][v] = __builtin_fma(ad[u], bd[v], acc[u][v]);
+        }
+      }
+    }
+    // tile t + step must have landed before the next step reads it; the pieces of
+    // tile t + 2 step (issued above, the youngest operations of this wave) may stay
+    // in flight when their number is known
+    sync_keep((t2 < ntiles && full(t2)) ? my_pieces : 0);
+    if (++cur == kGram2Bufs) cur = 0;
+  }
+  // sum the splits of every block entry inside the workgroup (fixed order)
+  double *red = reinterpret_cast<double *>(gram_raw);   // [threads][16]
+  constexpr int E = kGram2B * kGram2B;
+#pragma unroll
+  for (int u = 0; u < kGram2B; ++u)
+#pragma unroll
+    for (int v = 0; v < kGram2B; ++v)
+      red[tid * E + u * kGram2B + v] = worker ? acc[u][v] : 0.0;
+  __syncthreads();
+  const int nent = nblk * E;
+  for (int o = tid; o < nent; o += kGram2Threads) {
+    const int kb = o / E, ent = o - kb * E;
+    double sum = 0.0;
+    for (int sq = 0; sq < splits; ++sq) sum += red[(kb * splits + sq) * E + ent];
+    ws[(int64_t)blockIdx.x * kGram2Ent + o] = sum;
+  }
+}
+
+// one workgroup per pair (i <= j): sums the workgroups' partials in a fixed order
+__global__ __launch_bounds__(kBlock) void k_gram2_final(const double *ws, int nblocks,
+                                                         int nvec, int nb, double *result) {
+  __shared__ double s[kBlock / kWave];
+  int vi = 0, r = blockIdx.x;
+  while (r >= nvec - vi) { r -= nvec - vi; ++vi; }
+  const int vj = vi + r;
+  const int bi = vi / kGram2B, bj = vj / kGram2B;
+  int kb = bj - bi;                                 // block index of (bi, bj), bi <= bj
+  for (int u = 0; u < bi; ++u) kb += nb - u;
+  const int o = kb * (kGram2B * kGram2B) + (vi % kGram2B) * kGram2B + (vj % kGram2B);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) t += ws[(int64_t)b * kGram2Ent + o];
+  t = wsum(t);
+  if (lane == 0) s[wv] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double rr = s[0];
+    for (int j = 1; j < kBlock / kWave; ++j) rr += s[j];
+    result[blockIdx.x] = rr;
+  }
+}
+
+int g_gram_dma = 1;              // 1: k_masked_gram_dma where it applies; 0: k_masked_gram
+
+template <typename T, int TB>
+int masked_gram_dma_launch_tb(const GramPtrs<T> &P, int nvec, const int8_t *iwhere,
+                              int64_t n, double *result, double *ws, hipStream_t st) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int kTile = TB / (int)sizeof(T);
+  const int nb = (nvec + kGram2B - 1) / kGram2B;
+  const int nblk = nb * (nb + 1) / 2;
+  int splits = 1;
+  while (splits * 2 * nblk <= kGram2Threads && splits * 2 <= kTile / VEC) splits *= 2;
+  size_t lds = kGram2Bufs * ((size_t)nb * kGram2B * (TB + 16) + ((kTile + 15) & ~15));
+  const size_t red = (size_t)kGram2Threads * kGram2B * kGram2B * sizeof(double);
+  if (lds < red) lds = red;
+  if (lds > 160 * 1024) return -2;
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  int64_t blocks = 256;                              // one 16-wave workgroup per CU
+  if (blocks > kGramBlocks) blocks = kGramBlocks;
+  if (blocks > ntiles) blocks = ntiles;
+  auto kern = k_masked_gram_dma<T, TB>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGram2Threads), lds, st, P, nvec,
+                     iwhere, n, nb, splits, ws);
+  hipLaunchKernelGGL(k_gram2_final, dim3(nvec * (nvec + 1) / 2), dim3(kBlock), 0, st, ws,
+                     (int)blocks, nvec, nb, result);
+  return launch_status();
+}
+
+template <typename T>
+int masked_gram_dma_launch(const GramPtrs<T> &P, int nvec, const int8_t *iwhere, int64_t n,
+                           double *result, double *ws, hipStream_t st) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  if (n % VEC != 0 || (iwhere && n % 16 != 0) || nvec > kGram2MaxVec) return -2;
+  const int rows = ((nvec + kGram2B - 1) / kGram2B) * kGram2B;
+  if (rows <= 4) return masked_gram_dma_launch_tb<T, 8192>(P, nvec, iwhere, n, result, ws, st);
+  if (rows <= 12) return masked_gram_dma_launch_tb<T, 4096>(P, nvec, iwhere, n, result, ws, st);
+  return masked_gram_dma_launch_tb<T, 2048>(P, nvec, iwhere, n, result, ws, st);
+}
+
 template <typename T>
 int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
                      double *result, double *ws, void *stream) {
@@ -451,6 +689,10 @@ int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64
   for (int v = 0; v < kGramMax; ++v) {
     P.p[v] = v < nvec ? vecs[v] : nullptr;
     if (v < nvec && (!vecs[v] || ((uintptr_t)vecs[v] & 15u))) return NSOL_EINVAL;
+  }
+  if (g_gram_dma) {
+    const int rc = masked_gram_dma_launch<T>(P, nvec, iwhere, n, result, ws, as_stream(stream));
+    if (rc != -2) return rc;
   }
   const int nb = (nvec + kGramB - 1) / kGramB;
   const int nblk = nb * (nb + 1) / 2;               // <= 36 for nvec <= 24
@@ -828,7 +1070,16 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
 }
 
 extern "C" {
-int64_t nsol_lb_gram_ws_doubles(void) { return (int64_t)kGramBlocks * kGramEnt; }
+/* experiment knobs of this file: "lb_gram_dma" */
+int nsol_hip_set_param_lb(const char *name, int value) {
+  if (!name) return NSOL_EINVAL;
+  if (!strcmp(name, "lb_gram_dma")) g_gram_dma = value;
+  else return NSOL_EINVAL;
+  return 0;
+}
+int64_t nsol_lb_gram_ws_doubles(void) {
+  return (int64_t)kGramBlocks * (kGramEnt > kGram2Ent ? kGramEnt : kGram2Ent);
+}
 int nsol_lb_mdots_f32(const float *const *vecs, int nvec, const float *y,
                       const int8_t *iwhere, int64_t n, double *result, double *ws,
                       void *stream) {

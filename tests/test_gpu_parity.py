@@ -1096,10 +1096,15 @@ def test_two_iterations_per_pass_large_shapes(nsol, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("c,n", [(1, 1000), (3, 70001), (7, 262144), (10, 300007)])
+@pytest.mark.parametrize("c,n", [(1, 1000), (3, 70001), (7, 262144), (10, 300007),
+                                 (10, 300048), (12, 1 << 20), (5, 8208),
+                                 (2, 16), (9, 512 * 700 + 256)])
 def test_masked_gram_matches_masked_dots(nsol, dtype, c, n):
     """nsol_lb_masked_gram_* (all Y'ZZ'Y, S'ZZ'S, S'ZZ'Y entries from one pass)
-    against one nsol_lb_mdot_* per entry and against NumPy in float64."""
+    against one nsol_lb_mdot_* per entry and against NumPy in float64; lengths
+    that are a multiple of 16 take the LDS-DMA staged kernel (partial last
+    tiles, fewer tiles than workgroups), the others the register-staged one,
+    and the two agree where both apply."""
     import torch
     from nsol_amd.lbfgsb_device import DeviceBackend
     td = torch.float32 if dtype == np.float32 else torch.float64
@@ -1109,8 +1114,14 @@ def test_masked_gram_matches_masked_dots(nsol, dtype, c, n):
     free = (torch.rand(n, device="cuda", generator=gen) < 0.3).to(torch.int8)
     free = free * 2 - 1 * (torch.rand(n, device="cuda", generator=gen) < 0.1).to(
         torch.int8)                                   # values in {-1, 0, 1, 2}
+    from nsol_amd import _lib
     be = DeviceBackend()
     one = be.masked_grams(ws, wy, free)
+    _lib.set_param("lb_gram_dma", 0)
+    old = be.masked_grams(ws, wy, free)
+    _lib.set_param("lb_gram_dma", 1)
+    for a, b in zip(one, old):
+        assert np.abs(a - b).max() <= 1e-12 * (np.abs(b).max() + 1e-300)
     be.USE_GRAM_KERNEL = False
     many = be.masked_grams(ws, wy, free)
     m = (free.cpu().numpy() <= 0).astype(np.float64)

@@ -22,7 +22,6 @@ times = {c: [] for c in cfgs}
 res = {}
 for rnd in range(5):
     for dma, zc, nw, sg in cfgs:
-        _lib.set_param("corr_blur3_stagger", sg)
         _lib.set_param("corr_blur3_dma", dma)
         _lib.set_param("corr_blur3_zchunk", zc)
         _lib.set_param("corr_blur3_nw", nw)
