@@ -491,8 +491,9 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
         wy.append(r)
         c = cm.col
         cm.theta = rr / dr
-        sdots = be.dots(ws[:c - 1], d)            # S_old^T d
-        ydots = be.dots(wy[:c - 1], d)            # d^T Y_old
+        both = be.dots(ws[:c - 1] + wy[:c - 1], d)   # one pass, one read-back
+        sdots = both[:c - 1]                      # S_old^T d
+        ydots = both[c - 1:]                      # d^T Y_old
         for j in range(c - 1):
             cm.sy[c - 1, j] = ydots[j]
             cm.ss[j, c - 1] = sdots[j]
@@ -537,8 +538,9 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     S.f1 = st["f1"]
     S.p = np.zeros(2 * col)
     if col > 0:
-        S.p[:col] = be.dots(wy, d)
-        S.p[col:] = theta * np.asarray(be.dots(ws, d))
+        both = np.asarray(be.dots(wy + ws, d))     # one pass, one read-back
+        S.p[:col] = both[:col]
+        S.p[col:] = theta * both[col:]
     if not st["any_move"]:
         return be.copy(x), np.zeros(2 * col), iwhere
     S.c = np.zeros(2 * col)
@@ -687,8 +689,9 @@ def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free):
     the projection refinement; returns the new point."""
     col, theta = cm.col, cm.theta
     wv = np.zeros(2 * col)
-    wv[:col] = be.dots(wy, r, free)
-    wv[col:] = theta * np.asarray(be.dots(ws, r, free))
+    both = np.asarray(be.dots(wy + ws, r, free))   # one pass, one read-back
+    wv[:col] = both[:col]
+    wv[col:] = theta * both[col:]
     wv = solve_k(fac, wv, col)
     # d = (1/theta) r + (1/theta^2) Z'W wv   (wv already carries theta in S)
     d = be.subspace_direction(r, ws, wy, wv[:col] / theta, wv[col:], theta,
