@@ -1609,6 +1609,79 @@ def test_full_size_admm_path_properties(nsol):
     assert d < 2e-6
 
 
+def test_full_size_config4_admm_and_lbfgsb(nsol):
+    """BASELINE config 4 at its full size (512^3 float32, sigma = 2 blur, ADMM,
+    rho = 0.1, alpha = 0.01; the reference cannot run this size), by
+    size-independent properties: the fused outer loop + fused LSMR against the
+    generic vector kernels (same algorithm, other kernels); the Huber / L-BFGS-B
+    branch decreases its objective monotonically, respects the bound and ends
+    below the objective of the start; both reconstructions are closer to the
+    clean volume than the blurred, noisy input."""
+    import torch
+    import nsol_amd.admm_linear_solver as admm
+    import nsol_amd.tikhonov_linear_solver as tk
+    from nsol_amd import ops
+    from nsol_amd.synthetic import synth_volume
+    n = 512
+    shp = (n, n, n)
+    lo = _lo(3)
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
+    grad, grad_adj = lo.get_gradient_operators()
+    A_ = lambda v: A(v.reshape(*shp)).flatten()
+    D_ = lambda v: grad(v.reshape(*shp)).flatten()
+    Da_ = lambda v: grad_adj(v.reshape(3 * n, n, n)).flatten()
+    clean = torch.from_numpy(synth_volume(n, 0, "clean", np.float32)
+                             .reshape(-1)).cuda()
+    y = A_(clean)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    y = y + 0.02 * float(y.max()) * torch.randn(y.shape, device="cuda",
+                                                 generator=gen)
+    xs = float(y.max())
+    err0 = ops.norm2(ops.lincomb2(1.0, y, -1.0, clean))
+
+    def run(**kw):
+        s = admm.ADMMLinearSolver(A=A_, A_adj=A_, b=y, B=D_, B_adj=Da_, x0=y,
+                                  dimension=3, alpha=0.01, rho=0.1,
+                                  x_scale=xs, dtype=np.float32, **kw)
+        s.run()
+        return s
+    outs = []
+    for fused in (True, False):
+        tk.USE_FUSED_LSMR = fused
+        try:
+            s = run(iterations=2, iter_max=4)
+            assert s.get_execution() == "fused-outer"
+            outs.append(s.get_x_device())
+        finally:
+            tk.USE_FUSED_LSMR = True
+        del s
+    d = ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, outs[1])) / ops.norm2(outs[1])
+    assert d < 2e-6, d
+    assert ops.norm2(ops.lincomb2(1.0, outs[0], -1.0, clean)) < err0
+    del outs
+    torch.cuda.empty_cache()
+    # Huber loss through the GPU-resident L-BFGS-B (one ADMM iteration of 5)
+    from nsol_amd import lbfgsb
+    trace = []
+    orig = lbfgsb.LineSearch.step
+
+    def spy(self, f, g):
+        trace.append(f)
+        return orig(self, f, g)
+    lbfgsb.LineSearch.step = spy
+    try:
+        s = run(iterations=1, iter_max=5, minimizer="L-BFGS-B",
+                data_loss="huber")
+    finally:
+        lbfgsb.LineSearch.step = orig
+    x = s.get_x_device()
+    assert bool(torch.isfinite(x).all().item())
+    assert float(x.min().item()) >= 0.0                     # bounds = (0, inf)
+    assert len(trace) >= 5 and trace[-1] < trace[0]
+    assert trace[-1] <= min(trace) * (1 + 1e-6)
+    assert ops.norm2(ops.lincomb2(1.0, x, -1.0, clean)) < err0
+
+
 def test_device_lbfgsb_vs_scipy_driver_at_64_cubed(nsol):
     """A size SciPy's host driver still handles: ADMM + Huber through both
     L-BFGS-B drivers give the same reconstruction."""
