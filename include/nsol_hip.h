@@ -19,7 +19,8 @@
  *  - wx, wy, wz are the INVERSE spacings 1/h of the x, y, z axes
  *    (reference kernels.py:102-112,160-190,240-286 scale taps by 1/spacing);
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
- *  - functions never allocate device memory, never synchronise, never throw;
+ *  - functions never allocate device memory, never synchronise, never throw
+ *    (nsol_pd_persist_run_* works in a caller-owned scratch buffer);
  *    they return 0 on success, a positive hipError_t on a HIP failure and
  *    NSOL_EINVAL (-1) on bad arguments.  They keep no state between calls with
  *    two exceptions, neither of which changes results: (1) the experiment
@@ -296,6 +297,36 @@ int nsol_pd_fusedk_launches(int k);
  * NSOL_EINVAL while the shape is unknown or still exploring. */
 int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,
                         int *waves, int *ntx, int64_t *zchunk);
+/* The whole loop of primal_dual_solver.py:232-261 in ONE launch for cache-
+ * resident volumes (BASELINE configs 1-2; at most one tile of <= 1024 lanes x one
+ * 16-byte vector per CU, i.e. up to ~1 Mi float voxels): every workgroup keeps its
+ * tile's x, xbar, b~, p in registers for all iterations and hands the one-voxel
+ * faces to its face neighbours through tagged 8-byte granules in `ws`
+ * (nsol_pdp.hip).  Bit-identical to `iterations` calls of nsol_pd_fused_iter_*.
+ * xbar, x, p are updated in place (p is read only when p_is_zero == 0); the step
+ * sizes are host arrays as for nsol_pd_run_*.  ws: caller-owned DEVICE scratch
+ * of nsol_pd_persist_ws_bytes() bytes, 16-byte aligned; the function clears it
+ * (hipMemsetAsync) and copies the step sizes into it (hipMemcpyAsync) on
+ * `stream`.  After the run the first 32-bit word of ws is non-zero if a
+ * workgroup gave up waiting for a neighbour (every wait is bounded; the
+ * results are then invalid and the caller falls back to nsol_pd_run_*).
+ * Returns -2 (nothing launched) when the kernel does not apply: rows not a
+ * multiple of 16 bytes, unaligned arrays, more tiles than CUs.
+ * nsol_pd_persist_ws_bytes returns -1 in that case. */
+int64_t nsol_pd_persist_ws_bytes(int elem_size, int ndim, int64_t nz, int64_t ny,
+                                 int64_t nx, int iterations);
+int nsol_pd_persist_run_f32(float *xbar, float *x, const float *bt, float *p, int ndim,
+                            int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                            double wz, double lambda, const double *sigma_host,
+                            const double *tau_host, const double *theta_host,
+                            int iterations, int p_is_zero, double gamma_huber, int flags,
+                            void *ws, int64_t ws_bytes, void *stream);
+int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p, int ndim,
+                            int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                            double wz, double lambda, const double *sigma_host,
+                            const double *tau_host, const double *theta_host,
+                            int iterations, int p_is_zero, double gamma_huber, int flags,
+                            void *ws, int64_t ws_bytes, void *stream);
 /* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;

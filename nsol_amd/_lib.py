@@ -73,6 +73,9 @@ def load():
     lib.nsol_lb_walk_tmp_bytes.argtypes = [c_int]
     lib.nsol_lb_gram_ws_doubles.restype = c_i64
     lib.nsol_lb_gram_ws_doubles.argtypes = []
+    lib.nsol_pd_persist_ws_bytes.restype = c_i64
+    lib.nsol_pd_persist_ws_bytes.argtypes = [c_int, c_int, c_i64, c_i64, c_i64,
+                                             c_int]
     lib.nsol_hip_set_param_conv.restype = c_int
     lib.nsol_hip_set_param_conv.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_hip_set_param_pd2.restype = c_int

@@ -1,0 +1,489 @@
+// Persistent primal-dual kernel for cache-resident volumes (BASELINE configs 1-2:
+// 256^2 x 50 iterations, 64^3 x 200 iterations): ONE launch runs the whole
+// Chambolle-Pock loop of primal_dual_solver.py:232-261.
+//
+// With one launch per iteration such a volume costs 7-8 us per iteration -- the
+// latency of a short kernel plus a launch boundary -- for about a microsecond of
+// arithmetic and traffic.  A grid barrier per iteration would cost the same again
+// (MI355X_MICROARCH.md prices the XCD-hierarchical barrier at 4.1 us for 256
+// workgroups).  Here every workgroup owns a tile of the volume for the whole run
+// and keeps its x, xbar, b~ and p in REGISTERS (one 16-byte vector per lane and
+// array); per iteration it only
+//   * exchanges its own values between lanes through LDS (two barriers), and
+//   * hands the one-voxel faces of xbar (first and last layer per axis) and of p
+//     (last layer, the component of that axis) to its <= 6 face neighbours through
+//     global memory as 8-byte {value, tag} granules written and polled with
+//     agent-scope relaxed atomics (sc1 stores / loads: a granule is complete when
+//     its tag says so, no fence, no flag); tag = iteration + 1, two slots per
+//     granule by iteration parity -- a workgroup can only run one iteration ahead
+//     of a neighbour, because it needs that neighbour's faces of every iteration.
+// The arithmetic per voxel is that of k_pd_fused in the same order (the new dual of
+// the lower neighbour voxel across a tile face is recomputed from the neighbour's
+// old p and xbar, exactly as k_pd_fused recomputes it across its patches), so the
+// result is bit-identical to one launch of k_pd_fused per iteration.
+//
+// Co-residency: the grid is at most one workgroup per CU (checked on the host), so
+// every workgroup is running when its neighbours wait for it.  Every wait is still
+// bounded: a workgroup that does not see a granule within ~2^22 polls gives up
+// polling for the rest of the run and raises the error word of the workspace,
+// which the host reads after the run -- no wave can spin forever.
+#include <string.h>
+
+#include <vector>
+
+#include "nsol_common.hpp"
+#include "nsol_pd_common.hpp"
+
+using namespace nsol;
+
+namespace {
+
+constexpr int kMaxTiles = 256;
+constexpr int kMaxSpin = 1 << 22;
+constexpr int kKinds = 3;          // XF: xbar first layer, XL: xbar last, PL: p last
+
+template <typename T>
+struct IterScalars {               // one Chambolle-Pock iteration's step sizes
+  T sigma, hden, tau, tl, one_plus_tl, theta;
+};
+
+struct Tiling {
+  int lx, ly, lz;                  // lanes per tile along x (vectors), y, z
+  int ntx, nty, ntz;
+  int face;                        // elements of the largest tile face
+};
+
+// granules: 8 bytes {32 payload bits, 32-bit tag}; a double travels as two
+template <typename T> struct GranOf;
+template <> struct GranOf<float> { static constexpr int N = 1; };
+template <> struct GranOf<double> { static constexpr int N = 2; };
+
+__device__ __forceinline__ void gran_put(uint64_t *g, uint32_t bits, uint32_t tag) {
+  __hip_atomic_store(g, ((uint64_t)tag << 32) | (uint64_t)bits, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// polls until the tag arrives; false (and *failed set) when it does not
+__device__ __forceinline__ uint32_t gran_get(const uint64_t *g, uint32_t tag, bool *failed) {
+  uint64_t v = 0;
+  if (*failed) return 0;
+  for (int spin = 0; spin < kMaxSpin; ++spin) {
+    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(v >> 32) == tag) return (uint32_t)v;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  *failed = true;
+  return 0;
+}
+__device__ __forceinline__ void val_put(uint64_t *g, float v, uint32_t tag) {
+  gran_put(g, __float_as_uint(v), tag);
+}
+__device__ __forceinline__ void val_put(uint64_t *g, double v, uint32_t tag) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  gran_put(g, (uint32_t)b, tag);
+  gran_put(g + 1, (uint32_t)(b >> 32), tag);
+}
+__device__ __forceinline__ float val_get(const uint64_t *g, uint32_t tag, bool *failed, float) {
+  return __uint_as_float(gran_get(g, tag, failed));
+}
+__device__ __forceinline__ double val_get(const uint64_t *g, uint32_t tag, bool *failed, double) {
+  const uint64_t lo = gran_get(g, tag, failed), hi = gran_get(g + 1, tag, failed);
+  return __longlong_as_double((long long)((hi << 32) | lo));
+}
+
+template <typename T, int VEC, int NDIM>
+__global__ __launch_bounds__(1024) void k_pd_persist(
+    T *__restrict__ xbar, T *__restrict__ x, const T *__restrict__ bt, T *__restrict__ p,
+    Geom<T> G, const IterScalars<T> *__restrict__ sc, int iterations, int huber, int l1,
+    int has_p, Tiling Q, uint64_t *__restrict__ halo, unsigned int *__restrict__ err) {
+  constexpr int GN = GranOf<T>::N;
+  typedef typename Pack<T, VEC>::type V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pdp_smem[];
+  const int nthr = Q.lx * Q.ly * Q.lz;
+  V *sx = reinterpret_cast<V *>(pdp_smem);          // xbar of the tile
+  V *spy = sx + nthr;                               // new p_y
+  V *spz = spy + nthr;                              // new p_z
+  T *spx = reinterpret_cast<T *>(spz + nthr);       // last element of new p_x
+  const int tid = threadIdx.x;
+  const int lx = tid % Q.lx, ly = (tid / Q.lx) % Q.ly, lz = tid / (Q.lx * Q.ly);
+  int bid = blockIdx.x;
+  const int tx = bid % Q.ntx; bid /= Q.ntx;
+  const int ty = bid % Q.nty;
+  const int tz = bid / Q.nty;
+  const int64_t x0 = ((int64_t)tx * Q.lx + lx) * VEC;
+  const int64_t y = (int64_t)ty * Q.ly + ly, z = (int64_t)tz * Q.lz + lz;
+  const bool in = x0 < G.nx && y < G.ny && z < G.nz;
+  const int64_t off = z * G.sz + y * G.sy + x0;
+  // neighbour voxels inside the volume / across a tile face
+  const bool has_r = in && x0 + VEC < G.nx, has_l = in && x0 > 0;
+  const bool has_u = in && NDIM >= 2 && y + 1 < G.ny, has_d = in && NDIM >= 2 && y > 0;
+  const bool has_b = in && NDIM >= 3 && z + 1 < G.nz, has_f = in && NDIM >= 3 && z > 0;
+  const bool edge_r = lx == Q.lx - 1, edge_l = lx == 0;
+  const bool edge_u = ly == Q.ly - 1, edge_d = ly == 0;
+  const bool edge_b = lz == Q.lz - 1, edge_f = lz == 0;
+  // halo addressing: [tile][axis][kind][slot][face element][GN]
+  const int64_t face = Q.face;
+  auto hp = [&](int ttx, int tty, int ttz, int axis, int kind, int slot, int64_t idx) {
+    const int64_t t = ((int64_t)ttz * Q.nty + tty) * Q.ntx + ttx;
+    return halo + ((((t * 3 + axis) * kKinds + kind) * 2 + slot) * face + idx) * GN;
+  };
+  // face element index of this lane's voxels on the faces normal to each axis
+  const int64_t fx = (int64_t)lz * Q.ly + ly;                        // one value
+  const int64_t fy = ((int64_t)lz * Q.lx + lx) * VEC;                // VEC values
+  const int64_t fz = ((int64_t)ly * Q.lx + lx) * VEC;                // VEC values
+
+  T xb[VEC], xv[VEC], bv[VEC], px[VEC], py[VEC], pz[VEC];
+  zero(xb); zero(xv); zero(bv); zero(px); zero(py); zero(pz);
+  if (in) {
+    ldv<T, VEC>(xbar + off, xb);
+    ldv<T, VEC>(x + off, xv);
+    ldv<T, VEC>(bt + off, bv);
+    if (has_p) {
+      ldv<T, VEC>(p + off, px);
+      if constexpr (NDIM >= 2) ldv<T, VEC>(p + G.n + off, py);
+      if constexpr (NDIM >= 3) ldv<T, VEC>(p + 2 * G.n + off, pz);
+    }
+  }
+  bool failed = false;
+  // faces of the state after `k` iterations go out with tag k + 1 into slot k & 1
+  auto publish = [&](int k) {
+    if (!in) return;
+    const uint32_t tag = (uint32_t)k + 1u;
+    const int s = k & 1;
+    if (edge_l && has_l) val_put(hp(tx, ty, tz, 0, 0, s, fx), xb[0], tag);
+    if (edge_r && has_r) {
+      val_put(hp(tx, ty, tz, 0, 1, s, fx), xb[VEC - 1], tag);
+      val_put(hp(tx, ty, tz, 0, 2, s, fx), px[VEC - 1], tag);
+    }
+    if constexpr (NDIM >= 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (edge_d && has_d) val_put(hp(tx, ty, tz, 1, 0, s, fy + e), xb[e], tag);
+        if (edge_u && has_u) {
+          val_put(hp(tx, ty, tz, 1, 1, s, fy + e), xb[e], tag);
+          val_put(hp(tx, ty, tz, 1, 2, s, fy + e), py[e], tag);
+        }
+      }
+    }
+    if constexpr (NDIM >= 3) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (edge_f && has_f) val_put(hp(tx, ty, tz, 2, 0, s, fz + e), xb[e], tag);
+        if (edge_b && has_b) {
+          val_put(hp(tx, ty, tz, 2, 1, s, fz + e), xb[e], tag);
+          val_put(hp(tx, ty, tz, 2, 2, s, fz + e), pz[e], tag);
+        }
+      }
+    }
+  };
+  publish(0);
+
+  for (int k = 0; k < iterations; ++k) {
+    PdScalars<T> S;
+    {
+      const IterScalars<T> c = sc[k];
+      S.sigma = c.sigma; S.hden = c.hden; S.tau = c.tau; S.tl = c.tl;
+      S.one_plus_tl = c.one_plus_tl; S.theta = c.theta;
+      S.huber = huber; S.l1 = l1; S.has_p = 1;
+    }
+    const uint32_t tag = (uint32_t)k + 1u;
+    const int s = k & 1;
+    // ---- faces of the neighbouring tiles (state after k iterations)
+    T xr = T(0), xl = T(0), pl_old = T(0);
+    T xu[VEC], xd[VEC], pd_old[VEC], xbk[VEC], xf[VEC], pf_old[VEC];
+    zero(xu); zero(xd); zero(pd_old); zero(xbk); zero(xf); zero(pf_old);
+    if (edge_r && has_r) xr = val_get(hp(tx + 1, ty, tz, 0, 0, s, fx), tag, &failed, T(0));
+    if (edge_l && has_l) {
+      xl = val_get(hp(tx - 1, ty, tz, 0, 1, s, fx), tag, &failed, T(0));
+      pl_old = val_get(hp(tx - 1, ty, tz, 0, 2, s, fx), tag, &failed, T(0));
+    }
+    if constexpr (NDIM >= 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (edge_u && has_u)
+          xu[e] = val_get(hp(tx, ty + 1, tz, 1, 0, s, fy + e), tag, &failed, T(0));
+        if (edge_d && has_d) {
+          xd[e] = val_get(hp(tx, ty - 1, tz, 1, 1, s, fy + e), tag, &failed, T(0));
+          pd_old[e] = val_get(hp(tx, ty - 1, tz, 1, 2, s, fy + e), tag, &failed, T(0));
+        }
+      }
+    }
+    if constexpr (NDIM >= 3) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (edge_b && has_b)
+          xbk[e] = val_get(hp(tx, ty, tz + 1, 2, 0, s, fz + e), tag, &failed, T(0));
+        if (edge_f && has_f) {
+          xf[e] = val_get(hp(tx, ty, tz - 1, 2, 1, s, fz + e), tag, &failed, T(0));
+          pf_old[e] = val_get(hp(tx, ty, tz - 1, 2, 2, s, fz + e), tag, &failed, T(0));
+        }
+      }
+    }
+    // ---- xbar of the tile to LDS; upper neighbours of every voxel
+    {
+      V t;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) t[e] = xb[e];
+      sx[tid] = t;
+    }
+    __syncthreads();
+    T nbx = T(0);                                   // xbar right of the vector
+    if (has_r) nbx = edge_r ? xr : sx[tid + 1][0];
+    T hy[VEC], hz[VEC];
+    zero(hy); zero(hz);
+    if constexpr (NDIM >= 2) {
+      if (has_u) {
+        if (edge_u) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) hy[e] = xu[e];
+        } else {
+          const V t = sx[tid + Q.lx];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) hy[e] = t[e];
+        }
+      }
+    }
+    if constexpr (NDIM >= 3) {
+      if (has_b) {
+        if (edge_b) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) hz[e] = xbk[e];
+        } else {
+          const V t = sx[tid + Q.lx * Q.ly];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) hz[e] = t[e];
+        }
+      }
+    }
+    // ---- dual update at the lane's own voxels (k_pd_fused's order)
+    T pxn[VEC], pyn[VEC], pzn[VEC];
+    zero(pyn); zero(pzn);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const T hi = (e + 1 < VEC) ? xb[(e + 1) % VEC] : nbx;
+      pxn[e] = dual_update(px[e], hi, xb[e], G.wx, S);
+    }
+    if constexpr (NDIM >= 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pyn[e] = dual_update(py[e], hy[e], xb[e], G.wy, S);
+    }
+    if constexpr (NDIM >= 3) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pzn[e] = dual_update(pz[e], hz[e], xb[e], G.wz, S);
+    }
+    // ---- new dual values of the lower neighbours: inside the tile through LDS,
+    //      across a face recomputed from the neighbour's old p and xbar
+    spx[tid] = pxn[VEC - 1];
+    if constexpr (NDIM >= 2) {
+      V t;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) t[e] = pyn[e];
+      spy[tid] = t;
+    }
+    if constexpr (NDIM >= 3) {
+      V t;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) t[e] = pzn[e];
+      spz[tid] = t;
+    }
+    __syncthreads();
+    T pxl = T(0);
+    if (has_l) pxl = edge_l ? dual_update(pl_old, xb[0], xl, G.wx, S) : spx[tid - 1];
+    T pyu[VEC], pzp[VEC];
+    zero(pyu); zero(pzp);
+    if constexpr (NDIM >= 2) {
+      if (has_d) {
+        if (edge_d) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) pyu[e] = dual_update(pd_old[e], xb[e], xd[e], G.wy, S);
+        } else {
+          const V t = spy[tid - Q.lx];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) pyu[e] = t[e];
+        }
+      }
+    }
+    if constexpr (NDIM >= 3) {
+      if (has_f) {
+        if (edge_f) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) pzp[e] = dual_update(pf_old[e], xb[e], xf[e], G.wz, S);
+        } else {
+          const V t = spz[tid - Q.lx * Q.ly];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) pzp[e] = t[e];
+        }
+      }
+    }
+    // ---- primal update
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const T pl = (e > 0) ? pxn[(e + VEC - 1) % VEC] : pxl;
+      T kt = pxn[e] * (-G.wx) + pl * G.wx;
+      if constexpr (NDIM >= 2) kt += pyn[e] * (-G.wy) + pyu[e] * G.wy;
+      if constexpr (NDIM >= 3) kt += pzn[e] * (-G.wz) + pzp[e] * G.wz;
+      const T u = xv[e] - S.tau * kt;
+      const T xnew = prox_data(u, bv[e], S.tl, S.one_plus_tl, S.l1 != 0);
+      xb[e] = xnew + S.theta * (xnew - xv[e]);
+      xv[e] = xnew;
+      px[e] = pxn[e];
+      py[e] = pyn[e];
+      pz[e] = pzn[e];
+    }
+    if (k + 1 < iterations) publish(k + 1);
+    // (the LDS tiles are rewritten after the next iteration's first barrier only
+    // by lanes that have passed this iteration's second one: no third barrier)
+  }
+  if (in) {
+    stv<T, VEC>(xbar + off, xb);
+    stv<T, VEC>(x + off, xv);
+    stv<T, VEC>(p + off, px);
+    if constexpr (NDIM >= 2) stv<T, VEC>(p + G.n + off, py);
+    if constexpr (NDIM >= 3) stv<T, VEC>(p + 2 * G.n + off, pz);
+  }
+  if (failed) atomicOr(err, 1u);
+}
+
+inline int cu_count_pdp() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// lanes per tile: powers of two with 64..1024 lanes that cover the volume in at
+// most one tile per CU; among those the most tiles (the shortest latency chain per
+// iteration), then the fewest lanes
+template <int VEC>
+bool pick_tiling(int ndim, int64_t nz, int64_t ny, int64_t nx, Tiling *out) {
+  const int64_t nxv = nx / VEC;
+  const int max_tiles = cu_count_pdp() < kMaxTiles ? cu_count_pdp() : kMaxTiles;
+  int64_t best_tiles = -1, best_lanes = 0;
+  for (int lx = 1; lx <= 256; lx *= 2)
+    for (int ly = 1; ly <= (ndim >= 2 ? 256 : 1); ly *= 2)
+      for (int lz = 1; lz <= (ndim >= 3 ? 256 : 1); lz *= 2) {
+        const int64_t lanes = (int64_t)lx * ly * lz;
+        if (lanes < 64 || lanes > 1024) continue;
+        if ((lx > 1 && lx / 2 >= nxv) || (ly > 1 && ly / 2 >= ny) || (lz > 1 && lz / 2 >= nz))
+          continue;                                   // (a smaller box covers the axis)
+        const int64_t ntx = (nxv + lx - 1) / lx, nty = (ny + ly - 1) / ly,
+                      ntz = (nz + lz - 1) / lz;
+        const int64_t tiles = ntx * nty * ntz;
+        if (tiles > max_tiles) continue;
+        if (tiles > best_tiles || (tiles == best_tiles && lanes < best_lanes)) {
+          best_tiles = tiles; best_lanes = lanes;
+          out->lx = lx; out->ly = ly; out->lz = lz;
+          out->ntx = (int)ntx; out->nty = (int)nty; out->ntz = (int)ntz;
+        }
+      }
+  if (best_tiles < 0) return false;
+  const int fx = out->ly * out->lz, fy = out->lx * VEC * out->lz, fz = out->lx * VEC * out->ly;
+  out->face = fx > fy ? (fx > fz ? fx : fz) : (fy > fz ? fy : fz);
+  return true;
+}
+
+template <typename T>
+int64_t persist_ws_bytes(int ndim, int64_t nz, int64_t ny, int64_t nx, int iterations) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  Tiling Q;
+  if (!geom_ok(ndim, nz, ny, nx) || nx % VEC != 0 || iterations < 1 ||
+      !pick_tiling<VEC>(ndim, nz, ny, nx, &Q))
+    return -1;
+  const int64_t tiles = (int64_t)Q.ntx * Q.nty * Q.ntz;
+  const int64_t halo = tiles * 3 * kKinds * 2 * Q.face * GranOf<T>::N * 8;
+  const int64_t scal = (((int64_t)iterations * sizeof(IterScalars<T>)) + 255) / 256 * 256;
+  return 256 + scal + halo;                        // [error word | scalars | halo]
+}
+
+template <typename T>
+int persist_run(T *xbar, T *x, const T *bt, T *p, int ndim, int64_t nz, int64_t ny,
+                int64_t nx, double wx, double wy, double wz, double lambda,
+                const double *sig, const double *tau, const double *theta, int iterations,
+                int p_is_zero, double gamma_huber, int flags, void *ws, int64_t ws_bytes,
+                void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  constexpr int VEC = 16 / (int)sizeof(T);
+  if (!xbar || !x || !bt || !p || !sig || !tau || !theta || iterations < 1 || !ws)
+    return NSOL_EINVAL;
+  const int64_t need = persist_ws_bytes<T>(ndim, nz, ny, nx, iterations);
+  if (need < 0) return -2;                          // the kernel does not apply
+  if (ws_bytes < need || ((uintptr_t)ws & 15u)) return NSOL_EINVAL;
+  if (((uintptr_t)xbar | (uintptr_t)x | (uintptr_t)bt | (uintptr_t)p) & 15u) return -2;
+  if ((nz * ny * nx) % VEC != 0) return -2;
+  Tiling Q;
+  pick_tiling<VEC>(ndim, nz, ny, nx, &Q);
+  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  const bool huber = (flags & NSOL_PD_REG_HUBER) != 0;
+  std::vector<IterScalars<T>> sc((size_t)iterations);
+  for (int k = 0; k < iterations; ++k) {
+    const double hden = huber ? 1.0 + sig[k] * gamma_huber : 1.0;
+    const double tl = tau[k] * lambda;
+    sc[k].sigma = (T)sig[k]; sc[k].hden = huber_den<T>(hden); sc[k].tau = (T)tau[k];
+    sc[k].tl = (T)tl; sc[k].one_plus_tl = prox_den<T>(tl); sc[k].theta = (T)theta[k];
+  }
+  hipStream_t st = as_stream(stream);
+  unsigned char *base = static_cast<unsigned char *>(ws);
+  const int64_t scal = (((int64_t)iterations * sizeof(IterScalars<T>)) + 255) / 256 * 256;
+  hipError_t e = hipMemsetAsync(base, 0, (size_t)need, st);      // error word, tags
+  if (e != hipSuccess) return (int)e;
+  // (pageable source: the runtime stages it before the call returns)
+  e = hipMemcpyAsync(base + 256, sc.data(), (size_t)iterations * sizeof(IterScalars<T>),
+                     hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  const int nthr = Q.lx * Q.ly * Q.lz;
+  const size_t lds = (size_t)nthr * (3 * 16 + sizeof(T));
+  const dim3 grid((unsigned)(Q.ntx * Q.nty * Q.ntz));
+  auto *scd = reinterpret_cast<const IterScalars<T> *>(base + 256);
+  auto *halo = reinterpret_cast<uint64_t *>(base + 256 + scal);
+  auto *err = reinterpret_cast<unsigned int *>(base);
+#define NSOL_PDP_GO(ND)                                                              \
+  hipLaunchKernelGGL((k_pd_persist<T, VEC, ND>), grid, dim3(nthr), lds, st, xbar, x, bt, \
+                     p, G, scd, iterations, huber ? 1 : 0,                            \
+                     (flags & NSOL_PD_DATA_L1) ? 1 : 0, p_is_zero ? 0 : 1, Q, halo, err)
+  switch (ndim) {
+    case 1: NSOL_PDP_GO(1); break;
+    case 2: NSOL_PDP_GO(2); break;
+    default: NSOL_PDP_GO(3); break;
+  }
+#undef NSOL_PDP_GO
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t nsol_pd_persist_ws_bytes(int elem_size, int ndim, int64_t nz, int64_t ny,
+                                 int64_t nx, int iterations) {
+  if (elem_size == 4) return persist_ws_bytes<float>(ndim, nz, ny, nx, iterations);
+  if (elem_size == 8) return persist_ws_bytes<double>(ndim, nz, ny, nx, iterations);
+  return -1;
+}
+
+int nsol_pd_persist_run_f32(float *xbar, float *x, const float *bt, float *p, int ndim,
+                            int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                            double wz, double lambda, const double *sigma_host,
+                            const double *tau_host, const double *theta_host,
+                            int iterations, int p_is_zero, double gamma_huber, int flags,
+                            void *ws, int64_t ws_bytes, void *stream) {
+  return persist_run<float>(xbar, x, bt, p, ndim, nz, ny, nx, wx, wy, wz, lambda,
+                            sigma_host, tau_host, theta_host, iterations, p_is_zero,
+                            gamma_huber, flags, ws, ws_bytes, stream);
+}
+int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p, int ndim,
+                            int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                            double wz, double lambda, const double *sigma_host,
+                            const double *tau_host, const double *theta_host,
+                            int iterations, int p_is_zero, double gamma_huber, int flags,
+                            void *ws, int64_t ws_bytes, void *stream) {
+  return persist_run<double>(xbar, x, bt, p, ndim, nz, ny, nx, wx, wy, wz, lambda,
+                             sigma_host, tau_host, theta_host, iterations, p_is_zero,
+                             gamma_huber, flags, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

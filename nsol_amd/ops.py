@@ -406,12 +406,67 @@ def pd_fusedk_plan(x, shape, k=3):
     return None if rc else (int(wv.value), int(nt.value), int(zc.value))
 
 
+# Cache-resident volumes (BASELINE configs 1-2): the whole run in ONE launch of the
+# persistent kernel (nsol_pd_persist_run_*), from this many iterations on and up to
+# this many voxels (above, three iterations per pass take over).
+PD_PERSIST = True
+PD_PERSIST_MIN_ITERS = 6
+PD_PERSIST_MAX_VOXELS = 1 << 20
+_persist_launches = 0
+
+
+def pd_persist_launches():
+    """Runs that went through the persistent kernel (for tests and tools)."""
+    return _persist_launches
+
+
+def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero,
+                   gamma_huber, flags):
+    """All len(sigma) iterations in one launch, state updated in place (xbar, x,
+    p).  Returns False when the kernel does not apply (nothing launched) or when
+    a workgroup gave up waiting for a neighbour (state restored: the caller runs
+    the ordinary path).  Syncs once to read the error word."""
+    global _persist_launches
+    ndim, nz, ny, nx = dims3(shape)
+    iters = int(np.size(sigma))
+    need = int(_lib.load().nsol_pd_persist_ws_bytes(int(x.element_size()), ndim,
+                                                    nz, ny, nx, iters))
+    if need < 0:
+        return False
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    keep = (xbar.clone(), x.clone(), None if p_is_zero else p.clone())
+    rc = _fn("pd_persist_run", x)(
+        _p(xbar), _p(x), _p(bt), _p(p), ndim, nz, ny, nx, w[0], w[1], w[2],
+        float(lmbda), sigma.ctypes.data, tau.ctypes.data, theta.ctypes.data, iters,
+        int(bool(p_is_zero)), float(gamma_huber), int(flags), _p(ws), need,
+        stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_pd_persist_run")
+    if int(ws[:4].view(torch.int32).item()) != 0:       # a bounded wait ran out
+        xbar.copy_(keep[0])
+        x.copy_(keep[1])
+        if keep[2] is not None:
+            p.copy_(keep[2])
+        return False
+    _persist_launches += 1
+    return True
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
            p_is_zero, gamma_huber, flags, x_alt=None):
     """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that
     holds the final state.  x holds the final primal iterate."""
     import ctypes
     ndim, nz, ny, nx = dims3(shape)
+    if PD_PERSIST and PD_PERSIST_MIN_ITERS <= np.size(sigma) and \
+            nz * ny * nx <= PD_PERSIST_MAX_VOXELS and \
+            pd_persist_run(xbar0, x, bt, p0, shape, w, lmbda, sigma, tau, theta,
+                           p_is_zero, gamma_huber, flags):
+        return 0
     sigma = np.ascontiguousarray(sigma, dtype=np.float64)
     tau = np.ascontiguousarray(tau, dtype=np.float64)
     theta = np.ascontiguousarray(theta, dtype=np.float64)

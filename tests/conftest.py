@@ -61,6 +61,27 @@ def _restore_library_knobs():
         lib.reset_params()
 
 
+@pytest.fixture(autouse=True)
+def _one_launch_per_iteration_unless_asked(request):
+    """Small volumes run through the persistent kernel by default
+    (ops.PD_PERSIST).  Most GPU tests are about the other kernels -- the
+    one-iteration kernel, the two- and three-iterations-per-pass kernels on
+    small shapes -- so the persistent path is switched off unless the test asks
+    for it by name ("persist" / "configs" / "cli")."""
+    ops = sys.modules.get("nsol_amd.ops")
+    name = request.node.name.lower()
+    want = any(t in name for t in ("persist", "configs", "cli"))
+    if ops is None:
+        if request.node.get_closest_marker("gpu") is None:
+            yield
+            return
+        import nsol_amd.ops as ops
+    old = ops.PD_PERSIST
+    ops.PD_PERSIST = want
+    yield
+    ops.PD_PERSIST = old
+
+
 def rel_l2(a, b, label=None):
     a = np.asarray(a, np.float64).reshape(-1)
     b = np.asarray(b, np.float64).reshape(-1)

@@ -945,6 +945,81 @@ def test_500_iteration_fp32_drift_at_128_cubed(nsol, kind, data, alpha):
     assert rel_l2(s.get_x(), ref, "f64 500 it") < 1e-11
 
 
+# ------------------------- the persistent kernel (cache-resident volumes)
+PERSIST_SHAPES = [(64, 64, 64), (16, 20, 24), (7, 10, 12), (33, 17, 8), (1, 1, 8),
+                  (5, 9, 64), (40, 36), (256, 256), (9, 300), (1024,), (76,),
+                  (96, 96, 96), (3, 5, 260), (2, 2, 4), (1, 4), (100, 100, 100)]
+
+
+@pytest.mark.parametrize("shape", PERSIST_SHAPES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_persistent_kernel_is_bit_identical(nsol, shape, dtype):
+    """nsol_pd_persist_run_* (the whole run in one launch, faces handed between
+    workgroups through tagged granules) against one launch of k_pd_fused per
+    iteration: every bit of x, xbar and p, all four flag combinations, unit and
+    non-unit spacing, tiles that stick out of the volume, one tile only, 1-D /
+    2-D / 3-D, odd iteration counts, a warm start (p given)."""
+    import torch
+    from nsol_amd import ops
+    from nsol_amd.primal_dual_solver import step_schedule
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    d = len(shape)
+    vec = 16 // np.dtype(dtype).itemsize
+    if shape[-1] % vec:
+        pytest.skip("rows must be whole 16-byte vectors")
+    from nsol_amd import _lib
+    if _lib.load().nsol_pd_persist_ws_bytes(
+            np.dtype(dtype).itemsize, *ops.dims3(shape), 8) < 0:
+        pytest.skip("no tiling with at most one tile per CU")
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    for flags, w, iters, warm in (
+            (ops.PD_REG_TV | ops.PD_DATA_L2, (1.0, 1.0, 1.0), 23, False),
+            (ops.PD_REG_HUBER | ops.PD_DATA_L1, (1.0, 0.5, 2.0), 12, True),
+            (ops.PD_REG_TV | ops.PD_DATA_L1, (0.7, 1.0, 1.3), 7, False),
+            (ops.PD_REG_HUBER | ops.PD_DATA_L2, (1.0, 1.0, 1.0), 40, True)):
+        bt = torch.rand(n, device="cuda", dtype=td, generator=gen)
+        p0 = (torch.rand(d * n, device="cuda", dtype=td, generator=gen) - 0.5)
+        sig, ta, th = step_schedule("ALG2", 4.0 * d * max(w) ** 2, 1 / 0.1, iters)
+        outs = []
+        for persist in (True, False):
+            x = bt.clone()
+            xb = [bt.clone() * 0.9, torch.empty_like(bt)]
+            p = [p0.clone() if warm else torch.zeros_like(p0), torch.empty_like(p0)]
+            before = ops.pd_persist_launches()
+            ops.PD_PERSIST = persist
+            slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, w, 1 / 0.1,
+                              sig, ta, th, not warm, 0.05, flags)
+            assert (ops.pd_persist_launches() - before) == (1 if persist else 0)
+            outs.append((x, xb[slot], p[slot]))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (shape, flags, w)
+
+
+def test_persistent_kernel_applies_only_where_it_fits(nsol):
+    import torch
+    from nsol_amd import ops, _lib
+    lib = _lib.load()
+    # rows that are not whole vectors, more tiles than CUs
+    assert lib.nsol_pd_persist_ws_bytes(4, 3, 7, 10, 13, 10) == -1
+    assert lib.nsol_pd_persist_ws_bytes(4, 3, 256, 256, 256, 10) == -1
+    assert lib.nsol_pd_persist_ws_bytes(4, 3, 64, 64, 64, 200) > 0
+    assert lib.nsol_pd_persist_ws_bytes(8, 2, 1, 256, 256, 50) > 0
+    # the solver takes it for BASELINE config 2 and stays bit-identical to the
+    # one-launch-per-iteration path
+    vol = 50.0 + 30.0 * np.random.default_rng(3).standard_normal((64, 64, 64))
+    res = []
+    for persist in (True, False):
+        ops.PD_PERSIST = persist
+        before = ops.pd_persist_launches()
+        s = _pd_solver(vol, "TV", "L2", 0.03, 200, 16.0, "ALG2", np.float32)
+        s.run()
+        assert s.get_execution() == "fused"
+        assert (ops.pd_persist_launches() - before) == (1 if persist else 0)
+        res.append(s.get_x())
+    assert np.array_equal(res[0], res[1])
+
+
 # ------------------------------------------- two iterations per pass (TB2)
 def _run_pd_raw(shape, dtype, iters, flags, enable2, zchunk2=0, seed=0,
                 two_pass=0, pdk=None, w=(1.0, 0.5, 2.0)):
