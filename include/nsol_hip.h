@@ -305,11 +305,13 @@ int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx
  * (nsol_pdp.hip).  Bit-identical to `iterations` calls of nsol_pd_fused_iter_*.
  * xbar, x, p are updated in place (p is read only when p_is_zero == 0); the step
  * sizes are host arrays as for nsol_pd_run_*.  ws: caller-owned DEVICE scratch
- * of nsol_pd_persist_ws_bytes() bytes, 16-byte aligned; the function clears it
- * (hipMemsetAsync) and copies the step sizes into it (hipMemcpyAsync) on
- * `stream`.  After the run the first 32-bit word of ws is non-zero if a
- * workgroup gave up waiting for a neighbour (every wait is bounded; the
- * results are then invalid and the caller falls back to nsol_pd_run_*).
+ * of nsol_pd_persist_ws_bytes() bytes, 16-byte aligned; a small set-up kernel
+ * on `stream` fills it (the step sizes travel as its arguments).  err_word:
+ * a 32-bit word the kernel can write, zeroed by the caller -- device memory or
+ * pinned host memory the caller inspects after its own synchronisation --, or
+ * NULL for the first word of ws (then cleared here).  It is non-zero after the
+ * run if a workgroup gave up waiting for a neighbour (every wait is bounded;
+ * the results are then invalid).
  * Returns -2 (nothing launched) when the kernel does not apply: rows not a
  * multiple of 16 bytes, unaligned arrays, more tiles than CUs.
  * nsol_pd_persist_ws_bytes returns -1 in that case. */
@@ -320,13 +322,15 @@ int nsol_pd_persist_run_f32(float *xbar, float *x, const float *bt, float *p, in
                             double wz, double lambda, const double *sigma_host,
                             const double *tau_host, const double *theta_host,
                             int iterations, int p_is_zero, double gamma_huber, int flags,
-                            void *ws, int64_t ws_bytes, void *stream);
+                            void *ws, int64_t ws_bytes, unsigned int *err_word,
+                            void *stream);
 int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p, int ndim,
                             int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
                             double wz, double lambda, const double *sigma_host,
                             const double *tau_host, const double *theta_host,
                             int iterations, int p_is_zero, double gamma_huber, int flags,
-                            void *ws, int64_t ws_bytes, void *stream);
+                            void *ws, int64_t ws_bytes, unsigned int *err_word,
+                            void *stream);
 /* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;

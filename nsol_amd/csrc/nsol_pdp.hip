@@ -12,11 +12,16 @@
 //   * exchanges its own values between lanes through LDS (two barriers), and
 //   * hands the one-voxel faces of xbar (first and last layer per axis) and of p
 //     (last layer, the component of that axis) to its <= 6 face neighbours through
-//     global memory as 8-byte {value, tag} granules written and polled with
-//     agent-scope relaxed atomics (sc1 stores / loads: a granule is complete when
-//     its tag says so, no fence, no flag); tag = iteration + 1, two slots per
-//     granule by iteration parity -- a workgroup can only run one iteration ahead
-//     of a neighbour, because it needs that neighbour's faces of every iteration.
+//     global memory: the faces are written with agent-scope (sc1, write-through)
+//     stores, drained (s_waitcnt vmcnt(0) + workgroup barrier), then ONE flag per
+//     tile is raised to the iteration number; a neighbour polls that flag with one
+//     lane, and then reads the faces with sc1 loads.  Two slots per face by
+//     iteration parity -- a workgroup can only run one iteration ahead of a
+//     neighbour, because it needs that neighbour's faces of every iteration.
+//     (A first version tagged every value, {value, tag} in 8 bytes, and polled the
+//     values themselves: one round trip less per iteration, but 27 tiny requests per
+//     boundary lane and round -- 14 us per iteration at 64^3, against 8 with one
+//     launch per iteration.)
 // The arithmetic per voxel is that of k_pd_fused in the same order (the new dual of
 // the lower neighbour voxel across a tile face is recomputed from the neighbour's
 // old p and xbar, exactly as k_pd_fused recomputes it across its patches), so the
@@ -24,12 +29,10 @@
 //
 // Co-residency: the grid is at most one workgroup per CU (checked on the host), so
 // every workgroup is running when its neighbours wait for it.  Every wait is still
-// bounded: a workgroup that does not see a granule within ~2^22 polls gives up
+// bounded: a workgroup that does not see a flag within ~2^21 polls gives up
 // polling for the rest of the run and raises the error word of the workspace,
 // which the host reads after the run -- no wave can spin forever.
 #include <string.h>
-
-#include <vector>
 
 #include "nsol_common.hpp"
 #include "nsol_pd_common.hpp"
@@ -39,7 +42,7 @@ using namespace nsol;
 namespace {
 
 constexpr int kMaxTiles = 256;
-constexpr int kMaxSpin = 1 << 22;
+constexpr int kMaxSpin = 1 << 21;   // polling rounds of ~1-2 us before a workgroup gives up
 constexpr int kKinds = 3;          // XF: xbar first layer, XL: xbar last, PL: p last
 
 template <typename T>
@@ -53,49 +56,54 @@ struct Tiling {
   int face;                        // elements of the largest tile face
 };
 
-// granules: 8 bytes {32 payload bits, 32-bit tag}; a double travels as two
-template <typename T> struct GranOf;
-template <> struct GranOf<float> { static constexpr int N = 1; };
-template <> struct GranOf<double> { static constexpr int N = 2; };
-
-__device__ __forceinline__ void gran_put(uint64_t *g, uint32_t bits, uint32_t tag) {
-  __hip_atomic_store(g, ((uint64_t)tag << 32) | (uint64_t)bits, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+// agent-scope relaxed accesses (sc1): written through to / read from the level all
+// XCDs share, in 8-byte pieces where the data allow
+__device__ __forceinline__ void put1(float *g, float v) {
+  __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// polls until the tag arrives; false (and *failed set) when it does not
-__device__ __forceinline__ uint32_t gran_get(const uint64_t *g, uint32_t tag, bool *failed) {
-  uint64_t v = 0;
-  if (*failed) return 0;
-  for (int spin = 0; spin < kMaxSpin; ++spin) {
-    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(v >> 32) == tag) return (uint32_t)v;
-    __builtin_amdgcn_s_sleep(1);
+__device__ __forceinline__ void put1(double *g, double v) {
+  __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float get1(const float *g) {
+  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double get1(const double *g) {
+  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void putv(float *g, const float (&v)[4]) {
+  uint64_t *q = reinterpret_cast<uint64_t *>(g);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    __hip_atomic_store(q + h, ((uint64_t)__float_as_uint(v[2 * h + 1]) << 32) |
+                                  (uint64_t)__float_as_uint(v[2 * h]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void putv(double *g, const double (&v)[2]) {
+  put1(g, v[0]);
+  put1(g + 1, v[1]);
+}
+__device__ __forceinline__ void getv(const float *g, float (&v)[4]) {
+  const uint64_t *q = reinterpret_cast<const uint64_t *>(g);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint64_t w = __hip_atomic_load(q + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[2 * h] = __uint_as_float((uint32_t)w);
+    v[2 * h + 1] = __uint_as_float((uint32_t)(w >> 32));
   }
-  *failed = true;
-  return 0;
 }
-__device__ __forceinline__ void val_put(uint64_t *g, float v, uint32_t tag) {
-  gran_put(g, __float_as_uint(v), tag);
-}
-__device__ __forceinline__ void val_put(uint64_t *g, double v, uint32_t tag) {
-  const uint64_t b = (uint64_t)__double_as_longlong(v);
-  gran_put(g, (uint32_t)b, tag);
-  gran_put(g + 1, (uint32_t)(b >> 32), tag);
-}
-__device__ __forceinline__ float val_get(const uint64_t *g, uint32_t tag, bool *failed, float) {
-  return __uint_as_float(gran_get(g, tag, failed));
-}
-__device__ __forceinline__ double val_get(const uint64_t *g, uint32_t tag, bool *failed, double) {
-  const uint64_t lo = gran_get(g, tag, failed), hi = gran_get(g + 1, tag, failed);
-  return __longlong_as_double((long long)((hi << 32) | lo));
+__device__ __forceinline__ void getv(const double *g, double (&v)[2]) {
+  v[0] = get1(g);
+  v[1] = get1(g + 1);
 }
 
-template <typename T, int VEC, int NDIM>
-__global__ __launch_bounds__(1024) void k_pd_persist(
+// MAXT: upper bound of the lanes per tile (the 256-lane form has registers for a
+// boundary lane's 27-30 granules in flight; the 1024-lane form spills a few of them)
+template <typename T, int VEC, int NDIM, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_pd_persist(
     T *__restrict__ xbar, T *__restrict__ x, const T *__restrict__ bt, T *__restrict__ p,
     Geom<T> G, const IterScalars<T> *__restrict__ sc, int iterations, int huber, int l1,
-    int has_p, Tiling Q, uint64_t *__restrict__ halo, unsigned int *__restrict__ err) {
-  constexpr int GN = GranOf<T>::N;
+    int has_p, Tiling Q, T *__restrict__ halo, unsigned int *__restrict__ flags,
+    unsigned int *__restrict__ err) {
   typedef typename Pack<T, VEC>::type V;
   extern __shared__ __attribute__((aligned(16))) unsigned char pdp_smem[];
   const int nthr = Q.lx * Q.ly * Q.lz;
@@ -120,12 +128,16 @@ __global__ __launch_bounds__(1024) void k_pd_persist(
   const bool edge_r = lx == Q.lx - 1, edge_l = lx == 0;
   const bool edge_u = ly == Q.ly - 1, edge_d = ly == 0;
   const bool edge_b = lz == Q.lz - 1, edge_f = lz == 0;
-  // halo addressing: [tile][axis][kind][slot][face element][GN]
+  // faces: [tile][slot][axis][kind][face element]; flags: [tile]
   const int64_t face = Q.face;
-  auto hp = [&](int ttx, int tty, int ttz, int axis, int kind, int slot, int64_t idx) {
-    const int64_t t = ((int64_t)ttz * Q.nty + tty) * Q.ntx + ttx;
-    return halo + ((((t * 3 + axis) * kKinds + kind) * 2 + slot) * face + idx) * GN;
+  constexpr int XF = 0, XL = 1, PL = 2;              // kinds
+  auto tile_id = [&](int ttx, int tty, int ttz) {
+    return ((int64_t)ttz * Q.nty + tty) * Q.ntx + ttx;
   };
+  auto hp = [&](int64_t t, int slot, int axis, int kind, int64_t idx) {
+    return halo + (((t * 2 + slot) * 3 + axis) * kKinds + kind) * face + idx;
+  };
+  const int64_t me = tile_id(tx, ty, tz);
   // face element index of this lane's voxels on the faces normal to each axis
   const int64_t fx = (int64_t)lz * Q.ly + ly;                        // one value
   const int64_t fy = ((int64_t)lz * Q.lx + lx) * VEC;                // VEC values
@@ -144,38 +156,55 @@ __global__ __launch_bounds__(1024) void k_pd_persist(
     }
   }
   bool failed = false;
-  // faces of the state after `k` iterations go out with tag k + 1 into slot k & 1
+  // faces of the state after `k` iterations go into slot k & 1; the tile's flag is
+  // raised to k + 1 once every lane's stores have been acknowledged
   auto publish = [&](int k) {
-    if (!in) return;
-    const uint32_t tag = (uint32_t)k + 1u;
     const int s = k & 1;
-    if (edge_l && has_l) val_put(hp(tx, ty, tz, 0, 0, s, fx), xb[0], tag);
-    if (edge_r && has_r) {
-      val_put(hp(tx, ty, tz, 0, 1, s, fx), xb[VEC - 1], tag);
-      val_put(hp(tx, ty, tz, 0, 2, s, fx), px[VEC - 1], tag);
-    }
-    if constexpr (NDIM >= 2) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        if (edge_d && has_d) val_put(hp(tx, ty, tz, 1, 0, s, fy + e), xb[e], tag);
+    if (in) {
+      if (edge_l && has_l) put1(hp(me, s, 0, XF, fx), xb[0]);
+      if (edge_r && has_r) {
+        put1(hp(me, s, 0, XL, fx), xb[VEC - 1]);
+        put1(hp(me, s, 0, PL, fx), px[VEC - 1]);
+      }
+      if constexpr (NDIM >= 2) {
+        if (edge_d && has_d) putv(hp(me, s, 1, XF, fy), xb);
         if (edge_u && has_u) {
-          val_put(hp(tx, ty, tz, 1, 1, s, fy + e), xb[e], tag);
-          val_put(hp(tx, ty, tz, 1, 2, s, fy + e), py[e], tag);
+          putv(hp(me, s, 1, XL, fy), xb);
+          putv(hp(me, s, 1, PL, fy), py);
         }
       }
-    }
-    if constexpr (NDIM >= 3) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        if (edge_f && has_f) val_put(hp(tx, ty, tz, 2, 0, s, fz + e), xb[e], tag);
+      if constexpr (NDIM >= 3) {
+        if (edge_f && has_f) putv(hp(me, s, 2, XF, fz), xb);
         if (edge_b && has_b) {
-          val_put(hp(tx, ty, tz, 2, 1, s, fz + e), xb[e], tag);
-          val_put(hp(tx, ty, tz, 2, 2, s, fz + e), pz[e], tag);
+          putv(hp(me, s, 2, XL, fz), xb);
+          putv(hp(me, s, 2, PL, fz), pz);
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(flags + me, (unsigned int)k + 1u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
   };
   publish(0);
+  // the (up to six) neighbour tiles whose flags lanes 0..5 poll
+  int64_t nb_tile = -1;
+  if (tid < 6) {
+    const int axis = tid >> 1, up = tid & 1;
+    const int ntile[3] = {Q.ntx, Q.nty, Q.ntz};
+    const int t3[3] = {tx, ty, tz};
+    if (axis < NDIM) {
+      int c[3] = {tx, ty, tz};
+      c[axis] += up ? 1 : -1;
+      // a neighbour tile matters only if it holds voxels of the volume
+      const int64_t lanes[3] = {(int64_t)Q.lx * VEC, Q.ly, Q.lz};
+      const int64_t ext[3] = {G.nx, G.ny, G.nz};
+      if (c[axis] >= 0 && c[axis] < ntile[axis] && (int64_t)c[axis] * lanes[axis] < ext[axis])
+        nb_tile = tile_id(c[0], c[1], c[2]);
+      (void)t3;
+    }
+  }
 
   for (int k = 0; k < iterations; ++k) {
     PdScalars<T> S;
@@ -185,37 +214,41 @@ __global__ __launch_bounds__(1024) void k_pd_persist(
       S.one_plus_tl = c.one_plus_tl; S.theta = c.theta;
       S.huber = huber; S.l1 = l1; S.has_p = 1;
     }
-    const uint32_t tag = (uint32_t)k + 1u;
     const int s = k & 1;
-    // ---- faces of the neighbouring tiles (state after k iterations)
+    // ---- wait until every neighbour tile has published its state after k
+    //      iterations (flag >= k + 1), then read its faces
+    if (nb_tile >= 0 && !failed) {
+      int spin = 0;
+      while (__hip_atomic_load(flags + nb_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+             (unsigned int)k + 1u) {
+        if (++spin >= kMaxSpin) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
     T xr = T(0), xl = T(0), pl_old = T(0);
     T xu[VEC], xd[VEC], pd_old[VEC], xbk[VEC], xf[VEC], pf_old[VEC];
     zero(xu); zero(xd); zero(pd_old); zero(xbk); zero(xf); zero(pf_old);
-    if (edge_r && has_r) xr = val_get(hp(tx + 1, ty, tz, 0, 0, s, fx), tag, &failed, T(0));
+    if (edge_r && has_r) xr = get1(hp(tile_id(tx + 1, ty, tz), s, 0, XF, fx));
     if (edge_l && has_l) {
-      xl = val_get(hp(tx - 1, ty, tz, 0, 1, s, fx), tag, &failed, T(0));
-      pl_old = val_get(hp(tx - 1, ty, tz, 0, 2, s, fx), tag, &failed, T(0));
+      const int64_t t = tile_id(tx - 1, ty, tz);
+      xl = get1(hp(t, s, 0, XL, fx));
+      pl_old = get1(hp(t, s, 0, PL, fx));
     }
     if constexpr (NDIM >= 2) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        if (edge_u && has_u)
-          xu[e] = val_get(hp(tx, ty + 1, tz, 1, 0, s, fy + e), tag, &failed, T(0));
-        if (edge_d && has_d) {
-          xd[e] = val_get(hp(tx, ty - 1, tz, 1, 1, s, fy + e), tag, &failed, T(0));
-          pd_old[e] = val_get(hp(tx, ty - 1, tz, 1, 2, s, fy + e), tag, &failed, T(0));
-        }
+      if (edge_u && has_u) getv(hp(tile_id(tx, ty + 1, tz), s, 1, XF, fy), xu);
+      if (edge_d && has_d) {
+        const int64_t t = tile_id(tx, ty - 1, tz);
+        getv(hp(t, s, 1, XL, fy), xd);
+        getv(hp(t, s, 1, PL, fy), pd_old);
       }
     }
     if constexpr (NDIM >= 3) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        if (edge_b && has_b)
-          xbk[e] = val_get(hp(tx, ty, tz + 1, 2, 0, s, fz + e), tag, &failed, T(0));
-        if (edge_f && has_f) {
-          xf[e] = val_get(hp(tx, ty, tz - 1, 2, 1, s, fz + e), tag, &failed, T(0));
-          pf_old[e] = val_get(hp(tx, ty, tz - 1, 2, 2, s, fz + e), tag, &failed, T(0));
-        }
+      if (edge_b && has_b) getv(hp(tile_id(tx, ty, tz + 1), s, 2, XF, fz), xbk);
+      if (edge_f && has_f) {
+        const int64_t t = tile_id(tx, ty, tz - 1);
+        getv(hp(t, s, 2, XL, fz), xf);
+        getv(hp(t, s, 2, PL, fz), pf_old);
       }
     }
     // ---- xbar of the tile to LDS; upper neighbours of every voxel
@@ -343,6 +376,37 @@ __global__ __launch_bounds__(1024) void k_pd_persist(
   if (failed) atomicOr(err, 1u);
 }
 
+// Step sizes of up to kSetupChunk iterations travel as kernel arguments (no host
+// -> device copy to wait for) and are turned into the per-iteration scalars on the
+// device with the arithmetic of make_scalars() (IEEE double, no contraction: the
+// same bits as on the host); the first chunk also clears the tiles' flags.
+constexpr int kSetupChunk = 128;
+struct SetupArgs {
+  double sig[kSetupChunk], tau[kSetupChunk], theta[kSetupChunk];
+};
+__device__ __forceinline__ float dev_huber_den(double den, float) { return (float)(1.0 / den); }
+__device__ __forceinline__ double dev_huber_den(double den, double) { return den; }
+__device__ __forceinline__ float dev_prox_den(double tl, float) { return (float)(1.0 / (1.0 + tl)); }
+__device__ __forceinline__ double dev_prox_den(double tl, double) { return 1.0 + tl; }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pdp_setup(SetupArgs A, int first, int count,
+                                                       double lambda, double gamma,
+                                                       int huber, IterScalars<T> *sc,
+                                                       unsigned int *flags, int nflags) {
+  const int i = threadIdx.x;
+  if (i < count) {
+    const double hden = huber ? 1.0 + A.sig[i] * gamma : 1.0;
+    const double tl = A.tau[i] * lambda;
+    IterScalars<T> c;
+    c.sigma = (T)A.sig[i]; c.hden = dev_huber_den(hden, T(0)); c.tau = (T)A.tau[i];
+    c.tl = (T)tl; c.one_plus_tl = dev_prox_den(tl, T(0)); c.theta = (T)A.theta[i];
+    sc[first + i] = c;
+  }
+  if (first == 0)
+    for (int j = i; j < nflags; j += kBlock) flags[j] = 0u;
+}
+
 inline int cu_count_pdp() {
   static int n = 0;
   if (n == 0) {
@@ -395,9 +459,10 @@ int64_t persist_ws_bytes(int ndim, int64_t nz, int64_t ny, int64_t nx, int itera
       !pick_tiling<VEC>(ndim, nz, ny, nx, &Q))
     return -1;
   const int64_t tiles = (int64_t)Q.ntx * Q.nty * Q.ntz;
-  const int64_t halo = tiles * 3 * kKinds * 2 * Q.face * GranOf<T>::N * 8;
+  const int64_t halo = tiles * 2 * 3 * kKinds * Q.face * (int64_t)sizeof(T);
   const int64_t scal = (((int64_t)iterations * sizeof(IterScalars<T>)) + 255) / 256 * 256;
-  return 256 + scal + halo;                        // [error word | scalars | halo]
+  const int64_t flg = (tiles * 4 + 255) / 256 * 256;
+  return 256 + scal + flg + halo;                  // [error word | scalars | flags | faces]
 }
 
 template <typename T>
@@ -405,7 +470,7 @@ int persist_run(T *xbar, T *x, const T *bt, T *p, int ndim, int64_t nz, int64_t 
                 int64_t nx, double wx, double wy, double wz, double lambda,
                 const double *sig, const double *tau, const double *theta, int iterations,
                 int p_is_zero, double gamma_huber, int flags, void *ws, int64_t ws_bytes,
-                void *stream) {
+                unsigned int *err_word, void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   constexpr int VEC = 16 / (int)sizeof(T);
   if (!xbar || !x || !bt || !p || !sig || !tau || !theta || iterations < 1 || !ws)
@@ -419,36 +484,51 @@ int persist_run(T *xbar, T *x, const T *bt, T *p, int ndim, int64_t nz, int64_t 
   pick_tiling<VEC>(ndim, nz, ny, nx, &Q);
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool huber = (flags & NSOL_PD_REG_HUBER) != 0;
-  std::vector<IterScalars<T>> sc((size_t)iterations);
-  for (int k = 0; k < iterations; ++k) {
-    const double hden = huber ? 1.0 + sig[k] * gamma_huber : 1.0;
-    const double tl = tau[k] * lambda;
-    sc[k].sigma = (T)sig[k]; sc[k].hden = huber_den<T>(hden); sc[k].tau = (T)tau[k];
-    sc[k].tl = (T)tl; sc[k].one_plus_tl = prox_den<T>(tl); sc[k].theta = (T)theta[k];
-  }
   hipStream_t st = as_stream(stream);
   unsigned char *base = static_cast<unsigned char *>(ws);
   const int64_t scal = (((int64_t)iterations * sizeof(IterScalars<T>)) + 255) / 256 * 256;
-  hipError_t e = hipMemsetAsync(base, 0, (size_t)need, st);      // error word, tags
-  if (e != hipSuccess) return (int)e;
-  // (pageable source: the runtime stages it before the call returns)
-  e = hipMemcpyAsync(base + 256, sc.data(), (size_t)iterations * sizeof(IterScalars<T>),
-                     hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return (int)e;
+  const int64_t tiles = (int64_t)Q.ntx * Q.nty * Q.ntz;
+  const int64_t flg = (tiles * 4 + 255) / 256 * 256;
+  auto *scd = reinterpret_cast<IterScalars<T> *>(base + 256);
+  auto *flags_d = reinterpret_cast<unsigned int *>(base + 256 + scal);
+  auto *halo = reinterpret_cast<T *>(base + 256 + scal + flg);
+  // the error word: the caller's (e.g. pinned host memory it can look at after its
+  // own synchronisation) or the first word of the workspace
+  unsigned int *err = err_word ? err_word : reinterpret_cast<unsigned int *>(base);
+  if (!err_word) {
+    hipError_t e = hipMemsetAsync(base, 0, 256, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  for (int first = 0; first < iterations; first += kSetupChunk) {
+    SetupArgs A;
+    const int count = iterations - first < kSetupChunk ? iterations - first : kSetupChunk;
+    for (int i = 0; i < count; ++i) {
+      A.sig[i] = sig[first + i]; A.tau[i] = tau[first + i]; A.theta[i] = theta[first + i];
+    }
+    for (int i = count; i < kSetupChunk; ++i) A.sig[i] = A.tau[i] = A.theta[i] = 0.0;
+    hipLaunchKernelGGL(k_pdp_setup<T>, dim3(1), dim3(kBlock), 0, st, A, first, count, lambda,
+                       gamma_huber, huber ? 1 : 0, scd, flags_d, (int)tiles);
+  }
   const int nthr = Q.lx * Q.ly * Q.lz;
   const size_t lds = (size_t)nthr * (3 * 16 + sizeof(T));
   const dim3 grid((unsigned)(Q.ntx * Q.nty * Q.ntz));
-  auto *scd = reinterpret_cast<const IterScalars<T> *>(base + 256);
-  auto *halo = reinterpret_cast<uint64_t *>(base + 256 + scal);
-  auto *err = reinterpret_cast<unsigned int *>(base);
-#define NSOL_PDP_GO(ND)                                                              \
-  hipLaunchKernelGGL((k_pd_persist<T, VEC, ND>), grid, dim3(nthr), lds, st, xbar, x, bt, \
-                     p, G, scd, iterations, huber ? 1 : 0,                            \
-                     (flags & NSOL_PD_DATA_L1) ? 1 : 0, p_is_zero ? 0 : 1, Q, halo, err)
-  switch (ndim) {
-    case 1: NSOL_PDP_GO(1); break;
-    case 2: NSOL_PDP_GO(2); break;
-    default: NSOL_PDP_GO(3); break;
+#define NSOL_PDP_GO(ND, MT)                                                          \
+  hipLaunchKernelGGL((k_pd_persist<T, VEC, ND, MT>), grid, dim3(nthr), lds, st, xbar, x, \
+                     bt, p, G, scd, iterations, huber ? 1 : 0,                        \
+                     (flags & NSOL_PD_DATA_L1) ? 1 : 0, p_is_zero ? 0 : 1, Q, halo, flags_d, \
+                     err)
+  if (nthr <= 256) {
+    switch (ndim) {
+      case 1: NSOL_PDP_GO(1, 256); break;
+      case 2: NSOL_PDP_GO(2, 256); break;
+      default: NSOL_PDP_GO(3, 256); break;
+    }
+  } else {
+    switch (ndim) {
+      case 1: NSOL_PDP_GO(1, 1024); break;
+      case 2: NSOL_PDP_GO(2, 1024); break;
+      default: NSOL_PDP_GO(3, 1024); break;
+    }
   }
 #undef NSOL_PDP_GO
   return launch_status();
@@ -470,20 +550,22 @@ int nsol_pd_persist_run_f32(float *xbar, float *x, const float *bt, float *p, in
                             double wz, double lambda, const double *sigma_host,
                             const double *tau_host, const double *theta_host,
                             int iterations, int p_is_zero, double gamma_huber, int flags,
-                            void *ws, int64_t ws_bytes, void *stream) {
+                            void *ws, int64_t ws_bytes, unsigned int *err_word,
+                            void *stream) {
   return persist_run<float>(xbar, x, bt, p, ndim, nz, ny, nx, wx, wy, wz, lambda,
                             sigma_host, tau_host, theta_host, iterations, p_is_zero,
-                            gamma_huber, flags, ws, ws_bytes, stream);
+                            gamma_huber, flags, ws, ws_bytes, err_word, stream);
 }
 int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p, int ndim,
                             int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
                             double wz, double lambda, const double *sigma_host,
                             const double *tau_host, const double *theta_host,
                             int iterations, int p_is_zero, double gamma_huber, int flags,
-                            void *ws, int64_t ws_bytes, void *stream) {
+                            void *ws, int64_t ws_bytes, unsigned int *err_word,
+                            void *stream) {
   return persist_run<double>(xbar, x, bt, p, ndim, nz, ny, nx, wx, wy, wz, lambda,
                              sigma_host, tau_host, theta_host, iterations, p_is_zero,
-                             gamma_huber, flags, ws, ws_bytes, stream);
+                             gamma_huber, flags, ws, ws_bytes, err_word, stream);
 }
 
 }  // extern "C"

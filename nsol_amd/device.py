@@ -114,7 +114,14 @@ def to_device(x, dtype=None):
 
 
 def to_numpy(t, dtype=np.float64):
-    return _download(t, dtype)
+    out = _download(t, dtype)
+    # (the copy has synchronised the stream: settle the error words of the
+    # persistent runs that produced what was just downloaded)
+    import sys
+    ops = sys.modules.get("nsol_amd.ops")
+    if ops is not None and ops._err_pending:
+        ops.drain_persist_checks()
+    return out
 
 
 def empty_like(t, n=None):

@@ -410,7 +410,7 @@ def pd_fusedk_plan(x, shape, k=3):
 # persistent kernel (nsol_pd_persist_run_*), from this many iterations on and up to
 # this many voxels (above, three iterations per pass take over).
 PD_PERSIST = True
-PD_PERSIST_MIN_ITERS = 6
+PD_PERSIST_MIN_ITERS = 16
 PD_PERSIST_MAX_VOXELS = 1 << 20
 _persist_launches = 0
 
@@ -420,12 +420,52 @@ def pd_persist_launches():
     return _persist_launches
 
 
+# Error words of the persistent runs: a ring of 32-bit words in pinned host
+# memory the kernels write to directly.  A word is looked at when the result is
+# downloaded (device.to_numpy -> drain_persist_checks: the stream has been
+# synchronised by then) or when its slot is needed again -- never with a
+# synchronisation of its own.
+_ERR_SLOTS = 256
+_err_ring = None
+_err_next = 0
+_err_pending = []          # (slot, stream the run was enqueued on)
+
+
+def _err_slot():
+    global _err_ring, _err_next
+    if _err_ring is None:
+        _err_ring = torch.zeros(_ERR_SLOTS, dtype=torch.int32).pin_memory()
+    slot = _err_next
+    _err_next = (_err_next + 1) % _ERR_SLOTS
+    for k, (s, _) in enumerate(_err_pending):
+        if s == slot:                     # the ring has wrapped: settle that run first
+            torch.cuda.synchronize()
+            drain_persist_checks()
+            break
+    _err_ring[slot] = 0
+    return slot
+
+
+def drain_persist_checks():
+    """Raise if a persistent run that has completed reported a time-out.  Call
+    after the stream(s) have been synchronised."""
+    bad = False
+    while _err_pending:
+        slot, _ = _err_pending.pop(0)
+        bad = bad or int(_err_ring[slot]) != 0
+    if bad:
+        raise _lib.NsolHipError(
+            "nsol_pd_persist_run: a workgroup gave up waiting for a neighbour "
+            "(device oversubscribed?); the result is invalid -- set "
+            "nsol_amd.ops.PD_PERSIST = False to run one launch per iteration")
+
+
 def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero,
                    gamma_huber, flags):
     """All len(sigma) iterations in one launch, state updated in place (xbar, x,
-    p).  Returns False when the kernel does not apply (nothing launched) or when
-    a workgroup gave up waiting for a neighbour (state restored: the caller runs
-    the ordinary path).  Syncs once to read the error word."""
+    p).  Returns False when the kernel does not apply (nothing launched).  Does
+    not synchronise: a time-out of a bounded wait inside the kernel surfaces as
+    an exception when the result is downloaded (drain_persist_checks)."""
     global _persist_launches
     ndim, nz, ny, nx = dims3(shape)
     iters = int(np.size(sigma))
@@ -437,23 +477,30 @@ def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero
     tau = np.ascontiguousarray(tau, dtype=np.float64)
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-    keep = (xbar.clone(), x.clone(), None if p_is_zero else p.clone())
+    slot = _err_slot()
     rc = _fn("pd_persist_run", x)(
         _p(xbar), _p(x), _p(bt), _p(p), ndim, nz, ny, nx, w[0], w[1], w[2],
         float(lmbda), sigma.ctypes.data, tau.ctypes.data, theta.ctypes.data, iters,
         int(bool(p_is_zero)), float(gamma_huber), int(flags), _p(ws), need,
-        stream_ptr())
+        _err_ring.data_ptr() + 4 * slot, stream_ptr())
     if rc == -2:
         return False
     _lib.check(rc, "nsol_pd_persist_run")
-    if int(ws[:4].view(torch.int32).item()) != 0:       # a bounded wait ran out
-        xbar.copy_(keep[0])
-        x.copy_(keep[1])
-        if keep[2] is not None:
-            p.copy_(keep[2])
-        return False
+    ws.record_stream(torch.cuda.current_stream())      # freed once the run is done
+    _err_pending.append((slot, stream_ptr()))
     _persist_launches += 1
     return True
+
+
+def persist_pays(shape, iterations):
+    """Where one launch per run beats one launch per iteration (tools/
+    bench_persist.py): the persistent kernel takes 4.2-4.8 us per iteration whatever
+    the size (the hand-off between workgroups) plus ~20 us per run; a launch per
+    iteration costs 5.3-6.7 us on 3-D volumes but only 3.4 us on small images."""
+    n = int(np.prod(shape))
+    if n > PD_PERSIST_MAX_VOXELS or iterations < PD_PERSIST_MIN_ITERS:
+        return False
+    return len(shape) == 3 or n >= (1 << 19)
 
 
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
@@ -462,8 +509,7 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
     holds the final state.  x holds the final primal iterate."""
     import ctypes
     ndim, nz, ny, nx = dims3(shape)
-    if PD_PERSIST and PD_PERSIST_MIN_ITERS <= np.size(sigma) and \
-            nz * ny * nx <= PD_PERSIST_MAX_VOXELS and \
+    if PD_PERSIST and persist_pays(shape, np.size(sigma)) and \
             pd_persist_run(xbar0, x, bt, p0, shape, w, lmbda, sigma, tau, theta,
                            p_is_zero, gamma_huber, flags):
         return 0

@@ -987,11 +987,18 @@ def test_persistent_kernel_is_bit_identical(nsol, shape, dtype):
             xb = [bt.clone() * 0.9, torch.empty_like(bt)]
             p = [p0.clone() if warm else torch.zeros_like(p0), torch.empty_like(p0)]
             before = ops.pd_persist_launches()
-            ops.PD_PERSIST = persist
-            slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, w, 1 / 0.1,
-                              sig, ta, th, not warm, 0.05, flags)
+            ops.PD_PERSIST = False
+            if persist:
+                assert ops.pd_persist_run(xb[0], x, bt, p[0], shape, w, 1 / 0.1, sig,
+                                          ta, th, not warm, 0.05, flags)
+                slot = 0
+            else:
+                slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, w, 1 / 0.1,
+                                  sig, ta, th, not warm, 0.05, flags)
             assert (ops.pd_persist_launches() - before) == (1 if persist else 0)
             outs.append((x, xb[slot], p[slot]))
+        torch.cuda.synchronize()
+        ops.drain_persist_checks()
         for a, b in zip(*outs):
             assert torch.equal(a, b), (shape, flags, w)
 

@@ -38,23 +38,31 @@ def main():
               "cfg1_lena_TVL2_50it_L2eq8"),
              ("config2 phantom 64^3 TVL2 200 it L2=16", ph, 200, 16.0,
               "cfg2_phantom_TVL2_200it_L2eq16")]
+    from nsol_amd import ops
     for name, obs, iters, L2, key in cases:
         for dtype in (np.float32, np.float64):
-            best = 1e9
-            for _ in range(5):
-                s = solver(obs, 0.03, iters, L2, dtype)
-                s._x0_device()                      # upload outside the timing
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                s.run()
-                best = min(best, time.perf_counter() - t0)
-            ref = g[key].astype(np.float64)
-            err = np.linalg.norm(s.get_x() - ref) / np.linalg.norm(ref)
-            print(json.dumps({"case": name, "dtype": np.dtype(dtype).name,
-                              "run_ms": round(best * 1e3, 3),
-                              "it_per_s": round(iters / best, 1),
-                              "rel_l2_vs_reference": float(err),
-                              "execution": s.get_execution()}), flush=True)
+            for persist in (True, False):
+                ops.PD_PERSIST = persist
+                best = 1e9
+                for _ in range(7):
+                    s = solver(obs, 0.03, iters, L2, dtype)
+                    s._x0_device()                  # upload outside the timing
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    s.run()
+                    torch.cuda.synchronize()        # the iterations, not their enqueue
+                    best = min(best, time.perf_counter() - t0)
+                ref = g[key].astype(np.float64)
+                err = np.linalg.norm(s.get_x() - ref) / np.linalg.norm(ref)
+                print(json.dumps({"case": name, "dtype": np.dtype(dtype).name,
+                                  "kernel": "k_pd_persist (one launch)" if persist
+                                  else "k_pd_fused (one launch per iteration)",
+                                  "run_ms": round(best * 1e3, 3),
+                                  "us_per_iteration": round(best * 1e6 / iters, 2),
+                                  "it_per_s": round(iters / best, 1),
+                                  "rel_l2_vs_reference": float(err),
+                                  "execution": s.get_execution()}), flush=True)
+    ops.PD_PERSIST = True
 
 
 if __name__ == "__main__":
