@@ -44,6 +44,7 @@ def main():
             for persist in (True, False):
                 ops.PD_PERSIST = persist
                 best = 1e9
+                before = ops.pd_persist_launches()
                 for _ in range(7):
                     s = solver(obs, 0.03, iters, L2, dtype)
                     s._x0_device()                  # upload outside the timing
@@ -55,7 +56,9 @@ def main():
                 ref = g[key].astype(np.float64)
                 err = np.linalg.norm(s.get_x() - ref) / np.linalg.norm(ref)
                 print(json.dumps({"case": name, "dtype": np.dtype(dtype).name,
-                                  "kernel": "k_pd_persist (one launch)" if persist
+                                  "persistent_kernel_allowed": persist,
+                                  "kernel": "k_pd_persist (one launch)"
+                                  if ops.pd_persist_launches() > before
                                   else "k_pd_fused (one launch per iteration)",
                                   "run_ms": round(best * 1e3, 3),
                                   "us_per_iteration": round(best * 1e6 / iters, 2),
