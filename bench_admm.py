@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--data-loss", default="linear")
     ap.add_argument("--repeat", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-blur-epilogue", action="store_true",
+                    help="LSMR's top-block update as its own pass instead of the "
+                         "blur's epilogue (A/B runs)")
     ap.add_argument("--param", action="append", default=[],
                     help="library knob name=value (A/B runs, e.g. "
                          "corr_blur3_dma=0 for the register-window blur)")
@@ -130,6 +133,8 @@ def main():
     from nsol_amd.synthetic import synth_volume
 
     from nsol_amd import _lib
+    if args.no_blur_epilogue:
+        LO.USE_BLUR_EPILOGUE = False
     for kv in args.param:
         k, v = kv.split("=")
         _lib.set_param(k, int(v))
@@ -186,7 +191,7 @@ def main():
                                "dimension=3 (BASELINE config 4)" % n,
                    "iterations": args.iterations, "iter_max": args.iter_max,
                    "minimizer": args.minimizer, "data_loss": args.data_loss,
-                   "knobs": args.param,
+                   "knobs": args.param, "blur_epilogue": not args.no_blur_epilogue,
                    "execution": execution},
         "rel_change_vs_input": rel_change, "finite": finite}
     if args.minimizer == "lsmr":

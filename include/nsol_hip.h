@@ -129,6 +129,24 @@ int nsol_corr3_wrap_f32(const float *x, float *out, int64_t nz, int64_t ny,
 int nsol_corr3_wrap_f64(const double *x, double *out, int64_t nz, int64_t ny,
                         int64_t nx, const double *taps_z, const double *taps_y,
                         const double *taps_x, int ntaps, void *stream);
+/* The same blur with LSMR's top-block update as its epilogue
+ * (tikhonov_linear_solver.py:226-274 driving SciPy's lsmr.py:320-336,
+ * `u = A v - alpha u`): io = ca * (A x) + cb * io in place and *result = the sum
+ * of squares of the new io (double), without A x going to memory.  ws: device
+ * scratch of ws_doubles doubles (one per tile; nsol_hip_reduce_ws_doubles()
+ * suffices up to 2048^3).  Returns -2 (nothing launched) where the LDS-DMA staged
+ * kernel does not apply: rows that are not whole 16-byte vectors, asymmetric
+ * taps, even / > 17 taps, unaligned arrays. */
+int nsol_corr3_wrap_axpby_f32(const float *x, float *io, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double ca, double cb,
+                              double *result, double *ws, int64_t ws_doubles,
+                              void *stream);
+int nsol_corr3_wrap_axpby_f64(const double *x, double *io, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double ca, double cb,
+                              double *result, double *ws, int64_t ws_doubles,
+                              void *stream);
 /* dense N-D correlation with DEVICE taps [kz][ky][kx] and centre (cz,cy,cx):
  *   out[i] = sum_t taps[t] * x[i + t - c].  Replaces linear_operators.py:60-68
  * (scipy.ndimage.convolve with an arbitrary kernel; the host flips the kernel
@@ -426,7 +444,9 @@ int nsol_vector_norm_sum_f64(const double *t, int ndim, int64_t m, int mode,
 #define NSOL_B_NONE 0
 #define NSOL_B_GRAD 1
 #define NSOL_B_IDENTITY 2
-/* u_top = c_av*Av + c_u*u_top;  u_bot = c_bv*B(v) + c_u*u_bot */
+/* u_top = c_av*Av + c_u*u_top;  u_bot = c_bv*B(v) + c_u*u_bot.  Av may be NULL
+ * when the top block has been updated by nsol_corr3_wrap_axpby_*: then only the
+ * lower block is updated and summed (bmode must not be 0). */
 int nsol_lsmr_u_update_f32(const float *Av, const float *v, float *u_top,
                            float *u_bot, int bmode, int ndim, int64_t nz,
                            int64_t ny, int64_t nx, double wx, double wy,

@@ -741,11 +741,18 @@ __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
 
 // ISO: the three axes share one set of taps (an isotropic Gaussian on unit or
 // isotropic spacing -- BASELINE config 4): 14 fewer live scalars at 13 taps.
-template <typename T, int VEC, int NT, int NW, bool ISO>
+// EPI: instead of storing A x the kernel forms io = ca * (A x) + cb * io in place and
+// the sum of squares of the result (per workgroup, in double: part[tile]) -- the top
+// block of LSMR's u update, `u_top = c * A v + c' * u_top` and its norm
+// (tikhonov_linear_solver.py:226-274 on SciPy's lsmr.py:320-336), without A v ever
+// going to memory.  The old io tile of the next output plane is staged by LDS-DMA
+// one phase ahead, issued BEFORE that phase's raw-tile pieces: the counted wait at
+// the end of the phase leaves only younger operations in flight, so it has landed.
+template <typename T, int VEC, int NT, int NW, bool ISO, bool EPI = false>
 __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
     Taps<T> tz_, Taps<T> ty_, Taps<T> tx, int ntx, int nty, int nzc, int zchunk,
-    int per_xcd) {
+    int per_xcd, T ca = T(1), T cb = T(0), double *__restrict__ part = nullptr) {
   const Taps<T> &tz = ISO ? tx : tz_;
   const Taps<T> &ty = ISO ? tx : ty_;
   typedef typename VecOf<T, VEC>::type V;
@@ -780,6 +787,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   static_assert(2 * R <= tyr, "halo rows must fit one round of lanes");
   V *raw = reinterpret_cast<V *>(smem_raw);    // three raw tiles, then two x-filtered
   V *xf = raw + 3 * (size_t)raw_stride;
+  constexpr int tile_vecs = tyr * lxb;         // (EPI) two tiles of the old io values
+  V *obuf = xf + 2 * (size_t)xf_stride;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -946,11 +955,39 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   const uint32_t plane_bytes = (uint32_t)(plane * sizeof(T));
   const uint32_t own_off =
       owner ? (uint32_t)(((y0 + row) * nx + (int64_t)xv * VEC) * sizeof(T)) : kNoLane;
-  auto put = [&](int64_t z, V val) {
+  double sumsq = 0.0;
+  auto put = [&](int64_t z, V val, int ob) {
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + z * plane, 0, plane_bytes,
                                                         0x00020000);
+    if constexpr (EPI) {
+      const V old = obuf[(size_t)ob * tile_vecs + (size_t)row * lxb + lx];
+      val = splat<V, T>(ca) * val + splat<V, T>(cb) * old;
+      if (owner) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sumsq += (double)val[e] * (double)val[e];
+      }
+    }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, own_off, 0, 0);
     asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
+  };
+  // (EPI) the io tile of one output plane -> obuf[ob]: one 1-KiB piece per wave; lanes
+  // whose tile position lies outside the volume re-read a valid neighbour
+  uint32_t old_off = 0;
+  if constexpr (EPI) {
+    const int i = wave * 64 + lane;
+    int64_t yy = y0 + i / lxb;
+    if (yy >= ny) yy = ny - 1;
+    int xx = bx * lxb + i % lxb;
+    if (xx >= nxv) xx = nxv - 1;
+    old_off = (uint32_t)(yy * nx + (int64_t)xx * VEC);
+  }
+  auto stage_old = [&](int64_t z, int ob) {
+    if constexpr (EPI)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(out + z * plane + old_off),
+          (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
+                                                     (size_t)wave * 64),
+          16, 0, 0);
   };
 
   // prologue: planes 0, 1, 2 staged, plane 0 filtered along x  (nsteps >= 2R + 1 >= 3)
@@ -972,6 +1009,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     constexpr int u = decltype(U)::value;           // = st mod M
     constexpr int q = u & 1;                        // = st & 1 (M is even)
     const bool more = st + 3 < nsteps;
+    if (EPI && st + 1 >= 2 * R && st + 1 < nsteps)
+      stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io of the next output plane
     if (more) stage(next_plane(), r_cur);           // plane st + 3, two phases ahead
     // (The x pass of plane st + 1 and the y / z passes of plane st are independent,
     // but letting half of the waves of a SIMD run them in the opposite order, so that
@@ -990,7 +1029,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         for (int t = 1; t < M; ++t)
           acc = __builtin_elementwise_fma(splat<V, T>(tz.w[sym(t)]), ring[(u + t) % M], acc);
         acc = __builtin_elementwise_fma(splat<V, T>(tz.w[0]), v, acc);
-        if (storing) put(zbeg + (st - 2 * R), acc);
+        if (storing) put(zbeg + (st - 2 * R), acc, q);
       }
       ring[u] = v;                                  // replaces plane st - M
     };
@@ -1003,6 +1042,34 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   };
 #pragma unroll 1
   for (int st0 = 0; st0 < nsteps; st0 += M) blur3_phases<0, M>(st0, nsteps, phase);
+  if constexpr (EPI) {
+    // (the last phase ended with a barrier: the LDS is free)
+    double *red = reinterpret_cast<double *>(smem_raw);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sumsq += __shfl_down(sumsq, o, 64);
+    if (lane == 0) red[wave] = sumsq;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < NW; ++w2) t += red[w2];
+      part[logical] = t;
+    }
+  }
+}
+
+// sum of the per-tile partials in a fixed order
+__global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, int n,
+                                                            double *result) {
+  __shared__ double s[kBlock];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) t += part[i];
+  s[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0;
+    for (int i = 0; i < kBlock; ++i) r += s[i];
+    *result = r;
+  }
 }
 
 inline int blur3_cu_count() {
@@ -1019,19 +1086,26 @@ inline int blur3_cu_count() {
 }
 
 // LDS-DMA staged kernel: tiles of kDmaLxb lanes per row whatever the row length;
-// returns -2 when it does not apply.
-template <typename T, int VEC, int NT, int NWD>
+// returns -2 when it does not apply.  EPI (out = io, in place): io = ca * blur(x) +
+// cb * io and *result = sum of squares of the new io (part: >= tiles doubles).
+template <typename T, int VEC, int NT, int NWD, bool EPI = false>
 int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                      const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
-                     hipStream_t st) {
+                     hipStream_t st, double ca = 1.0, double cb = 0.0,
+                     double *result = nullptr, double *part = nullptr,
+                     int64_t part_doubles = 0) {
   constexpr int R = NT / 2;
   constexpr int NBH = (R + VEC - 1) / VEC;
   constexpr int dl = kDmaLxb;
   constexpr int dtyr = (NWD * 64) / dl;
   constexpr int frows = dtyr + 2 * R;
   constexpr int npieces = (frows * (dl + 2 * NBH) + 63) / 64;
-  constexpr size_t lds = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl) * 16;
-  static_assert(lds <= 160 * 1024, "LDS-DMA blur tile does not fit");
+  constexpr size_t lds = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl +
+                          (EPI ? 2 * (size_t)dtyr * dl : 0)) * 16;
+  if constexpr (lds > 160 * 1024) {
+    static_assert(EPI, "LDS-DMA blur tile does not fit");
+    return -2;                                           // (no room for the io tiles)
+  } else {
   if (dtyr < 2 * R) return -2;
   const int64_t nxv = nx / VEC;
   const int64_t dntx = (nxv + dl - 1) / dl, dnty = (ny + dtyr - 1) / dtyr;
@@ -1054,10 +1128,12 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t tiles = dntx * dnty * nzc;
   if (tiles >= ((int64_t)1 << 28)) return -2;
+  if (EPI && tiles > part_doubles) return -2;
   const int per_xcd = (int)((tiles + 7) / 8);
   bool iso = true;
   for (int t = 0; t < NT; ++t) iso = iso && tz.w[t] == tx.w[t] && ty.w[t] == tx.w[t];
-  auto kern = iso ? k_blur3_dma<T, VEC, NT, NWD, true> : k_blur3_dma<T, VEC, NT, NWD, false>;
+  auto kern = iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI>
+                  : k_blur3_dma<T, VEC, NT, NWD, false, EPI>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1066,8 +1142,51 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
                      nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
-                     per_xcd);
+                     per_xcd, (T)ca, (T)cb, part);
+  if (EPI)
+    hipLaunchKernelGGL(k_blur3_epi_final, dim3(1), dim3(kBlock), 0, st, part, (int)tiles,
+                       result);
   return launch_status();
+  }
+}
+
+// nsol_corr3_wrap_axpby_*: io = ca * A x + cb * io in place with the sum of squares
+// of the result; -2 when the LDS-DMA kernel does not apply (the caller then blurs
+// and combines in two steps)
+template <typename T>
+int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
+                     const double *tz_host, const double *ty_host, const double *tx_host,
+                     int ntaps, double ca, double cb, double *result, double *ws,
+                     int64_t ws_doubles, void *stream) {
+  if (!x || !io || x == io || !tz_host || !ty_host || !tx_host || !result || !ws ||
+      nz < 1 || ny < 1 || nx < 1 || ntaps < 1)
+    return NSOL_EINVAL;
+  constexpr int VEC = 16 / sizeof(T);
+  if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > 17 || nx % VEC != 0 || !g_blur3_dma ||
+      g_blur3_lxb != kDmaLxb || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(io) & 15u))
+    return -2;
+  Taps<T> tz, ty, tx;
+  bool symmetric = true;
+  for (int t = 0; t < kMaxTaps; ++t) {
+    tz.w[t] = t < ntaps ? (T)tz_host[t] : T(0);
+    ty.w[t] = t < ntaps ? (T)ty_host[t] : T(0);
+    tx.w[t] = t < ntaps ? (T)tx_host[t] : T(0);
+  }
+  for (int t = 0; t < ntaps / 2; ++t)
+    symmetric = symmetric && tz.w[t] == tz.w[ntaps - 1 - t] &&
+                ty.w[t] == ty.w[ntaps - 1 - t] && tx.w[t] == tx.w[ntaps - 1 - t];
+  if (!symmetric) return -2;
+  hipStream_t st = as_stream(stream);
+#define NSOL_B3E_CASE(N)                                                               \
+  case N: return launch_blur3_dma<T, VEC, N, 16, true>(x, io, nz, ny, nx, tz, ty, tx, st, \
+                                                        ca, cb, result, ws, ws_doubles);
+  switch (ntaps) {
+    NSOL_B3E_CASE(3) NSOL_B3E_CASE(5) NSOL_B3E_CASE(7) NSOL_B3E_CASE(9)
+    NSOL_B3E_CASE(11) NSOL_B3E_CASE(13) NSOL_B3E_CASE(15) NSOL_B3E_CASE(17)
+    default: return -2;
+  }
+#undef NSOL_B3E_CASE
 }
 
 template <typename T, int VEC, int NT>
@@ -1242,6 +1361,22 @@ int nsol_corr3_wrap_f64(const double *x, double *out, int64_t nz, int64_t ny,
                         int64_t nx, const double *taps_z, const double *taps_y,
                         const double *taps_x, int ntaps, void *stream) {
   return corr3_impl<double>(x, out, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, stream);
+}
+int nsol_corr3_wrap_axpby_f32(const float *x, float *io, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double ca, double cb,
+                              double *result, double *ws, int64_t ws_doubles,
+                              void *stream) {
+  return corr3_axpby_impl<float>(x, io, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, ca, cb,
+                                 result, ws, ws_doubles, stream);
+}
+int nsol_corr3_wrap_axpby_f64(const double *x, double *io, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double ca, double cb,
+                              double *result, double *ws, int64_t ws_doubles,
+                              void *stream) {
+  return corr3_axpby_impl<double>(x, io, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, ca, cb,
+                                  result, ws, ws_doubles, stream);
 }
 int nsol_corr_dense_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const float *taps, int kz, int ky, int kx,

@@ -98,14 +98,16 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
     if (!c.ok) continue;
     {
     T a[VEC], u[VEC];
-    vl<RAG, T, VEC>(c.nval, Av + c.i, a);
-    vl<RAG, T, VEC>(c.nval, u_top + c.i, u);
+    if (Av) {      // (null: the top block was updated elsewhere -- the blur's epilogue)
+      vl<RAG, T, VEC>(c.nval, Av + c.i, a);
+      vl<RAG, T, VEC>(c.nval, u_top + c.i, u);
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      u[k] = c_av * a[k] + c_u * u[k];
-      if (!RAG || k < c.nval) acc += (double)u[k] * (double)u[k];
+      for (int k = 0; k < VEC; ++k) {
+        u[k] = c_av * a[k] + c_u * u[k];
+        if (!RAG || k < c.nval) acc += (double)u[k] * (double)u[k];
+      }
+      vs<RAG, T, VEC>(c.nval, u_top + c.i, u);
     }
-    vs<RAG, T, VEC>(c.nval, u_top + c.i, u);
     if (bmode == kBIdentity) {
       vl<RAG, T, VEC>(c.nval, v + c.i, a);
       vl<RAG, T, VEC>(c.nval, u_bot + c.i, u);
@@ -313,11 +315,12 @@ int u_impl(const T *Av, const T *v, T *u_top, T *u_bot, int bmode, int ndim,
            double c_av, double c_bv, double c_u, double *result, double *ws,
            void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (!Av || !u_top || !result || !ws || bmode < 0 || bmode > 2 ||
-      (bmode != kBNone && (!v || !u_bot)))
+  // Av == NULL: only the lower block is updated (and summed); needs one
+  if (!u_top || !result || !ws || bmode < 0 || bmode > 2 ||
+      (bmode != kBNone && (!v || !u_bot)) || (!Av && bmode == kBNone))
     return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  const bool al = ptr16(Av) && ptr16(u_top) && (!v || ptr16(v)) &&
+  const bool al = (!Av || ptr16(Av)) && ptr16(u_top) && (!v || ptr16(v)) &&
                   (!u_bot || ptr16(u_bot)) && G.n % 4 == 0;
   return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;

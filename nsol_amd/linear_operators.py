@@ -153,6 +153,8 @@ def _rank1_factors(kernel, tol=1e-13):
 
 # one-pass 3-D blur (nsol_corr3_wrap_*); False = always three 1-D passes
 USE_FUSED_BLUR3 = True
+# LSMR's top-block update as the epilogue of that blur (nsol_corr3_wrap_axpby_*)
+USE_BLUR_EPILOGUE = True
 
 
 class ConvolutionOperator(DeviceOperator):
@@ -194,6 +196,16 @@ class ConvolutionOperator(DeviceOperator):
                 and len({t.size for _, t, _ in p}) == 1
                 and p[0][1].size % 2 == 1
                 and all(c == t.size // 2 for _, t, c in p))
+
+    def apply_axpby(self, x, io, in_shape, ca, cb):
+        """io = ca * A(x) + cb * io in place with the sum of squares of the
+        result (flat device tensors; the top block of LSMR's u update as the
+        epilogue of the one-pass blur).  None when that kernel does not apply."""
+        if not (USE_FUSED_BLUR3 and USE_BLUR_EPILOGUE and self._passes and
+                len(in_shape) == 3 and self._fusable3()):
+            return None
+        return ops.corr3_wrap_axpby(x, io, in_shape, self._passes[0][1],
+                                    self._passes[1][1], self._passes[2][1], ca, cb)
 
     def _apply(self, x, in_shape):
         if len(in_shape) != self.dimension:

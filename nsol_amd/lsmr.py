@@ -156,11 +156,13 @@ def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-               atol=0.0, btol=0.0, conlim=1e8):
+               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
-    A, A_adj: device callables (flat tensor -> flat tensor)."""
+    A, A_adj: device callables (flat tensor -> flat tensor).  A_axpby(v, io, ca,
+    cb) -> sum of squares or None: io = ca * A v + cb * io formed by the blur
+    itself (its epilogue), when A is nsol_amd's one-pass blur."""
     import torch
     ut, ub = b_top, b_bot
     normb = math.sqrt(ops.dot(ut, ut) +
@@ -199,8 +201,15 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     while itn < maxiter:
         itn += 1
         # ut <- A v - alpha u   (v = vt/sv, u = ut/su)
-        nu2 = ops.lsmr_u_update(A(vt), vt, ut, ub, bmode, shape, w, 1.0 / sv,
-                                sa / sv, -alpha / su)
+        top2 = None
+        if A_axpby is not None and bmode != ops.B_NONE:
+            top2 = A_axpby(vt, ut, 1.0 / sv, -alpha / su)
+        if top2 is not None:
+            nu2 = top2 + ops.lsmr_u_update(None, vt, ut, ub, bmode, shape, w,
+                                           1.0 / sv, sa / sv, -alpha / su)
+        else:
+            nu2 = ops.lsmr_u_update(A(vt), vt, ut, ub, bmode, shape, w, 1.0 / sv,
+                                    sa / sv, -alpha / su)
         beta = math.sqrt(nu2)
         su = beta if beta > 0 else 1.0
         if beta > 0:

@@ -132,6 +132,27 @@ def corr3_wrap(x, shape, taps_z, taps_y, taps_x, out=None):
     return out
 
 
+def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True):
+    """io = ca * blur(x) + cb * io in place (the blur's epilogue; A x never goes
+    to memory); returns the sum of squares of the new io, or None when the
+    LDS-DMA staged kernel does not apply (nothing was launched)."""
+    _same(x, io)
+    _, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(t, dtype=np.float64)
+                  for t in (taps_z, taps_y, taps_x))
+    if not (tz.size == ty.size == tx.size):
+        return None
+    ws, res = _workspace(x.device)
+    rc = _fn("corr3_wrap_axpby", x)(
+        _p(x), _p(io), nz, ny, nx, tz.ctypes.data, ty.ctypes.data, tx.ctypes.data,
+        int(tz.size), float(ca), float(cb), _p(res), _p(ws), int(ws.numel()),
+        stream_ptr())
+    if rc == -2:
+        return None
+    _lib.check(rc, "nsol_corr3_wrap_axpby")
+    return float(res.item()) if sync else res
+
+
 def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
     _chk(x)
     _chk(taps_dev)
@@ -579,17 +600,22 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
     """u_top = c_av*Av + c_u*u_top; u_bot = c_bv*B(v) + c_u*u_bot;
     returns ||[u_top; u_bot]||^2 (sync=False: the device scalar, not read
     back)."""
-    _same(Av, v, u_top)
+    if Av is None:               # lower block only (top: corr3_wrap_axpby)
+        _same(u_top, v)
+        Av_ptr, nn = None, u_top.numel()
+    else:
+        _same(Av, v, u_top)
+        Av_ptr, nn = Av, Av.numel()
     if u_bot is not None:
         _chk(u_bot)
-        rows = (len(tuple(shape)) if bmode == B_GRAD else 1) * Av.numel()
-        if u_bot.dtype != Av.dtype or u_bot.numel() != rows:
+        rows = (len(tuple(shape)) if bmode == B_GRAD else 1) * nn
+        if u_bot.dtype != u_top.dtype or u_bot.numel() != rows:
             raise ValueError("lsmr_u_update: lower block has %d elements, "
                              "expected %d" % (u_bot.numel(), rows))
-    (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Av.numel())
-    ws, res = _workspace(Av.device)
-    _lib.check(_fn("lsmr_u_update", Av)(
-        _p(Av), _p(v), _p(u_top), _p(u_bot), int(bmode), ndim, nz, ny, nx,
+    (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, nn)
+    ws, res = _workspace(u_top.device)
+    _lib.check(_fn("lsmr_u_update", u_top)(
+        _p(Av_ptr), _p(v), _p(u_top), _p(u_bot), int(bmode), ndim, nz, ny, nx,
         w[0], w[1], w[2], float(c_av), float(c_bv), float(c_u), _p(res),
         _p(ws), stream_ptr()), "nsol_lsmr_u_update")
     return float(res.item()) if sync else res

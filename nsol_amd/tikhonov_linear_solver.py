@@ -130,11 +130,24 @@ class TikhonovLinearSolver(LinearSolver):
     def _run_lsmr(self, x0):
         fused = self._fused_lsmr_setup(x0) if USE_FUSED_LSMR else None
         if fused is not None:
-            x, _, _ = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max)
+            x, _, _ = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
+                                 A_axpby=self._blur_epilogue(x0.numel()))
             return x
         matvec, rmatvec, rhs = self._augmented(x0)
         x, _, _ = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
         return x
+
+    def _blur_epilogue(self, n):
+        """A_axpby(v, io, ca, cb) when A is nsol_amd's convolution operator seen
+        through the caller's reshape / flatten lambda (its one-pass blur can form
+        the top block of LSMR's u update itself), else None."""
+        d = trace_operator(self._A, n)
+        if d is None or d[0] != "conv" or int(np.prod(d[2])) != n:
+            return None
+        op, shape = d[1], tuple(d[2])
+        if not hasattr(op, "apply_axpby"):
+            return None
+        return lambda v, io, ca, cb: op.apply_axpby(v, io, shape, ca, cb)
 
     def _fused_lsmr_setup(self, x0):
         """Arguments for lsmr_fused when the regulariser operator is

@@ -102,6 +102,39 @@ def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
         assert rel_l2(one, ref) < (1e-12 if dtype == np.float64 else 2e-6)
 
 
+@pytest.mark.parametrize("shape,sigma2,dtype", [
+    ((20, 37, 64), 2.0, np.float64), ((9, 5, 16), 4.0, np.float64),
+    ((33, 70, 132), 1.0, np.float32), ((64, 64, 64), 4.0, np.float32),
+    ((40, 48, 512), 4.0, np.float32), ((130, 66, 72), 4.0, np.float32),
+    ((7, 100, 24), 0.5, np.float64), ((16, 16, 16), 7.0, np.float32)])
+def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
+    """nsol_corr3_wrap_axpby_* (io = ca * A x + cb * io formed by the blur itself,
+    with the sum of squares of the result: the top block of LSMR's u update,
+    SciPy lsmr.py:320-336) against the blur followed by nsol_lincomb2 / nsol_dot:
+    tiles that stick out of the volume, z-chunk seams, several tap counts."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    io0 = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    A, _ = _lo(3).get_gaussian_blurring_operators(np.diag([sigma2] * 3))
+    assert A._fusable3()
+    ca, cb = 0.37, -1.25
+    ref = ops.lincomb2(ca, A(x.view(shape)).view(-1), cb, io0)
+    io = io0.clone()
+    got2 = A.apply_axpby(x, io, shape, ca, cb)
+    assert got2 is not None, "the epilogue kernel did not run"
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    d = ops.norm2(ops.lincomb2(1.0, io, -1.0, ref)) / ops.norm2(ref)
+    assert d < tol, d
+    ref2 = ops.dot(ref, ref)
+    assert abs(got2 - ref2) / ref2 < (1e-12 if dtype == np.float64 else 2e-6)
+    # (the sum belongs to the values the kernel stored)
+    assert abs(got2 - ops.dot(io, io)) / ref2 < 1e-12
+
+
 @pytest.mark.parametrize("mode", ["wrap", "constant", "nearest", "reflect",
                                   "mirror"])
 def test_user_kernel_convolution(nsol, golden, mode):
