@@ -16,8 +16,9 @@ to this build's op list):
   k_lsmr_v               24   (read A^T u, u_bot[3], v; write v)
   k_lsmr_hx              28   (read hbar, x, h, v; write hbar, x, h)
   k_admm_vw              52   (read x, v[3], w[3]; write v[3], w[3], rhs[3])
-One LSMR iteration = 2 blurs + u + v + hx = 108; one ADMM iteration with
-LSMR(iter_max) = iter_max * 108 + set-up (copy of b 8, scaled rhs 24, its norm
+One LSMR iteration = 2 blurs + u + v + hx = 108 (the contract's figure; with the
+blur's epilogue forming the top block of u the kernels move 100); one ADMM iteration
+with LSMR(iter_max) = iter_max * 108 + set-up (copy of b 8, scaled rhs 24, its norm
 16, A^T b 8, first v 24, h 8, zeroed x / hbar 8) + clip 8 + k_admm_vw 52
 = iter_max * 108 + 156  (1 236 B per voxel for iter_max = 10).
 """
