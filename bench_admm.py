@@ -119,6 +119,10 @@ def main():
     ap.add_argument("--no-blur-epilogue", action="store_true",
                     help="LSMR's top-block update as its own pass instead of the "
                          "blur's epilogue (A/B runs)")
+    ap.add_argument("--no-prescaled-rhs", action="store_true",
+                    help="scale and norm passes over LSMR's lower right-hand side "
+                         "per ADMM iteration instead of taking both from the outer "
+                         "step (A/B runs)")
     ap.add_argument("--param", action="append", default=[],
                     help="library knob name=value (A/B runs, e.g. "
                          "corr_blur3_dma=0 for the register-window blur)")
@@ -136,6 +140,8 @@ def main():
     from nsol_amd import _lib
     if args.no_blur_epilogue:
         LO.USE_BLUR_EPILOGUE = False
+    if args.no_prescaled_rhs:
+        admm.USE_PRESCALED_RHS = False
     for kv in args.param:
         k, v = kv.split("=")
         _lib.set_param(k, int(v))
@@ -193,6 +199,7 @@ def main():
                    "iterations": args.iterations, "iter_max": args.iter_max,
                    "minimizer": args.minimizer, "data_loss": args.data_loss,
                    "knobs": args.param, "blur_epilogue": not args.no_blur_epilogue,
+                   "prescaled_rhs": not args.no_prescaled_rhs,
                    "execution": execution},
         "rel_change_vs_input": rel_change, "finite": finite}
     if args.minimizer == "lsmr":

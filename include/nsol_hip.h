@@ -389,6 +389,22 @@ int nsol_admm_vw_update_f64(const double *x, double *v, double *w,
                             int64_t ny, int64_t nx, double wx, double wy,
                             double wz, double thr, double rhs_scale,
                             void *stream);
+/* The same with *result = the sum of squares of the rhs written (double; ws:
+ * nsol_hip_reduce_ws_doubles() doubles): with rhs_scale = sqrt(rho) the rhs is
+ * the lower block of the right-hand side LSMR starts from
+ * (tikhonov_linear_solver.py:232-236) and the sum its share of ||b||^2, so
+ * neither a scaling pass nor a norm pass over it is needed.  rhs must not be
+ * NULL. */
+int nsol_admm_vw_update_norm_f32(const float *x, float *v, float *w, const float *c,
+                                 float *rhs, int ndim, int64_t nz, int64_t ny,
+                                 int64_t nx, double wx, double wy, double wz,
+                                 double thr, double rhs_scale, double *result,
+                                 double *ws, void *stream);
+int nsol_admm_vw_update_norm_f64(const double *x, double *v, double *w,
+                                 const double *c, double *rhs, int ndim, int64_t nz,
+                                 int64_t ny, int64_t nx, double wx, double wy,
+                                 double wz, double thr, double rhs_scale,
+                                 double *result, double *ws, void *stream);
 /* isotropic vector soft-threshold alone (admm_linear_solver.py:239-253):
  * t, v are ndim stacked blocks of m elements. */
 int nsol_vector_shrink_f32(const float *t, float *v, int ndim, int64_t m,

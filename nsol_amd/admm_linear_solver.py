@@ -19,6 +19,11 @@ from .linear_solver import LinearSolver
 from .symbolic import trace_operator
 from ._accessors import add_accessors
 from . import tikhonov_linear_solver as tk
+from .definitions import EPS
+
+# the fused outer step hands LSMR its lower right-hand side pre-multiplied by
+# sqrt(rho) together with its norm (False: scale and norm passes per iteration)
+USE_PRESCALED_RHS = True
 
 
 class ADMMLinearSolver(LinearSolver):
@@ -80,12 +85,27 @@ class ADMMLinearSolver(LinearSolver):
         if c is not None:
             breg = ops.lincomb2(1.0, breg, 1.0, c, out=breg)
         thr = self._alpha / self._rho
+        # With the fused outer step and the fused LSMR inside, the step writes
+        # the next right-hand side already multiplied by sqrt(rho) -- what the
+        # augmented system wants (tikhonov :232-236) -- together with its sum of
+        # squares, and ||b||^2 is taken once: no scaling pass and no norm passes
+        # per ADMM iteration.
+        prescale = fused and tk.USE_FUSED_LSMR and USE_PRESCALED_RHS and \
+            self._minimizer == "lsmr" and self._data_loss == "linear" and \
+            self._rho > EPS
+        sa = float(np.sqrt(self._rho))
+        hint = None
+        b2 = ops.dot(self._dev(self._b), self._dev(self._b)) if prescale else None
 
         for i in range(self._iterations):
             if self._verbose:
                 print("ADMM iteration %d/%d" % (i + 1, self._iterations))
-            x = self._solve_tikhonov_least_squares(x, breg)
-            if fused:
+            x = self._solve_tikhonov_least_squares(x, breg, hint)
+            if fused and prescale:
+                n2 = ops.admm_vw_update(x, v, w, c, breg, desc[2], desc[1].w, thr,
+                                        sa, want_norm=True)
+                hint = (sa, b2, n2)        # breg holds sqrt(rho) * (v - w + c)
+            elif fused:
                 ops.admm_vw_update(x, v, w, c, breg, desc[2], desc[1].w, thr,
                                    1.0)
             else:
@@ -103,7 +123,7 @@ class ADMMLinearSolver(LinearSolver):
                 self._observer.add_x(self.get_x())
         self._x = x
 
-    def _solve_tikhonov_least_squares(self, x, b_reg):
+    def _solve_tikhonov_least_squares(self, x, b_reg, prescaled=None):
         # admm :220-237: data_loss_scale and bounds are NOT forwarded
         tikhonov = tk.TikhonovLinearSolver(
             A=self._A, A_adj=self._A_adj, B=self._B, B_adj=self._B_adj,
@@ -111,6 +131,7 @@ class ADMMLinearSolver(LinearSolver):
             x_scale=1, iter_max=self._iter_max, data_loss=self._data_loss,
             minimizer=self._minimizer, verbose=self._verbose,
             dtype=self._dtype, _borrow=True)
+        tikhonov._prescaled_b_reg = prescaled
         tikhonov.run()
         return tikhonov._x
 

@@ -187,14 +187,17 @@ inline int reduce_grid(int64_t n) {
 
 // ------------------------------------------------------------------ ADMM ----
 // admm_linear_solver.py:208-216 with grad fused in
-template <typename T, int VEC, int ROWS, bool RAG>
+// NORM: also the sum of squares of the right-hand side written (per workgroup:
+// ws[block]) -- the lower part of ||b|| that LSMR starts from
+template <typename T, int VEC, int ROWS, bool RAG, bool NORM = false>
 __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
                                                      T *__restrict__ v,
                                                      T *__restrict__ w,
                                                      const T *__restrict__ c,
                                                      T *__restrict__ rhs,
                                                      Geom<T> G, T thr,
-                                                     T rhs_scale) {
+                                                     T rhs_scale, double *ws = nullptr) {
+  double acc = 0.0;
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
   const Voxel q = voxel_at<T, VEC, ROWS>(G, rg);
@@ -239,11 +242,24 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
       va[k] = (nrm[k] > thr) ? mag[k] * t[a][k] / nrm[k] : T(0);
       wa[k] = t[a][k] - va[k];
       ra[k] = rhs_scale * (va[k] - wa[k] + cc[a][k]);
+      if (NORM && (!RAG || k < q.nval)) acc += (double)ra[k] * (double)ra[k];
     }
     vs<RAG, T, VEC>(q.nval, v + a * G.n + q.i, va);
     vs<RAG, T, VEC>(q.nval, w + a * G.n + q.i, wa);
     if (rhs) vs<RAG, T, VEC>(q.nval, rhs + a * G.n + q.i, ra);
   }
+  }
+  if constexpr (NORM) {
+    __shared__ double sred[kBlock / kWave];
+    acc = wave_sum(acc);
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    if (lane == 0) sred[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int k = 0; k < kBlock / kWave; ++k) t += sred[k];
+      ws[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
   }
 }
 
@@ -528,18 +544,29 @@ int dot_impl(const T *x, const T *y, int64_t n, double *result, double *ws,
 template <typename T>
 int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
                  int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
-                 double wz, double thr, double rhs_scale, void *stream) {
+                 double wz, double thr, double rhs_scale, void *stream,
+                 double *result = nullptr, double *ws = nullptr) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (!x || !v || !w) return NSOL_EINVAL;
+  if (!x || !v || !w || (result && (!ws || !rhs))) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool al = ptr16(x) && ptr16(v) && ptr16(w) && (!c || ptr16(c)) &&
                   (!rhs || ptr16(rhs)) && G.n % 4 == 0;
   return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
     constexpr bool RG = decltype(rag)::value;
-    hipLaunchKernelGGL((k_admm_vw<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
-                       dim3(kBlock), 0, as_stream(stream), x, v, w, c, rhs, G,
-                       (T)thr, (T)rhs_scale);
+    const dim3 grid = stencil_grid<V, R>(nz, ny, nx);
+    if (result) {
+      const int nparts = (int)(grid.x * grid.y);
+      if (nparts > kReducePartials) return NSOL_EINVAL;
+      hipLaunchKernelGGL((k_admm_vw<T, V, R, RG, true>), grid, dim3(kBlock), 0,
+                         as_stream(stream), x, v, w, c, rhs, G, (T)thr, (T)rhs_scale, ws);
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws,
+                         nparts, result, 1.0);
+      return launch_status();
+    }
+    hipLaunchKernelGGL((k_admm_vw<T, V, R, RG>), grid, dim3(kBlock), 0,
+                       as_stream(stream), x, v, w, c, rhs, G, (T)thr, (T)rhs_scale,
+                       (double *)nullptr);
     return launch_status();
   });
 }
@@ -666,6 +693,15 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
                                 double rs, void *s) {                            \
     return admm_vw_impl<T>(x, v, w, c, rhs, ndim, nz, ny, nx, wx, wy, wz, thr,   \
                            rs, s);                                               \
+  }                                                                              \
+  int nsol_admm_vw_update_norm_##SUF(const T *x, T *v, T *w, const T *c, T *rhs, \
+                                     int ndim, int64_t nz, int64_t ny,           \
+                                     int64_t nx, double wx, double wy, double wz,\
+                                     double thr, double rs, double *res,         \
+                                     double *ws, void *s) {                      \
+    if (!res || !ws) return NSOL_EINVAL;                                         \
+    return admm_vw_impl<T>(x, v, w, c, rhs, ndim, nz, ny, nx, wx, wy, wz, thr,   \
+                           rs, s, res, ws);                                      \
   }                                                                              \
   int nsol_vector_shrink_##SUF(const T *t, T *v, int ndim, int64_t m,            \
                                double thr, void *s) {                            \

@@ -156,17 +156,21 @@ def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None):
+               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
     A, A_adj: device callables (flat tensor -> flat tensor).  A_axpby(v, io, ca,
     cb) -> sum of squares or None: io = ca * A v + cb * io formed by the blur
-    itself (its epilogue), when A is nsol_amd's one-pass blur."""
+    itself (its epilogue), when A is nsol_amd's one-pass blur.  normb2: the squared
+    norm of the right-hand side when the caller has it already."""
     import torch
     ut, ub = b_top, b_bot
-    normb = math.sqrt(ops.dot(ut, ut) +
-                      (ops.dot(ub, ub) if ub is not None else 0.0))
+    if normb2 is not None:           # ||[b_top; b_bot]||^2 known to the caller
+        normb = math.sqrt(normb2)
+    else:
+        normb = math.sqrt(ops.dot(ut, ut) +
+                          (ops.dot(ub, ub) if ub is not None else 0.0))
     x = torch.zeros_like(x_like)
     beta = normb
     su = beta if beta > 0 else 1.0

@@ -548,8 +548,17 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
 
 
 # ----------------------------------------------------------------- ADMM ----
-def admm_vw_update(x, v, w_, c, rhs, shape, w, thr, rhs_scale):
+def admm_vw_update(x, v, w_, c, rhs, shape, w, thr, rhs_scale, want_norm=False):
+    """v, w_ and the next right-hand side rhs = rhs_scale * (v - w_ + c) from one
+    pass over x; want_norm: returns sum(rhs^2) (syncs)."""
     ndim, nz, ny, nx = dims3(shape)
+    if want_norm:
+        ws, res = _workspace(x.device)
+        _lib.check(_fn("admm_vw_update_norm", x)(
+            _p(x), _p(v), _p(w_), _p(c), _p(rhs), ndim, nz, ny, nx, w[0], w[1],
+            w[2], float(thr), float(rhs_scale), _p(res), _p(ws), stream_ptr()),
+            "nsol_admm_vw_update_norm")
+        return float(res.item())
     _lib.check(_fn("admm_vw_update", x)(
         _p(x), _p(v), _p(w_), _p(c), _p(rhs), ndim, nz, ny, nx, w[0], w[1],
         w[2], float(thr), float(rhs_scale), stream_ptr()),

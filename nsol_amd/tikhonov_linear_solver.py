@@ -53,6 +53,9 @@ class TikhonovLinearSolver(LinearSolver):
         self._B_adj = B_adj
         self._b_reg = self._scaled(b_reg)          # tikhonov :91
         self._bounds = bounds
+        # (sqrt(alpha), ||b||^2, ||sqrt(alpha) b_reg||^2) when b_reg already holds
+        # sqrt(alpha) * b_reg (set by ADMMLinearSolver's fused outer step)
+        self._prescaled_b_reg = None
 
     def get_b_reg(self):
         if is_device_tensor(self._b_reg):
@@ -129,10 +132,15 @@ class TikhonovLinearSolver(LinearSolver):
 
     def _run_lsmr(self, x0):
         fused = self._fused_lsmr_setup(x0) if USE_FUSED_LSMR else None
+        pre = self._prescaled_b_reg
         if fused is not None:
             x, _, _ = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
-                                 A_axpby=self._blur_epilogue(x0.numel()))
+                                 A_axpby=self._blur_epilogue(x0.numel()),
+                                 normb2=None if pre is None else pre[1] + pre[2])
             return x
+        if pre is not None:            # (not expected: undo the pre-multiplication)
+            self._b_reg = ops.scale(self._dev(self._b_reg), 1.0 / pre[0])
+            self._prescaled_b_reg = None
         matvec, rmatvec, rhs = self._augmented(x0)
         x, _, _ = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
         return x
@@ -186,11 +194,20 @@ class TikhonovLinearSolver(LinearSolver):
         else:
             return None
         sa = float(np.sqrt(self._alpha))
-        if is_device_tensor(self._b_reg) or np.ndim(self._b_reg) > 0:
+        if self._prescaled_b_reg is not None and \
+                is_device_tensor(self._b_reg) and self._b_reg.numel() == rows:
+            # already sqrt(alpha) * b_reg; consumed by LSMR (it becomes u's lower
+            # block), which is fine: the caller rewrites it before the next solve
+            lower = self._dev(self._b_reg)
+        elif is_device_tensor(self._b_reg) or np.ndim(self._b_reg) > 0:
+            if self._prescaled_b_reg is not None:
+                return None
             lower = ops.scale(self._dev(self._b_reg), sa)
             if lower.numel() != rows:
                 return None
         else:
+            if self._prescaled_b_reg is not None:
+                return None
             import torch
             lower = torch.full((rows,), sa * float(self._b_reg),
                                dtype=x0.dtype, device=x0.device)
