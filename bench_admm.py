@@ -44,6 +44,15 @@ def bytes_per_admm_iteration(iter_max):
     return iter_max * 108 + SETUP_BYTES
 
 
+def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs):
+    """What the kernels have to move at least with this build's fusions: the
+    blur's epilogue saves the write and the read of A v (8 B per LSMR iteration),
+    the pre-scaled right-hand side the scaling pass, its norm pass and the norm
+    pass over b (40 B per ADMM iteration)."""
+    return iter_max * (100 if blur_epilogue else 108) + SETUP_BYTES - \
+        (40 if prescaled_rhs else 0)
+
+
 def time_kernels(shape, reps=20):
     """Average launch duration of each kernel of the LSMR branch on vectors of
     the run's size (HIP events on the launch stream, 3 warm-up launches)."""
@@ -224,6 +233,14 @@ def main():
             "whole_run": {
                 "algorithmic_bytes_per_voxel_per_admm_iteration":
                     bytes_per_admm_iteration(args.iter_max),
+                "bytes_moved_per_voxel_per_admm_iteration":
+                    bytes_moved_per_admm_iteration(
+                        args.iter_max, not args.no_blur_epilogue,
+                        not args.no_prescaled_rhs),
+                "frac_moved": bytes_moved_per_admm_iteration(
+                    args.iter_max, not args.no_blur_epilogue,
+                    not args.no_prescaled_rhs) * nvox * args.iterations / med / 1e9 /
+                HBM_PEAK_GBPS,
                 "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
                 "kernel_ms_per_admm_iteration_sum":
                     sum(k["ms_per_admm_iteration"] for k in kern.values())}}
