@@ -1,0 +1,29 @@
+#!/bin/bash
+# The measurement battery behind profiles/<tag>_*: GPU test suite (observed
+# errors), smoke, headline bench (plain, under rocprofv3 --stats, PMC passes),
+# config 4 (both branches, plain and under rocprofv3 --stats), the blur's PMC
+# passes, the driver's own bench invocation, the launcher rehearsals.
+#   tools/battery.sh <tag>      (on the GPU box; results under gpurun_out/)
+set -e
+TAG=${1:-prof}
+O=gpurun_out
+mkdir -p $O
+timeout -k 10 500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/${TAG}_pytest_gpu.log
+cp $O/parity_errors.json $O/${TAG}_parity_errors.json
+python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1
+timeout -k 10 500 bash tools/profile_bench.sh ${TAG}
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_driver_args.json 2>> $O/${TAG}_bench.err
+timeout -k 10 300 bash tools/profile_admm.sh ${TAG}
+python bench_admm.py > $O/${TAG}_bench_admm_lsmr.json 2>/dev/null
+python bench_admm.py --minimizer L-BFGS-B --data-loss huber > $O/${TAG}_bench_admm_lbfgsb_huber.json 2>/dev/null
+timeout -k 10 300 bash tools/profile_blur3.sh ${TAG}
+python3 tools/summarize_pmc.py blur3 $O/${TAG}_blur3_stats $O/${TAG}_blur3_fetch $O/${TAG}_blur3_write $O/${TAG}_blur3_sq1 $O/${TAG}_blur3_sq2 > $O/${TAG}_blur3_pmc.jsonl
+python bench.py --gpus 2 --backend gloo --steps 300 > $O/${TAG}_bench_2ranks_gloo.json 2>> $O/${TAG}_bench.err
+python bench.py --gpus 2 --backend gloo --batch 4 --steps 150 > $O/${TAG}_bench_batch4_2ranks_gloo.json 2>> $O/${TAG}_bench.err
+python tools/bench_small.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_small.jsonl
+python tools/bench_persist.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_persist.jsonl
+python tools/bench_lbfgsb_kernels.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_lbfgsb_kernels.jsonl
+python tools/bench_blur3_taps.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_blur3_taps.jsonl
+python tools/bench_shapes.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_shapes.jsonl
+echo BATTERY_DONE
