@@ -397,3 +397,26 @@ def test_data_term_cache_sees_in_place_changes():
     f1 = _fingerprint(b)
     b[3] = -1.0
     assert _fingerprint(b) != f1
+
+
+def test_persistent_kernel_tiling_rules():
+    """nsol_pd_persist_ws_bytes (host logic only): the persistent kernel applies
+    to volumes one tile of <= 1024 lanes per CU can cover, with rows of whole
+    16-byte vectors; the workspace grows with the iteration count (the step
+    sizes live in it)."""
+    from nsol_amd import _lib, ops
+    lib = _lib.load()
+    ws = lib.nsol_pd_persist_ws_bytes
+    assert ws(4, 3, 64, 64, 64, 200) > 0 and ws(8, 3, 64, 64, 64, 200) > 0
+    assert ws(4, 2, 1, 256, 256, 50) > 0 and ws(4, 1, 1, 1, 4096, 10) > 0
+    assert ws(4, 3, 64, 64, 64, 400) > ws(4, 3, 64, 64, 64, 200)
+    assert ws(4, 3, 7, 10, 13, 10) == -1            # ragged rows
+    assert ws(4, 3, 512, 512, 512, 10) == -1        # more tiles than CUs
+    assert ws(4, 2, 64, 64, 64, 10) == -1           # ndim / extents mismatch
+    assert ws(2, 3, 64, 64, 64, 10) == -1 and ws(4, 3, 64, 64, 64, 0) == -1
+    # where one launch per run is expected to pay (tools/bench_persist.py)
+    assert ops.persist_pays((64, 64, 64), 200) and ops.persist_pays((32, 32, 32), 16)
+    assert not ops.persist_pays((256, 256), 50)     # 3.4 us launches win
+    assert ops.persist_pays((1024, 1024), 100)
+    assert not ops.persist_pays((64, 64, 64), 8)    # too few iterations
+    assert not ops.persist_pays((128, 128, 128), 100)   # K = 3 kernel's range
