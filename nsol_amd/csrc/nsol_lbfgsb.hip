@@ -158,23 +158,23 @@ __global__ __launch_bounds__(kBlock) void k_mdot(const T *__restrict__ x,
 
 // ---- one vector against several: result[k] = sum_free vecs[k] * v ------------
 // (v and the mask are read once instead of once per product)
-constexpr int kDotsMax = 12;
+constexpr int kDotsMax = 24;     // per launch (a 12-vector instantiation serves the short lists)
 
 template <typename T>
 struct DotsPtrs {
   const T *p[kDotsMax];
 };
 
-template <typename T, int VEC>
+template <typename T, int VEC, int NV>
 __global__ __launch_bounds__(kBlock) void k_mdots(DotsPtrs<T> P, int nvec,
                                                    const T *__restrict__ y,
                                                    const int8_t *iw, int64_t n,
                                                    double *ws) {
   typedef T V __attribute__((ext_vector_type(VEC)));
   typedef int8_t M __attribute__((ext_vector_type(VEC)));
-  double a[kDotsMax];
+  double a[NV];
 #pragma unroll
-  for (int k = 0; k < kDotsMax; ++k) a[k] = 0.0;
+  for (int k = 0; k < NV; ++k) a[k] = 0.0;
   const int64_t nv = n / VEC;
   GRID_STRIDE(j, nv) {
     V yv = reinterpret_cast<const V *>(y)[j];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_mdots(DotsPtrs<T> P, int nvec,
       for (int e = 0; e < VEC; ++e) yv[e] = m[e] <= 0 ? yv[e] : T(0);
     }
 #pragma unroll
-    for (int k = 0; k < kDotsMax; ++k) {
+    for (int k = 0; k < NV; ++k) {
       if (k < nvec) {
         const V xv = reinterpret_cast<const V *>(P.p[k])[j];
 #pragma unroll
@@ -193,10 +193,10 @@ __global__ __launch_bounds__(kBlock) void k_mdots(DotsPtrs<T> P, int nvec,
     }
   }
   // per-statistic block sums; layout ws[k * kRed + block] like block_partials
-  __shared__ double s[kDotsMax][kBlock / kWave];
+  __shared__ double s[NV][kBlock / kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
 #pragma unroll
-  for (int k = 0; k < kDotsMax; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const double v = wsum(a[k]);
     if (lane == 0) s[k][wv] = v;
   }
@@ -225,12 +225,17 @@ int mdots_impl(const T *const *vecs, int nvec, const T *y, const int8_t *iwhere,
     const int cnt = nvec - b < kDotsMax ? nvec - b : kDotsMax;
     DotsPtrs<T> P;
     for (int k = 0; k < kDotsMax; ++k) P.p[k] = k < cnt ? vecs[b + k] : nullptr;
-    if (vec)
-      hipLaunchKernelGGL((k_mdots<T, VW>), dim3(gr), dim3(kBlock), 0,
+    // (W'v with ten stored pairs is 20 vectors against one: one pass over v
+    // instead of two)
+    if (vec && cnt > 12)
+      hipLaunchKernelGGL((k_mdots<T, VW, kDotsMax>), dim3(gr), dim3(kBlock), 0,
+                         as_stream(stream), P, cnt, y, iwhere, n, ws);
+    else if (vec)
+      hipLaunchKernelGGL((k_mdots<T, VW, 12>), dim3(gr), dim3(kBlock), 0,
                          as_stream(stream), P, cnt, y, iwhere, n, ws);
     else
-      hipLaunchKernelGGL((k_mdots<T, 1>), dim3(gr), dim3(kBlock), 0, as_stream(stream),
-                         P, cnt, y, iwhere, n, ws);
+      hipLaunchKernelGGL((k_mdots<T, 1, kDotsMax>), dim3(gr), dim3(kBlock), 0,
+                         as_stream(stream), P, cnt, y, iwhere, n, ws);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, gr,
                        cnt, false, result + b);
   }

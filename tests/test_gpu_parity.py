@@ -106,7 +106,8 @@ def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
     ((20, 37, 64), 2.0, np.float64), ((9, 5, 16), 4.0, np.float64),
     ((33, 70, 132), 1.0, np.float32), ((64, 64, 64), 4.0, np.float32),
     ((40, 48, 512), 4.0, np.float32), ((130, 66, 72), 4.0, np.float32),
-    ((7, 100, 24), 0.5, np.float64), ((16, 16, 16), 7.0, np.float32)])
+    ((7, 100, 24), 0.5, np.float64), ((16, 16, 16), 7.0, np.float32),
+    ((16, 24, 16), 7.0, np.float64)])
 def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
     """nsol_corr3_wrap_axpby_* (io = ca * A x + cb * io formed by the blur itself,
     with the sum of squares of the result: the top block of LSMR's u update,
@@ -125,6 +126,11 @@ def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
     ref = ops.lincomb2(ca, A(x.view(shape)).view(-1), cb, io0)
     io = io0.clone()
     got2 = A.apply_axpby(x, io, shape, ca, cb)
+    if dtype == np.float64 and sigma2 == 7.0:
+        # 17 taps in float64: no LDS left for the io tiles -- the caller combines
+        # in a second step (and io is untouched)
+        assert got2 is None and torch.equal(io, io0)
+        return
     assert got2 is not None, "the epilogue kernel did not run"
     tol = 1e-13 if dtype == np.float64 else 2e-6
     d = ops.norm2(ops.lincomb2(1.0, io, -1.0, ref)) / ops.norm2(ref)
