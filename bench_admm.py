@@ -132,6 +132,9 @@ def main():
                     help="scale and norm passes over LSMR's lower right-hand side "
                          "per ADMM iteration instead of taking both from the outer "
                          "step (A/B runs)")
+    ap.add_argument("--lb-capacity", type=int, default=0,
+                    help="breakpoints per window of the L-BFGS-B Cauchy search "
+                         "(0 = the backend's default; A/B runs)")
     ap.add_argument("--param", action="append", default=[],
                     help="library knob name=value (A/B runs, e.g. "
                          "corr_blur3_dma=0 for the register-window blur)")
@@ -151,6 +154,9 @@ def main():
         LO.USE_BLUR_EPILOGUE = False
     if args.no_prescaled_rhs:
         admm.USE_PRESCALED_RHS = False
+    if args.lb_capacity:
+        from nsol_amd.lbfgsb_device import DeviceBackend
+        DeviceBackend.CAPACITY = args.lb_capacity
     for kv in args.param:
         k, v = kv.split("=")
         _lib.set_param(k, int(v))
