@@ -575,6 +575,26 @@ int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iw
                             int64_t n, double *result, double *ws, void *stream);
 int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream);
+/* The same pass also forming the reduced gradient of the subspace step
+ * (scipy's cmprlb behind tikhonov_linear_solver.py:214-220):
+ *   r_out = free ? bcoef3[0]*base3[0] + bcoef3[1]*base3[1] + bcoef3[2]*base3[2]
+ *                  + sum_k wcoef[k]*vecs[k] : 0
+ * -- nsol_lb_wcomb_*'s sum, term for term in the same order, without a pass of
+ * its own over the nvec vectors.  base3 / bcoef3 / wcoef: HOST arrays (three
+ * device pointers, three and nvec doubles).  Returns -2 (nothing launched) where
+ * the LDS-DMA staged kernel does not apply (n not a multiple of 16, unaligned
+ * arrays, no room for the three extra rows): call nsol_lb_masked_gram_* and
+ * nsol_lb_wcomb_* then. */
+int nsol_lb_masked_gram_rgrad_f32(const float *const *vecs, int nvec,
+                                  const int8_t *iwhere, int64_t n, double *result,
+                                  double *ws, const float *const *base3,
+                                  const double *bcoef3, const double *wcoef,
+                                  float *r_out, void *stream);
+int nsol_lb_masked_gram_rgrad_f64(const double *const *vecs, int nvec,
+                                  const int8_t *iwhere, int64_t n, double *result,
+                                  double *ws, const double *const *base3,
+                                  const double *bcoef3, const double *wcoef,
+                                  double *r_out, void *stream);
 int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
                        double *ws, void *stream);
 int nsol_lb_projgr_f32(const float *x, const float *g, int64_t n, double lo, double hi,

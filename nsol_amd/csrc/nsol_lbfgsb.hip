@@ -467,9 +467,24 @@ constexpr int kGram2Bufs = 3;
 constexpr int kGram2MaxVec = 24;                 // 6 x 6 blocks -> 21 block pairs
 constexpr int kGram2Ent = 21 * kGram2B * kGram2B;
 
-template <typename T, int TB>
+// RG: the same pass also forms the reduced gradient of the subspace step,
+//   r = free ? b0 * base0 + b1 * base1 + b2 * base2 + sum_k wc[k] * vec_k : 0
+// (scipy's cmprlb: -theta (xcp - x) - g + W M c; what k_wcomb computes from a pass
+// of its own over the same 2c vectors, term for term in the same order): the three
+// base vectors are staged like three more rows of the tile, and the first lanes
+// combine the tile's rows once they have landed.
+template <typename T>
+struct GramRG {
+  const T *base[3];
+  T bcoef[3];
+  T wcoef[kGram2MaxVec];
+  T *out;
+};
+
+template <typename T, int TB, bool RG = false>
 __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
-    GramPtrs<T> P, int nvec, const int8_t *iw, int64_t n, int nb, int splits, double *ws) {
+    GramPtrs<T> P, int nvec, const int8_t *iw, int64_t n, int nb, int splits, double *ws,
+    GramRG<T> R = GramRG<T>()) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gram_raw[];
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int kTile = TB / (int)sizeof(T);                   // voxels per tile
@@ -480,7 +495,9 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
   constexpr int kMaskPieces = (kMaskBytes + 1023) / 1024;
   typedef T V __attribute__((ext_vector_type(VEC)));
   const int rows = nb * kGram2B;
-  const int buf_bytes = rows * kPitch + ((kMaskBytes + 15) & ~15);
+  constexpr int kExtra = RG ? 3 : 0;                           // base vectors of r
+  const int buf_bytes = (rows + kExtra) * kPitch + ((kMaskBytes + 15) & ~15);
+  const int mask_at = (rows + kExtra) * kPitch;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -507,27 +524,30 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
   const int64_t ntiles = (n + kTile - 1) / kTile;
   // pieces of one tile: vector v, part h (1 KiB each), then the mask; piece k
   // belongs to wave k % kGram2Waves
-  const int npieces = kRowPieces * nvec + (iw ? kMaskPieces : 0);
+  const int nsrc = nvec + kExtra;                             // staged vectors
+  const int npieces = kRowPieces * nsrc + (iw ? kMaskPieces : 0);
   const int my_pieces = (npieces - wave + kGram2Waves - 1) / kGram2Waves;   // wave-uniform
   auto stage = [&](int64_t t, int b) {
     const int64_t base = t * kTile;
     unsigned char *dst = gram_raw + b * buf_bytes;
     for (int k = wave; k < npieces; k += kGram2Waves) {
-      if (k < kRowPieces * nvec) {
+      if (k < kRowPieces * nsrc) {
         const int v = k / kRowPieces, h = k - v * kRowPieces;
         const int64_t e = base + (int64_t)h * (1024 / (int)sizeof(T)) + (int64_t)lane * VEC;
+        const T *src = v < nvec ? P.p[v] : R.base[v < nvec ? 0 : v - nvec];
+        const int lrow = v < nvec ? v : rows + (v - nvec);
         if (e < n)                                       // n % VEC == 0 (host check)
           __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void *)(P.p[v] + e),
-              (__attribute__((address_space(3))) void *)(dst + v * kPitch + h * 1024),
+              (const __attribute__((address_space(1))) void *)(src + e),
+              (__attribute__((address_space(3))) void *)(dst + lrow * kPitch + h * 1024),
               16, 0, 0);
       } else {
-        const int h = k - kRowPieces * nvec;
+        const int h = k - kRowPieces * nsrc;
         const int64_t e = base + (int64_t)h * 1024 + (int64_t)lane * 16;
         if (h * 1024 + lane * 16 < kMaskBytes && e < n)   // n % 16 == 0 with a mask
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void *)(iw + e),
-              (__attribute__((address_space(3))) void *)(dst + rows * kPitch + h * 1024),
+              (__attribute__((address_space(3))) void *)(dst + mask_at + h * 1024),
               16, 0, 0);
       }
     }
@@ -542,6 +562,7 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
       case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
   };
@@ -557,11 +578,35 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
     const int64_t t2 = t + 2 * step;
     int nxt2 = cur + 2; if (nxt2 >= kGram2Bufs) nxt2 -= kGram2Bufs;
     if (t2 < ntiles) stage(t2, nxt2);
+    bool stored = false;                               // (wave-uniform below)
+    if constexpr (RG) {
+      // the first lanes: one 16-byte group of r each (k_wcomb's sum, same order)
+      const int64_t base = t * kTile;
+      const int64_t left = (n - base) / VEC;            // groups of this tile in range
+      const int quads_here = left < kQuads ? (int)left : kQuads;
+      stored = wave * kWave < quads_here;
+      for (int e = tid; e < quads_here; e += kGram2Threads) {
+        const unsigned char *bufp = gram_raw + cur * buf_bytes;
+        V accv = V(T(0));
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          accv += R.bcoef[k] * *reinterpret_cast<const V *>(bufp + (rows + k) * kPitch + e * 16);
+        for (int k = 0; k < nvec; ++k)
+          accv += R.wcoef[k] * *reinterpret_cast<const V *>(bufp + k * kPitch + e * 16);
+        if (iw) {
+          const unsigned char *mk = bufp + mask_at;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k)
+            if ((int8_t)mk[e * VEC + k] > 0) accv[k] = T(0);
+        }
+        *reinterpret_cast<V *>(R.out + base + (int64_t)e * VEC) = accv;
+      }
+    }
     if (worker) {
       const unsigned char *bufp = gram_raw + cur * buf_bytes;
       const unsigned char *a = bufp + (bi * kGram2B) * kPitch;
       const unsigned char *bb = bufp + (bj * kGram2B) * kPitch;
-      const unsigned char *mk = bufp + rows * kPitch;
+      const unsigned char *mk = bufp + mask_at;
       const int64_t base = t * kTile;
       for (int e = q; e < kQuads; e += splits) {
         if (base + (int64_t)e * VEC >= n) break;
@@ -595,7 +640,8 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
     // tile t + step must have landed before the next step reads it; the pieces of
     // tile t + 2 step (issued above, the youngest operations of this wave) may stay
     // in flight when their number is known
-    sync_keep((t2 < ntiles && full(t2)) ? my_pieces : 0);
+    // (a wave that stored a piece of r has one more operation behind the pieces)
+    sync_keep((t2 < ntiles && full(t2)) ? my_pieces + (stored ? 1 : 0) : 0);
     if (++cur == kGram2Bufs) cur = 0;
   }
   // sum the splits of every block entry inside the workgroup (fixed order)
@@ -642,16 +688,18 @@ __global__ __launch_bounds__(kBlock) void k_gram2_final(const double *ws, int nb
 
 int g_gram_dma = 1;              // 1: k_masked_gram_dma where it applies; 0: k_masked_gram
 
-template <typename T, int TB>
+template <typename T, int TB, bool RG>
 int masked_gram_dma_launch_tb(const GramPtrs<T> &P, int nvec, const int8_t *iwhere,
-                              int64_t n, double *result, double *ws, hipStream_t st) {
+                              int64_t n, double *result, double *ws, hipStream_t st,
+                              const GramRG<T> &R) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int kTile = TB / (int)sizeof(T);
   const int nb = (nvec + kGram2B - 1) / kGram2B;
   const int nblk = nb * (nb + 1) / 2;
   int splits = 1;
   while (splits * 2 * nblk <= kGram2Threads && splits * 2 <= kTile / VEC) splits *= 2;
-  size_t lds = kGram2Bufs * ((size_t)nb * kGram2B * (TB + 16) + ((kTile + 15) & ~15));
+  size_t lds = kGram2Bufs * ((size_t)(nb * kGram2B + (RG ? 3 : 0)) * (TB + 16) +
+                             ((kTile + 15) & ~15));
   const size_t red = (size_t)kGram2Threads * kGram2B * kGram2B * sizeof(double);
   if (lds < red) lds = red;
   if (lds > 160 * 1024) return -2;
@@ -659,7 +707,7 @@ int masked_gram_dma_launch_tb(const GramPtrs<T> &P, int nvec, const int8_t *iwhe
   int64_t blocks = 256;                              // one 16-wave workgroup per CU
   if (blocks > kGramBlocks) blocks = kGramBlocks;
   if (blocks > ntiles) blocks = ntiles;
-  auto kern = k_masked_gram_dma<T, TB>;
+  auto kern = k_masked_gram_dma<T, TB, RG>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -667,26 +715,38 @@ int masked_gram_dma_launch_tb(const GramPtrs<T> &P, int nvec, const int8_t *iwhe
     if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGram2Threads), lds, st, P, nvec,
-                     iwhere, n, nb, splits, ws);
+                     iwhere, n, nb, splits, ws, R);
   hipLaunchKernelGGL(k_gram2_final, dim3(nvec * (nvec + 1) / 2), dim3(kBlock), 0, st, ws,
                      (int)blocks, nvec, nb, result);
   return launch_status();
 }
 
+// rg: also form the reduced gradient (GramRG); tile size by the rows to stage
 template <typename T>
 int masked_gram_dma_launch(const GramPtrs<T> &P, int nvec, const int8_t *iwhere, int64_t n,
-                           double *result, double *ws, hipStream_t st) {
+                           double *result, double *ws, hipStream_t st,
+                           const GramRG<T> *rg = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
   if (n % VEC != 0 || (iwhere && n % 16 != 0) || nvec > kGram2MaxVec) return -2;
-  const int rows = ((nvec + kGram2B - 1) / kGram2B) * kGram2B;
-  if (rows <= 4) return masked_gram_dma_launch_tb<T, 8192>(P, nvec, iwhere, n, result, ws, st);
-  if (rows <= 12) return masked_gram_dma_launch_tb<T, 4096>(P, nvec, iwhere, n, result, ws, st);
-  return masked_gram_dma_launch_tb<T, 2048>(P, nvec, iwhere, n, result, ws, st);
+  const int rows = ((nvec + kGram2B - 1) / kGram2B) * kGram2B + (rg ? 3 : 0);
+  if (rg) {
+    for (int k = 0; k < 3; ++k)
+      if (!rg->base[k] || ((uintptr_t)rg->base[k] & 15u)) return -2;
+    if (!rg->out || ((uintptr_t)rg->out & 15u)) return -2;
+    if (rows <= 6) return masked_gram_dma_launch_tb<T, 8192, true>(P, nvec, iwhere, n, result, ws, st, *rg);
+    if (rows <= 12) return masked_gram_dma_launch_tb<T, 4096, true>(P, nvec, iwhere, n, result, ws, st, *rg);
+    return masked_gram_dma_launch_tb<T, 2048, true>(P, nvec, iwhere, n, result, ws, st, *rg);
+  }
+  const GramRG<T> none = GramRG<T>();
+  if (rows <= 4) return masked_gram_dma_launch_tb<T, 8192, false>(P, nvec, iwhere, n, result, ws, st, none);
+  if (rows <= 12) return masked_gram_dma_launch_tb<T, 4096, false>(P, nvec, iwhere, n, result, ws, st, none);
+  return masked_gram_dma_launch_tb<T, 2048, false>(P, nvec, iwhere, n, result, ws, st, none);
 }
 
 template <typename T>
 int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
-                     double *result, double *ws, void *stream) {
+                     double *result, double *ws, void *stream,
+                     const GramRG<T> *rg = nullptr) {
   if (!vecs || nvec < 1 || nvec > kGramMaxVec || n < 1 || !result || !ws)
     return NSOL_EINVAL;
   if (iwhere && ((uintptr_t)iwhere & 15u)) return NSOL_EINVAL;
@@ -696,9 +756,11 @@ int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64
     if (v < nvec && (!vecs[v] || ((uintptr_t)vecs[v] & 15u))) return NSOL_EINVAL;
   }
   if (g_gram_dma) {
-    const int rc = masked_gram_dma_launch<T>(P, nvec, iwhere, n, result, ws, as_stream(stream));
+    const int rc = masked_gram_dma_launch<T>(P, nvec, iwhere, n, result, ws,
+                                             as_stream(stream), rg);
     if (rc != -2) return rc;
   }
+  if (rg) return -2;             // (only the LDS-DMA staged kernel forms r as well)
   const int nb = (nvec + kGramB - 1) / kGramB;
   const int nblk = nb * (nb + 1) / 2;               // <= 36 for nvec <= 24
   int splits = 1;
@@ -1111,6 +1173,39 @@ int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iw
 int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream) {
   return masked_gram_impl<double>(vecs, nvec, iwhere, n, result, ws, stream);
+}
+}
+
+namespace {
+template <typename T>
+int gram_rgrad(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
+               double *result, double *ws, const T *const *base3,
+               const double *bcoef3, const double *wcoef, T *r_out, void *stream) {
+  if (!base3 || !bcoef3 || !wcoef || !r_out || nvec > kGram2MaxVec) return NSOL_EINVAL;
+  GramRG<T> R;
+  for (int k = 0; k < 3; ++k) { R.base[k] = base3[k]; R.bcoef[k] = (T)bcoef3[k]; }
+  for (int k = 0; k < kGram2MaxVec; ++k) R.wcoef[k] = k < nvec ? (T)wcoef[k] : T(0);
+  R.out = r_out;
+  return masked_gram_impl<T>(vecs, nvec, iwhere, n, result, ws, stream, &R);
+}
+}  // namespace
+
+extern "C" {
+int nsol_lb_masked_gram_rgrad_f32(const float *const *vecs, int nvec,
+                                  const int8_t *iwhere, int64_t n, double *result,
+                                  double *ws, const float *const *base3,
+                                  const double *bcoef3, const double *wcoef,
+                                  float *r_out, void *stream) {
+  return gram_rgrad<float>(vecs, nvec, iwhere, n, result, ws, base3, bcoef3, wcoef, r_out,
+                           stream);
+}
+int nsol_lb_masked_gram_rgrad_f64(const double *const *vecs, int nvec,
+                                  const int8_t *iwhere, int64_t n, double *result,
+                                  double *ws, const double *const *base3,
+                                  const double *bcoef3, const double *wcoef,
+                                  double *r_out, void *stream) {
+  return gram_rgrad<double>(vecs, nvec, iwhere, n, result, ws, base3, bcoef3, wcoef, r_out,
+                            stream);
 }
 }
 

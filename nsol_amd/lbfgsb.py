@@ -368,20 +368,32 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 free = None
             else:
                 free = iwhere
-            yzzy, szzs, szzy = be.masked_grams(ws, wy, free)
+            # r = -Z'(B(xcp - x) + g): its coefficients depend on the compact
+            # matrices and the Cauchy point only, so a backend may form it in the
+            # pass that computes the subspace matrix
+            r = None
+            fused = None
+            if cnstnd or col == 0:
+                mc = cm.bmv(c_vec)
+                coef_y = mc[:col]
+                coef_s = theta * mc[col:]
+                if hasattr(be, "masked_grams_rgrad"):
+                    fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
+                                                  coef_s, coef_y)
+            if fused is not None:
+                yzzy, szzs, szzy, r = fused
+            else:
+                yzzy, szzs, szzy = be.masked_grams(ws, wy, free)
             fac = form_k(cm, yzzy, szzs, szzy)
             if fac is None:
                 ok = False
-            if ok:
-                # r = -Z'(B(xcp - x) + g)
+            if ok and r is None:
                 if not cnstnd and col > 0:
                     r = be.scale(g, -1.0)
                 else:
-                    mc = cm.bmv(c_vec)
-                    coef_y = mc[:col]
-                    coef_s = theta * mc[col:]
                     r = be.reduced_gradient(z, x, g, theta, ws, wy, coef_s,
                                             coef_y, free)
+            if ok:
                 z = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free)
             else:
                 # refresh the memory and restart the iteration

@@ -142,6 +142,40 @@ class DeviceBackend(object):
         ss = np.triu(h[1]) + np.triu(h[1], 1).T
         return yy, ss, h[2]
 
+    def masked_grams_rgrad(self, ws_list, wy_list, free, z, x, g, theta, coef_s,
+                           coef_y):
+        """masked_grams and reduced_gradient from ONE pass over the 2c vectors
+        (nsol_lb_masked_gram_rgrad_*); None where that kernel does not apply."""
+        import ctypes
+        c = len(ws_list)
+        vecs = list(wy_list) + list(ws_list)           # Y first, then S
+        like = vecs[0]
+        nv = 2 * c
+        if not self.USE_GRAM_KERNEL or nv > 24 or free is None:
+            return None
+        lib = _lib.load()
+        if self._gram_ws is None or self._gram_ws.device != like.device:
+            self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
+                                        dtype=torch.float64, device=like.device)
+        out = torch.empty(nv * (nv + 1) // 2, dtype=torch.float64, device=like.device)
+        r = torch.empty_like(like)
+        ptrs = (ctypes.c_void_p * nv)(*[v.data_ptr() for v in vecs])
+        base = (ctypes.c_void_p * 3)(z.data_ptr(), x.data_ptr(), g.data_ptr())
+        bco = np.array([-theta, theta, -1.0], dtype=np.float64)
+        wco = np.ascontiguousarray(list(coef_y) + list(coef_s), dtype=np.float64)
+        rc = _fn("masked_gram_rgrad", like)(
+            ptrs, nv, _p(free), like.numel(), _p(out), _p(self._gram_ws),
+            ctypes.cast(base, ctypes.c_void_p), bco.ctypes.data, wco.ctypes.data,
+            _p(r), stream_ptr())
+        if rc == -2:
+            return None
+        self._check(rc, "masked_gram_rgrad")
+        flat = out.cpu().numpy()
+        gm = np.zeros((nv, nv))
+        gm[np.triu_indices(nv)] = flat
+        gm = gm + np.triu(gm, 1).T
+        return gm[:c, :c], gm[c:, c:], gm[c:, :c], r
+
     def _masked_grams_one_pass(self, ws_list, wy_list, free):
         """All entries from ONE pass over the 2c vectors (nsol_lb_masked_gram_*)."""
         import ctypes

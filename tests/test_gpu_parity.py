@@ -1260,6 +1260,44 @@ def test_masked_gram_matches_masked_dots(nsol, dtype, c, n):
         / (np.abs(none[0]).max()) < 1e-12
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("c,n", [(1, 4096), (2, 70000), (3, 262144), (5, 300048),
+                                 (10, 300048), (7, 512 * 700 + 256), (10, 1 << 20)])
+def test_gram_pass_also_forms_the_reduced_gradient(nsol, dtype, c, n):
+    """nsol_lb_masked_gram_rgrad_*: the subspace matrix and scipy cmprlb's reduced
+    gradient from one pass over the 2c stored vectors -- the gradient bit for
+    bit what nsol_lb_wcomb_* computes from a pass of its own, the matrix as from
+    nsol_lb_masked_gram_*."""
+    import torch
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(7 * c + n)
+    mk = lambda: torch.randn(n, device="cuda", dtype=td, generator=gen)
+    ws = [mk() for _ in range(c)]
+    wy = [mk() for _ in range(c)]
+    z, x, g = mk(), mk(), mk()
+    free = (torch.rand(n, device="cuda", generator=gen) < 0.3).to(torch.int8) * 2 - \
+        (torch.rand(n, device="cuda", generator=gen) < 0.1).to(torch.int8)
+    coef_s = list(np.linspace(-0.7, 0.9, c))
+    coef_y = list(np.linspace(0.3, -1.1, c))
+    be = DeviceBackend()
+    grams = be.masked_grams(ws, wy, free)
+    r_ref = be.reduced_gradient(z, x, g, 0.83, ws, wy, coef_s, coef_y, free)
+    fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, 0.83, coef_s, coef_y)
+    assert fused is not None, "the fused kernel did not run"
+    for a, b in zip(fused[:3], grams):
+        assert np.abs(a - b).max() <= 1e-12 * (np.abs(b).max() + 1e-300)
+    assert torch.equal(fused[3], r_ref)
+    # lengths the LDS-DMA staged kernel does not take: the caller's two-step path
+    if n % 16 == 0:
+        m = n - 3
+        short = be.masked_grams_rgrad([w[:m].clone() for w in ws],
+                                      [w[:m].clone() for w in wy], free[:m].clone(),
+                                      z[:m].clone(), x[:m].clone(), g[:m].clone(),
+                                      0.83, coef_s, coef_y)
+        assert short is None
+
+
 def test_online_tuner_settles_and_stays_bit_identical(nsol):
     """256^3 is large enough for the online footprint tuner: a 240-iteration run
     explores (every launch a different candidate), settles, and must not differ
