@@ -1116,6 +1116,18 @@ inline T cast_bound(double b) {
   return (T)b;
 }
 
+template <typename T>
+int gram_rgrad(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
+               double *result, double *ws, const T *const *base3,
+               const double *bcoef3, const double *wcoef, T *r_out, void *stream) {
+  if (!base3 || !bcoef3 || !wcoef || !r_out || nvec > kGram2MaxVec) return NSOL_EINVAL;
+  GramRG<T> R;
+  for (int k = 0; k < 3; ++k) { R.base[k] = base3[k]; R.bcoef[k] = (T)bcoef3[k]; }
+  for (int k = 0; k < kGram2MaxVec; ++k) R.wcoef[k] = k < nvec ? (T)wcoef[k] : T(0);
+  R.out = r_out;
+  return masked_gram_impl<T>(vecs, nvec, iwhere, n, result, ws, stream, &R);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1175,20 +1187,6 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
   return masked_gram_impl<double>(vecs, nvec, iwhere, n, result, ws, stream);
 }
 }
-
-namespace {
-template <typename T>
-int gram_rgrad(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
-               double *result, double *ws, const T *const *base3,
-               const double *bcoef3, const double *wcoef, T *r_out, void *stream) {
-  if (!base3 || !bcoef3 || !wcoef || !r_out || nvec > kGram2MaxVec) return NSOL_EINVAL;
-  GramRG<T> R;
-  for (int k = 0; k < 3; ++k) { R.base[k] = base3[k]; R.bcoef[k] = (T)bcoef3[k]; }
-  for (int k = 0; k < kGram2MaxVec; ++k) R.wcoef[k] = k < nvec ? (T)wcoef[k] : T(0);
-  R.out = r_out;
-  return masked_gram_impl<T>(vecs, nvec, iwhere, n, result, ws, stream, &R);
-}
-}  // namespace
 
 extern "C" {
 int nsol_lb_masked_gram_rgrad_f32(const float *const *vecs, int nvec,
