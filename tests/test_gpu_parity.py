@@ -1872,3 +1872,60 @@ def test_device_lbfgsb_vs_scipy_driver_at_64_cubed(nsol):
         finally:
             tk.USE_DEVICE_LBFGSB = True
     assert rel_l2(outs[0], outs[1]) < 1e-8
+
+
+_RCCL_WORKER = '''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+import nsol_amd.primal_dual_solver as pd
+from nsol_amd.linear_operators import LinearOperators3D
+from nsol_amd.proximal_operators import ProximalOperators as prox
+from nsol_amd.batch import solve_batch
+from nsol_amd.synthetic import synth_volume
+shape = (24, 20, 32)
+grad, grad_adj = LinearOperators3D().get_gradient_operators()
+D = lambda x: grad(x.reshape(*shape)).flatten()
+Da = lambda x: grad_adj(x.reshape(72, 20, 32)).flatten()
+def solve_one(i):
+    b = np.ascontiguousarray(synth_volume(32, i, "sp")[:24, :20, :]).reshape(-1)
+    xs = float(b.max())
+    pf = lambda x, tau: prox.prox_ell1_denoising(x, tau, x0=b, x_scale=xs)
+    s = pd.PrimalDualSolver(prox_f=pf, prox_g_conj=prox.prox_tv_conj, B=D,
+                            B_conj=Da, L2=16, x0=b, alpha=1.2, iterations=25,
+                            x_scale=xs, alg_type="ALG2", dtype=np.float32)
+    s.run()
+    assert s.get_execution() == "fused"
+    return s.get_x_device()
+ref = [solve_one(i).clone() for i in range(3)]
+out = solve_batch(solve_one, 3)
+assert dist.get_backend() == "nccl"
+assert len(out) == 3 and all(o.is_cuda for o in out)
+assert all(torch.equal(a, b) for a, b in zip(out, ref))
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_solve_batch_gathers_over_rccl(nsol, tmp_path):
+    """The gather of solve_batch on the backend the multi-GPU bench uses ("nccl" =
+    RCCL): one rank is all a one-GPU box allows, but it is the same
+    all_gather_object + gather sequence on device tensors the N-rank run issues
+    (the N > 1 leg is covered with gloo in test_host_logic.py)."""
+    import subprocess
+    import sys
+    import os
+    from conftest import ROOT
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(33500 + os.getpid() % 2000),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(script)], env=env, timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "RCCL_OK" in out, out[-3000:]
