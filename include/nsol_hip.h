@@ -119,10 +119,12 @@ int nsol_corr_axis_f64(const double *x, double *out, int axis, int64_t nz,
  * Gaussian blur A = A^T of linear_operators.py:82-86 on a volume, 8 bytes per
  * voxel instead of 24 for three nsol_corr_axis_* passes.  taps_* are HOST arrays
  * of `ntaps` doubles (odd, centre in the middle, the same count on every axis).
- * Passes run x, y, z.  Returns -2 (nothing launched) when the kernel does not
- * apply (even tap counts or more than 17, nx not a multiple of 16 bytes,
- * unaligned pointers, planes of more than 3 GiB): use the per-axis passes
- * then. */
+ * Passes run x, y, z.  Rows need not be whole 16-byte vectors and x / out need
+ * only be element-aligned (symmetric taps and rows of at least 16 + 2 * ceil(
+ * (ntaps / 2) / VEC) vectors of VEC = 16 / sizeof(T) elements; other ragged or
+ * off-grid cases take a slower kernel or -2).  Returns -2 (nothing launched)
+ * when no one-pass kernel applies (even tap counts or more than 17, short ragged
+ * rows, planes of more than 3 GiB): use the per-axis passes then. */
 int nsol_corr3_wrap_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const double *taps_z, const double *taps_y,
                         const double *taps_x, int ntaps, void *stream);
@@ -135,8 +137,8 @@ int nsol_corr3_wrap_f64(const double *x, double *out, int64_t nz, int64_t ny,
  * of squares of the new io (double), without A x going to memory.  ws: device
  * scratch of ws_doubles doubles (one per tile; nsol_hip_reduce_ws_doubles()
  * suffices up to 2048^3).  Returns -2 (nothing launched) where the LDS-DMA staged
- * kernel does not apply: rows that are not whole 16-byte vectors, asymmetric
- * taps, even / > 17 taps, unaligned arrays. */
+ * kernel does not apply: asymmetric taps, even / > 17 taps, ragged rows shorter
+ * than the bound above, 17 taps in double (no LDS left for the io tiles). */
 int nsol_corr3_wrap_axpby_f32(const float *x, float *io, int64_t nz, int64_t ny,
                               int64_t nx, const double *taps_z, const double *taps_y,
                               const double *taps_x, int ntaps, double ca, double cb,

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(CSRC, "libnsol_hip.so")
-SOURCES = ["nsol_conv.hip", "nsol_ops.hip", "nsol_pd.hip", "nsol_pd2.hip", "nsol_pdk.hip", "nsol_pdp.hip",
+SOURCES = ["nsol_blur3_f32.hip", "nsol_blur3_f64.hip", "nsol_conv.hip", "nsol_ops.hip", "nsol_pd.hip", "nsol_pd2.hip", "nsol_pdk.hip", "nsol_pdp.hip",
            "nsol_lsmr.hip", "nsol_lbfgsb.hip", "nsol_sort.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fPIC", "-shared"]
@@ -38,7 +38,7 @@ def build_library(force=False, verbose=False, jobs=None):
     from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     compile_flags = [f for f in FLAGS if f != "-shared"]
-    jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) // 2))
+    jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) - 2))
     tmp = tempfile.mkdtemp(prefix="nsol_build_")
     try:
         def one(src):

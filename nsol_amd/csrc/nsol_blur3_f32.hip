@@ -1,0 +1,13 @@
+// k_blur3_dma<float, ...>: see nsol_blur3_dma.hpp
+#define NSOL_BLUR3_DMA_IMPL
+#include "nsol_blur3_dma.hpp"
+
+namespace nsol_blur3 {
+int blur3_dma_run(const float *x, float *out, int64_t nz, int64_t ny, int64_t nx,
+                  const Taps<float> &tz, const Taps<float> &ty, const Taps<float> &tx, int ntaps,
+                  bool epi, double ca, double cb, double *result, double *part,
+                  int64_t part_doubles, hipStream_t st) {
+  return blur3_dma_dispatch<float>(x, out, nz, ny, nx, tz, ty, tx, ntaps, epi, ca, cb, result,
+                                part, part_doubles, st);
+}
+}  // namespace nsol_blur3

@@ -6,17 +6,13 @@
 #include <type_traits>
 
 #include "nsol_common.hpp"
+#include "nsol_blur3_dma.hpp"
 
 using namespace nsol;
+using namespace nsol_blur3;
 
 namespace {
 
-constexpr int kMaxTaps = 129;
-
-template <typename T>
-struct Taps {
-  T w[kMaxTaps];
-};
 
 // index of the sample that position i (possibly outside [0,n)) refers to under
 // `mode`; -1 means "zero" (constant mode).
@@ -126,10 +122,6 @@ __global__ __launch_bounds__(kBlock) void k_corr_dense(
 //     aligned vectors that cover [x-R, x+VEC-1+R]; neighbouring lanes read the
 //     same lines, so all but ~1/(2*ceil(R/VEC)+1) of the loads are L1 hits.
 // ---------------------------------------------------------------------------
-template <typename T, int V>
-struct VecOf {
-  typedef T type __attribute__((ext_vector_type(V)));
-};
 
 __device__ __forceinline__ int64_t wrap_once(int64_t j, int64_t n) {
   // valid for -n <= j < 2n
@@ -212,9 +204,9 @@ __global__ __launch_bounds__(kBlock) void k_corr_x_wrap(
   }
 }
 
-int g_blur3_zchunk = 0; // planes per z chunk of the one-pass blur; 0 = by the round model
+// (nsol_blur3_zchunk -- planes per z chunk of the one-pass blur, 0 = by the round model --
+// and nsol_blur3_dma_rag are shared with nsol_blur3_f*.hip: defined below the namespace)
 int g_blur3_lxb = 16;   // lanes per row of the one-pass blur's tile (experiment knob)
-int g_blur3_nw = 16;    // waves per workgroup of the LDS-DMA staged kernel (16 or 8)
 int g_blur3_dma = 1;    // 1: LDS-DMA staged kernel for 16-byte rows; 0: k_blur3_wrap(_pp)
 int g_corr_ra = 8;   // outputs per lane along a strided axis (experiment knob)
 int g_corr_xv = 1;   // output vectors per lane in the x pass (experiment knob)
@@ -318,10 +310,7 @@ int try_launch_wrap(const T *x, T *out, int axis, int64_t nz, int64_t ny,
 // Raw buffer addressing for the one-pass blur: a 32-bit byte offset per lane
 // plus a scalar plane offset; a lane whose offset is kNoLane is out of range of
 // every buffer, so its load returns 0 without touching memory.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-constexpr uint32_t kNoLane = 0xC0000000u;
+// (rsrc_t, u32x4, u32x2, kNoLane: nsol_blur3_dma.hpp)
 constexpr uint64_t kBlur3MaxBytes = 0xC0000000ull;
 
 // The x window of one lane: NB aligned vectors around its own one.  With 4-wide
@@ -681,475 +670,6 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
   }
 }
 
-// ---------------------------------------------------------------------------
-// The one-pass blur with the input staged by LDS-DMA (k_blur3_dma).
-//
-// k_blur3_wrap_pp above is bound by two things its structure cannot fix: the x
-// pass pulls five overlapping vectors per output vector through the L1, with the
-// whole workgroup waiting out the HBM latency of every plane (no registers left
-// for a prefetch: the z window holds 48), and its multiply / add pairs keep the
-// SIMDs busy for 0.26 ms at 512^3 (276 vector instructions per wave and plane).
-// Here
-//   * the raw tile of plane s + 3 (rows and columns including the halo, periodic
-//     wrap applied to the per-lane SOURCE address) travels global -> LDS with
-//     global_load_lds_dwordx4 while plane s + 1 is filtered along x and plane s
-//     along y and z: the loads cost no registers, are issued two phases before
-//     their tile has to be complete (three raw tiles rotate; a counted
-//     s_waitcnt vmcnt(N) leaves the newest one in flight across the barrier) and
-//     every input byte crosses the L1 once;
-//   * one barrier per plane: a phase runs the x pass of plane s + 1 (raw tile ->
-//     x-filtered tile, both in LDS) and the y / z passes of plane s; the output of
-//     plane s is stored at the START of the next phase, ahead of that phase's DMA;
-//   * taps are applied with fused multiply-adds (v_pk_fma_f32 / v_fma_f64: half
-//     the vector instructions; the blur is held to the reference by tolerance --
-//     a separable evaluation of its dense kernel differs by rounding anyway);
-//     (symmetric taps only -- every Gaussian; others take k_blur3_wrap_pp);
-//   * tiles are dealt so that every XCD works on a run of consecutive tiles
-//     (x fastest, then y): the halo columns and rows neighbouring tiles share are
-//     then hits in that XCD's L2 instead of second trips to HBM.
-// LDS per workgroup at 16 lanes per row, 13 taps, float: 3 raw tiles of 24 KiB +
-// 2 x-filtered tiles of 19 KiB = 110 KiB.
-// ---------------------------------------------------------------------------
-template <typename V, typename T>
-__device__ __forceinline__ V splat(T w) {
-  V r;
-#pragma unroll
-  for (int k = 0; k < (int)(sizeof(V) / sizeof(T)); ++k) r[k] = w;
-  return r;
-}
-
-__device__ __forceinline__ float fma1(float a, float b, float c) {
-  return __builtin_fmaf(a, b, c);
-}
-__device__ __forceinline__ double fma1(double a, double b, double c) {
-  return __builtin_fma(a, b, c);
-}
-
-constexpr int kDmaLxb = 16;
-
-// phases U .. M-1 of one trip through the loop body (each with its position in the
-// ring as a compile-time constant); stops at the end of the z chunk
-template <int U, int M, typename F>
-__device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
-  if constexpr (U < M) {
-    if (st0 + U < nsteps) {
-      f(st0 + U, std::integral_constant<int, U>());
-      blur3_phases<U + 1, M>(st0, nsteps, f);
-    }
-  }
-}
-
-// ISO: the three axes share one set of taps (an isotropic Gaussian on unit or
-// isotropic spacing -- BASELINE config 4): 14 fewer live scalars at 13 taps.
-// EPI: instead of storing A x the kernel forms io = ca * (A x) + cb * io in place and
-// the sum of squares of the result (per workgroup, in double: part[tile]) -- the top
-// block of LSMR's u update, `u_top = c * A v + c' * u_top` and its norm
-// (tikhonov_linear_solver.py:226-274 on SciPy's lsmr.py:320-336), without A v ever
-// going to memory.  The old io tile of the next output plane is staged by LDS-DMA
-// one phase ahead, issued BEFORE that phase's raw-tile pieces: the counted wait at
-// the end of the phase leaves only younger operations in flight, so it has landed.
-template <typename T, int VEC, int NT, int NW, bool ISO, bool EPI = false>
-__global__ __launch_bounds__(NW * 64) void k_blur3_dma(
-    const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
-    Taps<T> tz_, Taps<T> ty_, Taps<T> tx, int ntx, int nty, int nzc, int zchunk,
-    int per_xcd, T ca = T(1), T cb = T(0), double *__restrict__ part = nullptr) {
-  const Taps<T> &tz = ISO ? tx : tz_;
-  const Taps<T> &ty = ISO ? tx : ty_;
-  typedef typename VecOf<T, VEC>::type V;
-  constexpr int lxb = kDmaLxb;                 // lanes per tile row (compile time: the
-                                               // LDS strides fold into the addresses)
-  constexpr int R = NT / 2;
-  constexpr int NBH = (R + VEC - 1) / VEC;     // halo vectors on each side of a row
-  constexpr int NB = 2 * NBH + 1;
-  constexpr int NTHR = NW * 64;
-  constexpr int MAXP = 3;                      // LDS-DMA pieces per wave and plane
-  // the taps are symmetric (checked on the host): tap t is read as w[min(t, NT-1-t)],
-  // which leaves 3 * (R + 1) scalars live instead of 3 * NT (39 of them at 13 taps
-  // overflow the scalar registers and come back as a v_readlane per use)
-  auto sym = [](int t) { return t <= R ? t : NT - 1 - t; };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // every XCD (block id mod 8) takes a run of per_xcd consecutive tiles
-  const int total = ntx * nty * nzc;
-  const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (logical >= total) return;
-  const int bx = logical % ntx;
-  const int by = (logical / ntx) % nty;
-  const int bz = logical / (ntx * nty);
-
-  constexpr int tyr = NTHR / lxb;              // rows of the tile = rows of lanes
-  constexpr int frows = tyr + 2 * R;           // rows of the raw / x-filtered tile
-  constexpr int rl = lxb + 2 * NBH;            // vectors per raw row
-  constexpr int raw_vecs = frows * rl;
-  constexpr int npieces = (raw_vecs + 63) >> 6;  // 1 KiB per wave-instruction
-  constexpr int raw_stride = npieces * 64;     // vectors per raw buffer
-  constexpr int xf_stride = frows * lxb;
-  static_assert(npieces <= MAXP * NW, "raw tile needs more LDS-DMA pieces per wave");
-  static_assert(2 * R <= tyr, "halo rows must fit one round of lanes");
-  V *raw = reinterpret_cast<V *>(smem_raw);    // three raw tiles, then two x-filtered
-  V *xf = raw + 3 * (size_t)raw_stride;
-  constexpr int tile_vecs = tyr * lxb;         // (EPI) two tiles of the old io values
-  V *obuf = xf + 2 * (size_t)xf_stride;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Lane -> (row, lx).  A wave covers 4 rows x 16 lanes, and a ds_read_b128 is
-  // served in four groups of 16 lanes, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
-  // the same + 32 (MI355X_MICROARCH.md, LDS): the map puts every group on ONE row,
-  // so its 16 lanes read 16 consecutive 16-byte slots -- conflict-free whatever the
-  // row stride (20 slots in the raw tile).  With the plain map (row = lane / 16) half
-  // of each group sat a row further and a fifth of the LDS cycles were conflicts.
-  const int lx = lane & 15;
-  const int quad = (lane >> 2) & 3;
-  const int rsel = ((quad == 1 || quad == 2) ? 1 : 0) ^ ((lane >> 4) & 1);
-  const int row = (tid >> 6) * 4 + ((lane >> 5) & 1) * 2 + rsel;
-  const int nxv = (int)(nx / VEC);
-  const int xv = bx * lxb + lx;
-  const int64_t y0 = (int64_t)by * tyr;
-  const bool owner = xv < nxv && (y0 + row < ny);
-  const int64_t plane = ny * nx;
-
-  // LDS-DMA source offsets (elements inside a plane) of this lane's pieces:
-  // piece k = wave + j * NW covers the raw vectors [64 k, 64 k + 64)
-  uint32_t src_off[MAXP];
-#pragma unroll
-  for (int j = 0; j < MAXP; ++j) {
-    // (lanes past the end of the raw tile re-load its first vector into the
-    // padding behind it: no predicate to carry through the loop)
-    int i = (wave + j * NW) * 64 + lane;
-    if (i >= raw_vecs) i = 0;
-    const int rr = i / rl;
-    const int cc = i - rr * rl;
-    int64_t yy = (y0 - R + rr) % ny;
-    if (yy < 0) yy += ny;
-    int xx = (bx * lxb - NBH + cc) % nxv;
-    if (xx < 0) xx += nxv;
-    src_off[j] = (uint32_t)(yy * nx + (int64_t)xx * VEC);
-  }
-  // pieces this wave issues per plane (wave-uniform)
-  const int my_pieces = (npieces - wave + NW - 1) / NW;
-  auto stage = [&](int64_t z, int rbuf) {      // plane z -> raw tile at vector offset rbuf
-    const T *pl = x + z * plane;
-#pragma unroll
-    for (int j = 0; j < MAXP; ++j) {
-      if (j * NW >= npieces) break;              // (compile time)
-      const int k = wave + j * NW;
-      if ((j + 1) * NW <= npieces || k < npieces)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(pl + src_off[j]),
-            (__attribute__((address_space(3))) void *)(raw + (size_t)rbuf + (size_t)k * 64),
-            16, 0, 0);
-    }
-  };
-  // End of a phase: the LDS writes of this phase are done (lgkmcnt) and at most
-  // `newer` of this wave's vector-memory operations are still in flight.  On gfx9
-  // vmcnt is decremented in issue order for loads and stores alike, so with
-  // `newer` = the number of operations issued after the pieces of the tile that has
-  // to be complete (<= MAXP pieces + 1 store), that tile has landed.  Then the barrier.
-  auto phase_end = [&](int newer) {                // (wave-uniform)
-    switch (newer) {
-      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
-  };
-  // x pass: raw tile -> x-filtered tile; a lane filters footprint row `row` and,
-  // in the first waves, the halo row `tyr + row`
-  const bool second = row < 2 * R;
-  const bool second_wave = __builtin_amdgcn_readfirstlane((int)second) != 0;
-  auto xrow = [&](const V *rb, V *xb, int fr) {
-    const V *w = rb + (size_t)fr * rl + lx;
-    constexpr int off = NBH * VEC - R;             // window index of output 0, tap 0
-    V res;
-    if constexpr (sizeof(T) == 4 && VEC == 4) {
-      // Packed form: every vector instruction costs one issue slot whether it handles
-      // one float or two, so the taps are applied to aligned PAIRS of the window.
-      // Taps t with off + t even see outputs (0,1) and (2,3) on aligned pairs; the
-      // others see them shifted by one element: they are summed on the pair grid
-      // (B[0..2]) and their halves added to the outputs at the end.  32 + 4
-      // instructions instead of 52 at 13 taps; the summation order differs from
-      // t = 0 .. NT-1 (rounding only).
-      typedef T P2 __attribute__((ext_vector_type(2)));
-      P2 P[NB * 2];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const V t = w[b];
-        P[2 * b] = P2{t[0], t[1]};
-        P[2 * b + 1] = P2{t[2], t[3]};
-      }
-      P2 A[2], B[3];
-      bool a_set = false, b_set = false;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const P2 wt = P2{tx.w[sym(t)], tx.w[sym(t)]};
-        if (((off + t) & 1) == 0) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const P2 src = P[(off + 2 * h + t) / 2];
-            A[h] = a_set ? __builtin_elementwise_fma(wt, src, A[h]) : wt * src;
-          }
-          a_set = true;
-        } else {
-          const int sidx = (off + t + 1) / 2;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const P2 src = P[sidx - 1 + a];
-            B[a] = b_set ? __builtin_elementwise_fma(wt, src, B[a]) : wt * src;
-          }
-          b_set = true;
-        }
-      }
-      if (!a_set) A[0] = A[1] = P2{T(0), T(0)};
-      if (!b_set) B[0] = B[1] = B[2] = P2{T(0), T(0)};
-      res[0] = A[0][0] + B[0][1];
-      res[1] = A[0][1] + B[1][0];
-      res[2] = A[1][0] + B[1][1];
-      res[3] = A[1][1] + B[2][0];
-    } else {
-      T win[NB * VEC];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const V t = w[b];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) win[b * VEC + k] = t[k];
-      }
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        T acc = tx.w[0] * win[off + k];
-#pragma unroll
-        for (int t = 1; t < NT; ++t) acc = fma1(tx.w[sym(t)], win[off + k + t], acc);
-        res[k] = acc;
-      }
-    }
-    xb[(size_t)fr * lxb + lx] = res;
-  };
-  auto xpass = [&](int rbuf, int xbuf) {
-    const V *rb = raw + (size_t)rbuf;
-    V *xb = xf + (size_t)xbuf * xf_stride;
-    xrow(rb, xb, row);
-    if (second_wave) {
-      if (second) xrow(rb, xb, row + tyr);
-    }
-  };
-
-  const int64_t zbeg = (int64_t)bz * zchunk;
-  int64_t zend = zbeg + zchunk;
-  if (zend > nz) zend = nz;
-  const int nsteps = (int)(zend - zbeg) + 2 * R;    // planes zbeg - R .. zend + R - 1
-  int zw = (int)((zbeg - R) % nz);                  // plane of the next stage()
-  if (zw < 0) zw += (int)nz;
-  auto next_plane = [&]() {
-    const int z = zw;
-    if (++zw == (int)nz) zw = 0;
-    return (int64_t)z;
-  };
-  V ring[NT - 1];                                   // xy-filtered planes, oldest first
-#pragma unroll
-  for (int t = 0; t + 1 < NT; ++t) ring[t] = splat<V, T>(T(0));
-  // output: one buffer descriptor per plane and a 32-bit offset inside it; lanes
-  // that own no voxel carry an out-of-range offset (the store is dropped by the
-  // hardware), so EVERY wave issues exactly one store per output plane -- the
-  // counted waits below depend on that
-  const uint32_t plane_bytes = (uint32_t)(plane * sizeof(T));
-  const uint32_t own_off =
-      owner ? (uint32_t)(((y0 + row) * nx + (int64_t)xv * VEC) * sizeof(T)) : kNoLane;
-  double sumsq = 0.0;
-  auto put = [&](int64_t z, V val, int ob) {
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + z * plane, 0, plane_bytes,
-                                                        0x00020000);
-    if constexpr (EPI) {
-      const V old = obuf[(size_t)ob * tile_vecs + (size_t)row * lxb + lx];
-      val = splat<V, T>(ca) * val + splat<V, T>(cb) * old;
-      if (owner) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) sumsq += (double)val[e] * (double)val[e];
-      }
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, own_off, 0, 0);
-    asm volatile("s_nop 1");   // see nsol_pdk.hip: store data vs. the next VALU write
-  };
-  // (EPI) the io tile of one output plane -> obuf[ob]: one 1-KiB piece per wave; lanes
-  // whose tile position lies outside the volume re-read a valid neighbour
-  uint32_t old_off = 0;
-  if constexpr (EPI) {
-    const int i = wave * 64 + lane;
-    int64_t yy = y0 + i / lxb;
-    if (yy >= ny) yy = ny - 1;
-    int xx = bx * lxb + i % lxb;
-    if (xx >= nxv) xx = nxv - 1;
-    old_off = (uint32_t)(yy * nx + (int64_t)xx * VEC);
-  }
-  auto stage_old = [&](int64_t z, int ob) {
-    if constexpr (EPI)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(out + z * plane + old_off),
-          (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
-                                                     (size_t)wave * 64),
-          16, 0, 0);
-  };
-
-  // prologue: planes 0, 1, 2 staged, plane 0 filtered along x  (nsteps >= 2R + 1 >= 3)
-  stage(next_plane(), 0);
-  stage(next_plane(), raw_stride);
-  stage(next_plane(), 2 * raw_stride);
-  phase_end(0);
-  xpass(0, 0);
-  phase_end(0);
-  // rotating vector offsets of the raw tiles: r_cur holds plane st (free: the target
-  // of this phase's DMA), r_next plane st + 1, r_after plane st + 2
-  int r_cur = 0, r_next = raw_stride, r_after = 2 * raw_stride;
-  // One phase = one plane and one barrier.  The loop body holds M = NT - 1 phases:
-  // the z window is a ring of M register vectors whose slot indices are then
-  // compile-time constants (no register moves: they were a third of the vector
-  // instructions), like the x-filtered buffer's index.
-  constexpr int M = NT - 1;
-  auto phase = [&](int st, auto U) {
-    constexpr int u = decltype(U)::value;           // = st mod M
-    constexpr int q = u & 1;                        // = st & 1 (M is even)
-    const bool more = st + 3 < nsteps;
-    if (EPI && st + 1 >= 2 * R && st + 1 < nsteps)
-      stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io of the next output plane
-    if (more) stage(next_plane(), r_cur);           // plane st + 3, two phases ahead
-    // (The x pass of plane st + 1 and the y / z passes of plane st are independent,
-    // but letting half of the waves of a SIMD run them in the opposite order, so that
-    // not everybody waits for the LDS at the same time, measured no faster.)
-    const bool storing = st >= 2 * R;
-    auto yz = [&]() {
-      const V *col = xf + (size_t)q * xf_stride + (size_t)row * lxb + lx;
-      V v = splat<V, T>(ty.w[0]) * col[0];
-#pragma unroll
-      for (int t = 1; t < NT; ++t)
-        v = __builtin_elementwise_fma(splat<V, T>(ty.w[sym(t)]), col[(size_t)t * lxb], v);
-      if (st >= 2 * R) {
-        // window of plane st: the ring from its oldest slot (u), then v
-        V acc = splat<V, T>(tz.w[0]) * ring[u];
-#pragma unroll
-        for (int t = 1; t < M; ++t)
-          acc = __builtin_elementwise_fma(splat<V, T>(tz.w[sym(t)]), ring[(u + t) % M], acc);
-        acc = __builtin_elementwise_fma(splat<V, T>(tz.w[0]), v, acc);
-        if (storing) put(zbeg + (st - 2 * R), acc, q);
-      }
-      ring[u] = v;                                  // replaces plane st - M
-    };
-    if (st + 1 < nsteps) xpass(r_next, q ^ 1);
-    yz();
-    const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
-    // plane st + 2 (staged in the previous phase) must have landed; younger than
-    // its pieces are this phase's pieces and this phase's store
-    phase_end((more ? my_pieces : 0) + (storing ? 1 : 0));
-  };
-#pragma unroll 1
-  for (int st0 = 0; st0 < nsteps; st0 += M) blur3_phases<0, M>(st0, nsteps, phase);
-  if constexpr (EPI) {
-    // (the last phase ended with a barrier: the LDS is free)
-    double *red = reinterpret_cast<double *>(smem_raw);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sumsq += __shfl_down(sumsq, o, 64);
-    if (lane == 0) red[wave] = sumsq;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w2 = 0; w2 < NW; ++w2) t += red[w2];
-      part[logical] = t;
-    }
-  }
-}
-
-// sum of the per-tile partials in a fixed order
-__global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, int n,
-                                                            double *result) {
-  __shared__ double s[kBlock];
-  double t = 0.0;
-  for (int i = threadIdx.x; i < n; i += kBlock) t += part[i];
-  s[threadIdx.x] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double r = 0.0;
-    for (int i = 0; i < kBlock; ++i) r += s[i];
-    *result = r;
-  }
-}
-
-inline int blur3_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-
-// LDS-DMA staged kernel: tiles of kDmaLxb lanes per row whatever the row length;
-// returns -2 when it does not apply.  EPI (out = io, in place): io = ca * blur(x) +
-// cb * io and *result = sum of squares of the new io (part: >= tiles doubles).
-template <typename T, int VEC, int NT, int NWD, bool EPI = false>
-int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
-                     const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
-                     hipStream_t st, double ca = 1.0, double cb = 0.0,
-                     double *result = nullptr, double *part = nullptr,
-                     int64_t part_doubles = 0) {
-  constexpr int R = NT / 2;
-  constexpr int NBH = (R + VEC - 1) / VEC;
-  constexpr int dl = kDmaLxb;
-  constexpr int dtyr = (NWD * 64) / dl;
-  constexpr int frows = dtyr + 2 * R;
-  constexpr int npieces = (frows * (dl + 2 * NBH) + 63) / 64;
-  constexpr size_t lds = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl +
-                          (EPI ? 2 * (size_t)dtyr * dl : 0)) * 16;
-  if constexpr (lds > 160 * 1024) {
-    static_assert(EPI, "LDS-DMA blur tile does not fit");
-    return -2;                                           // (no room for the io tiles)
-  } else {
-  if (dtyr < 2 * R) return -2;
-  const int64_t nxv = nx / VEC;
-  const int64_t dntx = (nxv + dl - 1) / dl, dnty = (ny + dtyr - 1) / dtyr;
-  if (ny * nx >= ((int64_t)1 << 31)) return -2;          // 32-bit offsets in a plane
-  // z chunks by the round model: `slots` workgroups run at a time, a launch takes
-  // ceil(workgroups / slots) rounds of (chunk + 2R) plane steps
-  const int per_cu = (int)((160 * 1024) / lds) < (32 / NWD) ? (int)((160 * 1024) / lds)
-                                                            : (32 / NWD);
-  const int64_t slots = (int64_t)blur3_cu_count() * (per_cu < 1 ? 1 : per_cu);
-  int64_t zchunk = nz, best = -1;
-  for (int64_t c = 1; c <= nz && (nz + c - 1) / c >= R; ++c) {
-    const int64_t len = (nz + c - 1) / c;
-    const int64_t chunks = (nz + len - 1) / len;
-    const int64_t rounds = (dntx * dnty * chunks + slots - 1) / slots;
-    const int64_t cost = rounds * (len + 2 * R);
-    if (best < 0 || cost < best) { best = cost; zchunk = len; }
-    if (dntx * dnty * chunks >= 64 * slots) break;
-  }
-  if (g_blur3_zchunk > 0) zchunk = g_blur3_zchunk < nz ? g_blur3_zchunk : nz;
-  const int64_t nzc = (nz + zchunk - 1) / zchunk;
-  const int64_t tiles = dntx * dnty * nzc;
-  if (tiles >= ((int64_t)1 << 28)) return -2;
-  if (EPI && tiles > part_doubles) return -2;
-  const int per_xcd = (int)((tiles + 7) / 8);
-  bool iso = true;
-  for (int t = 0; t < NT; ++t) iso = iso && tz.w[t] == tx.w[t] && ty.w[t] == tx.w[t];
-  auto kern = iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI>
-                  : k_blur3_dma<T, VEC, NT, NWD, false, EPI>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
-                     nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
-                     per_xcd, (T)ca, (T)cb, part);
-  if (EPI)
-    hipLaunchKernelGGL(k_blur3_epi_final, dim3(1), dim3(kBlock), 0, st, part, (int)tiles,
-                       result);
-  return launch_status();
-  }
-}
-
 // nsol_corr3_wrap_axpby_*: io = ca * A x + cb * io in place with the sum of squares
 // of the result; -2 when the LDS-DMA kernel does not apply (the caller then blurs
 // and combines in two steps)
@@ -1162,9 +682,9 @@ int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
       nz < 1 || ny < 1 || nx < 1 || ntaps < 1)
     return NSOL_EINVAL;
   constexpr int VEC = 16 / sizeof(T);
-  if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > 17 || nx % VEC != 0 || !g_blur3_dma ||
-      g_blur3_lxb != kDmaLxb || (reinterpret_cast<uintptr_t>(x) & 15u) ||
-      (reinterpret_cast<uintptr_t>(io) & 15u))
+  if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > 17 || !g_blur3_dma ||
+      g_blur3_lxb != kDmaLxb || ((reinterpret_cast<uintptr_t>(x) |
+                                  reinterpret_cast<uintptr_t>(io)) & (sizeof(T) - 1)))
     return -2;
   Taps<T> tz, ty, tx;
   bool symmetric = true;
@@ -1178,15 +698,8 @@ int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
                 ty.w[t] == ty.w[ntaps - 1 - t] && tx.w[t] == tx.w[ntaps - 1 - t];
   if (!symmetric) return -2;
   hipStream_t st = as_stream(stream);
-#define NSOL_B3E_CASE(N)                                                               \
-  case N: return launch_blur3_dma<T, VEC, N, 16, true>(x, io, nz, ny, nx, tz, ty, tx, st, \
-                                                        ca, cb, result, ws, ws_doubles);
-  switch (ntaps) {
-    NSOL_B3E_CASE(3) NSOL_B3E_CASE(5) NSOL_B3E_CASE(7) NSOL_B3E_CASE(9)
-    NSOL_B3E_CASE(11) NSOL_B3E_CASE(13) NSOL_B3E_CASE(15) NSOL_B3E_CASE(17)
-    default: return -2;
-  }
-#undef NSOL_B3E_CASE
+  return blur3_dma_run(x, io, nz, ny, nx, tz, ty, tx, ntaps, true, ca, cb, result, ws,
+                       ws_doubles, st);
 }
 
 template <typename T, int VEC, int NT>
@@ -1218,16 +731,17 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
     if (best < 0 || cost < best) { best = cost; zchunk = len; }
     if (ntx * nty * chunks >= 64 * cus) break;
   }
-  if (g_blur3_zchunk > 0) zchunk = g_blur3_zchunk < nz ? g_blur3_zchunk : nz;
+  if (nsol_blur3_zchunk > 0) zchunk = nsol_blur3_zchunk < nz ? nsol_blur3_zchunk : nz;
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t blocks = ntx * nty * nzc;
   if (blocks > 0x7fffffff) return -2;
-  if (g_blur3_dma && symmetric && nx % VEC == 0 && g_blur3_lxb == kDmaLxb) {
+  if (g_blur3_dma && symmetric && g_blur3_lxb == kDmaLxb) {
     int rc = -2;
-    if (g_blur3_nw == 8) rc = launch_blur3_dma<T, VEC, NT, 8>(x, out, nz, ny, nx, tz, ty, tx, st);
-    else rc = launch_blur3_dma<T, VEC, NT, 16>(x, out, nz, ny, nx, tz, ty, tx, st);
+    rc = blur3_dma_run(x, out, nz, ny, nx, tz, ty, tx, NT, false, 1.0, 0.0, nullptr, nullptr, 0,
+                       st);
     if (rc != -2) return rc;
   }
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) return -2;
   // two planes per step where the registers allow it
   constexpr int PP = (NT >= 5 && NT <= (sizeof(T) == 4 ? 13 : 11)) ? 2 : 1;
   // (ragged rows: one plane per step, the element-wise edge path needs the registers)
@@ -1268,7 +782,7 @@ int corr3_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   // (ragged rows: the element-wise wrap of the edge lanes corrects by one period)
   if ((ntaps & 1) == 0 || ntaps < 3 || ntaps > kMaxFused ||
       (nx % VEC != 0 && nx < 2 * ntaps + 2 * VEC) ||
-      (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & (sizeof(T) - 1)))
     return -2;
   Taps<T> tz, ty, tx;
   for (int t = 0; t < kMaxTaps; ++t) {
@@ -1329,14 +843,19 @@ int corr_dense_impl(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
 }  // namespace
 
 extern "C" {
+int nsol_blur3_zchunk = 0;
+int nsol_blur3_dma_rag = 1;   // LDS-DMA staged blur also for rows / operands off the 16-byte grid
+}
+
+extern "C" {
 int nsol_hip_set_param_conv(const char *name, int value) {
   if (!name) return NSOL_EINVAL;
   if (!strcmp(name, "corr_ra")) g_corr_ra = value;
   else if (!strcmp(name, "corr_xv")) g_corr_xv = value;
   else if (!strcmp(name, "corr_blur3_lxb")) g_blur3_lxb = value;
-  else if (!strcmp(name, "corr_blur3_zchunk")) g_blur3_zchunk = value;
+  else if (!strcmp(name, "corr_blur3_zchunk")) nsol_blur3_zchunk = value;
   else if (!strcmp(name, "corr_blur3_dma")) g_blur3_dma = value;
-  else if (!strcmp(name, "corr_blur3_nw")) g_blur3_nw = value;
+  else if (!strcmp(name, "corr_blur3_dma_rag")) nsol_blur3_dma_rag = value;
   else return NSOL_EINVAL;
   return 0;
 }

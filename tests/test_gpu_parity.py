@@ -78,7 +78,12 @@ def test_blur_matches_reference_goldens(nsol, golden):
     # rows that are not a multiple of 16 bytes (one and several tiles along x)
     ((20, 37, 63), 4.0, np.float32), ((24, 70, 131), 4.0, np.float32),
     ((33, 20, 517), 4.0, np.float32), ((18, 40, 65), 1.0, np.float64),
-    ((12, 30, 41), 2.0, np.float32)])
+    ((12, 30, 41), 2.0, np.float32),
+    # ... long enough for the LDS-DMA staged kernel's ragged form: every remainder,
+    # a last tile narrower than the halo, three tile rows, both types
+    ((20, 140, 81), 4.0, np.float32), ((10, 70, 130), 4.0, np.float32),
+    ((37, 66, 203), 2.0, np.float32), ((11, 33, 101), 4.0, np.float64),
+    ((9, 12, 193), 7.0, np.float32), ((14, 65, 45), 2.0, np.float64)])
 def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
     """nsol_corr3_wrap_* (x, y, z passes fused, periodic) against the three
     nsol_corr_axis_* launches and against the oracle's dense convolution:
@@ -100,6 +105,46 @@ def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
     if np.prod(shape) <= 64 ** 3:
         ref = orc.gaussian_blur(x.astype(np.float64), np.diag([sigma2] * 3))
         assert rel_l2(one, ref) < (1e-12 if dtype == np.float64 else 2e-6)
+    if shape[2] % (16 // np.dtype(dtype).itemsize):
+        # ragged rows: the register-window kernel (the LDS-DMA one switched off)
+        nsol._lib.set_param("corr_blur3_dma_rag", 0)
+        assert rel_l2(A(x), three) < tol
+
+
+@pytest.mark.parametrize("shape,sigma2,dtype", [
+    ((12, 30, 128), 4.0, np.float32), ((12, 70, 131), 4.0, np.float32),
+    ((9, 20, 64), 2.0, np.float64), ((9, 20, 67), 2.0, np.float64)])
+def test_one_pass_blur_takes_operands_off_the_16_byte_grid(nsol, shape, sigma2, dtype):
+    """x and io that are element-aligned only (views into a larger buffer): the
+    same values as from aligned operands, bit for bit, and nothing written
+    outside the view."""
+    import torch
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x_al = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    io_src = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    A, _ = _lo(3).get_gaussian_blurring_operators(np.diag([sigma2] * 3))
+    want = A(x_al.view(shape)).view(-1)
+    ref_io = io_src.clone()
+    want2 = A.apply_axpby(x_al, ref_io, shape, 0.4, -0.7)
+    assert want2 is not None
+    xbuf = torch.empty(n + 8, device="cuda", dtype=td)
+    iobuf = torch.empty(n + 8, device="cuda", dtype=td)
+    for off in (1, 3):
+        x_off = xbuf[off:off + n]
+        x_off.copy_(x_al)
+        assert x_off.data_ptr() % 16 != 0
+        assert torch.equal(A(x_off.view(shape)).view(-1), want)
+        iobuf.fill_(777.0)
+        io_off = iobuf[off:off + n]
+        io_off.copy_(io_src)
+        got2 = A.apply_axpby(x_off, io_off, shape, 0.4, -0.7)
+        assert got2 is not None, "the epilogue kernel refused off-grid operands"
+        assert torch.equal(io_off, ref_io)
+        assert got2 == want2
+        assert bool((iobuf[:off] == 777.0).all().item())
+        assert bool((iobuf[off + n:] == 777.0).all().item())
 
 
 @pytest.mark.parametrize("shape,sigma2,dtype", [
@@ -107,7 +152,11 @@ def test_one_pass_blur_matches_three_passes(nsol, shape, sigma2, dtype):
     ((33, 70, 132), 1.0, np.float32), ((64, 64, 64), 4.0, np.float32),
     ((40, 48, 512), 4.0, np.float32), ((130, 66, 72), 4.0, np.float32),
     ((7, 100, 24), 0.5, np.float64), ((16, 16, 16), 7.0, np.float32),
-    ((16, 24, 16), 7.0, np.float64)])
+    ((16, 24, 16), 7.0, np.float64),
+    # rows that are not a multiple of 16 bytes (the kernel's ragged form)
+    ((24, 70, 131), 4.0, np.float32), ((20, 140, 81), 4.0, np.float32),
+    ((33, 20, 517), 4.0, np.float32), ((11, 33, 101), 4.0, np.float64),
+    ((10, 70, 130), 2.0, np.float32), ((14, 65, 45), 2.0, np.float64)])
 def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
     """nsol_corr3_wrap_axpby_* (io = ca * A x + cb * io formed by the blur itself,
     with the sum of squares of the result: the top block of LSMR's u update,

@@ -29,30 +29,54 @@ def _regs(tok):
 _ASM = {}
 
 
+def _sources_with_16_byte_buffer_stores():
+    """Translation units that issue 16-byte buffer stores: in their own text, or
+    through nsol_blur3_dma.hpp (whose kernels are compiled where
+    NSOL_BLUR3_DMA_IMPL is defined)."""
+    csrc = os.path.join(ROOT, "nsol_amd", "csrc")
+    assert "raw_buffer_store_b128" in open(
+        os.path.join(csrc, "nsol_blur3_dma.hpp")).read()
+    out = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            text = open(os.path.join(csrc, f)).read()
+            if "raw_buffer_store_b128" in text or \
+                    "#define NSOL_BLUR3_DMA_IMPL" in text:
+                out.append(f)
+    return out
+
+
 def _assembly(src, tmp_path_factory):
-    """gfx950 assembly of one translation unit (compiled once per session)."""
+    """gfx950 assembly of one translation unit.  The first request compiles every
+    guarded file side by side (the blur's instantiations take a minute and a
+    half each)."""
     if src not in _ASM:
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         if not os.path.exists(hipcc):
             pytest.skip("hipcc not available")
-        out = tmp_path_factory.mktemp("isa") / (src + ".s")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
-                        "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
-                        "-S", "--cuda-device-only", "-o", str(out),
-                        os.path.join(ROOT, "nsol_amd", "csrc", src)],
-                       check=True, stderr=subprocess.DEVNULL)
-        _ASM[src] = out.read_text()
+        from concurrent.futures import ThreadPoolExecutor
+        todo = sorted(set(_sources_with_16_byte_buffer_stores() + [src]) - set(_ASM))
+        tmp = tmp_path_factory.mktemp("isa")
+
+        def one(f):
+            out = tmp / (f + ".s")
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17",
+                            "-ffp-contract=off", "-I",
+                            os.path.join(ROOT, "include"), "-S",
+                            "--cuda-device-only", "-o", str(out),
+                            os.path.join(ROOT, "nsol_amd", "csrc", f)],
+                           check=True, stderr=subprocess.DEVNULL)
+            return f, out.read_text()
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            for f, text in pool.map(one, todo):
+                _ASM[f] = text
     return _ASM[src]
 
 
-def _sources_with_16_byte_buffer_stores():
-    csrc = os.path.join(ROOT, "nsol_amd", "csrc")
-    return sorted(f for f in os.listdir(csrc) if f.endswith(".hip") and
-                  "raw_buffer_store_b128" in open(os.path.join(csrc, f)).read())
-
-
 @pytest.mark.parametrize("src,min_stores", [("nsol_pdk.hip", 100),
-                                            ("nsol_conv.hip", 4)])
+                                            ("nsol_conv.hip", 4),
+                                            ("nsol_blur3_f32.hip", 100),
+                                            ("nsol_blur3_f64.hip", 100)])
 def test_no_store_data_hazard(src, min_stores, tmp_path_factory):
     """Every translation unit that issues 16-byte buffer stores (the headline
     kernel and the one-pass blur, config 4's A / A^T)."""
@@ -81,8 +105,9 @@ def test_no_store_data_hazard(src, min_stores, tmp_path_factory):
 
 
 def test_every_file_with_16_byte_buffer_stores_is_guarded():
-    assert _sources_with_16_byte_buffer_stores() == ["nsol_conv.hip",
-                                                     "nsol_pdk.hip"]
+    assert _sources_with_16_byte_buffer_stores() == [
+        "nsol_blur3_f32.hip", "nsol_blur3_f64.hip", "nsol_conv.hip",
+        "nsol_pdk.hip"]
 
 
 def test_headline_instantiations_do_not_spill(tmp_path_factory):
@@ -98,3 +123,15 @@ def test_headline_instantiations_do_not_spill(tmp_path_factory):
     ragged = [int(p) for n, p in zip(names, scratch)
               if "k_pd_fusedkIfLi4ELi12ELi3ELi3ELb0ELb0ELb0ELb1ELb1E" in n]
     assert ragged == [0], ragged
+
+
+def test_one_pass_blur_instantiations_do_not_spill(tmp_path_factory):
+    # config 4's A / A^T (13 taps, 16 waves: 128 registers per lane) in all its
+    # forms -- isotropic or not, with the LSMR epilogue, ragged rows
+    for src, t in (("nsol_blur3_f32.hip", "fLi4E"), ("nsol_blur3_f64.hip", "dLi2E")):
+        text = _assembly(src, tmp_path_factory)
+        names = re.findall(r"\.name:\s+(\S+)", text)
+        scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
+        hot = [int(p) for n, p in zip(names, scratch)
+               if "k_blur3_dmaI%sLi13ELi16E" % t in n]
+        assert len(hot) == 8 and not any(hot), (src, hot)
