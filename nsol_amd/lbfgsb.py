@@ -331,6 +331,24 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     (x, info dict).  Follows scipy's iteration accounting: stops after
     `maxiter` accepted iterations."""
     be = backend
+    # A backend whose kernels want whole vectors (DeviceBackend.pad_to: 16
+    # elements -- 16-byte accesses and one mask byte per element) gets the
+    # problem padded with inert variables: x = clip(0), gradient 0.  They sit at
+    # a bound (or are free with a zero gradient), never move, and add exact
+    # zeros to every inner product, so the iterates of the first n variables are
+    # those of the unpadded problem.
+    pad_to = getattr(be, "pad_to", 0)
+    n_in = be.size(x0)
+    if pad_to and n_in % pad_to:
+        n_pad = n_in + (-n_in) % pad_to
+
+        def padded(xp):
+            f, g = fun_and_grad(be.head(xp, n_in))
+            return f, be.pad(g, n_pad)
+        xp, info = minimize(padded, be.pad(x0, n_pad), lo, hi, be,
+                            maxiter=maxiter, m=m, factr=factr, pgtol=pgtol,
+                            maxls=maxls, maxfun=maxfun)
+        return be.copy(be.head(xp, n_in)), info
     has_lo, has_hi = np.isfinite(lo), np.isfinite(hi)
     cnstnd = has_lo or has_hi
     boxed = has_lo and has_hi

@@ -45,6 +45,19 @@ class DeviceBackend(object):
     def _check(self, rc, what):
         _lib.check(rc, "nsol_lb_" + what)
 
+    # lbfgsb.minimize pads the problem to a multiple of this many variables (the
+    # kernels' 16-byte vectors and 16 mask bytes per access; an odd-sized volume
+    # would otherwise run every pass element by element)
+    pad_to = 16
+
+    def pad(self, x, n_pad):
+        out = torch.zeros(n_pad, dtype=x.dtype, device=x.device)
+        out[:x.numel()].copy_(x)
+        return out
+
+    def head(self, x, n):
+        return x[:n]
+
     def size(self, x):
         return x.numel()
 
