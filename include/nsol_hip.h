@@ -92,6 +92,21 @@ int nsol_grad_adj_f32(const float *p, float *out, int ndim, int64_t nz,
 int nsol_grad_adj_f64(const double *p, double *out, int ndim, int64_t nz,
                       int64_t ny, int64_t nx, double wx, double wy, double wz,
                       void *stream);
+/* out = x - tau * grad_adj(p): the argument of prox_f (primal_dual_solver.py:246-248)
+ * in one pass, for a prox_f that is not one of the fused ones (e.g.
+ * prox_linear_least_squares, proximal_operators.py:43-78).  out may alias x. */
+int nsol_grad_adj_axpy_f32(const float *p, const float *x, float *out, int ndim,
+                           int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                           double wz, double tau, void *stream);
+int nsol_grad_adj_axpy_f64(const double *p, const double *x, double *out, int ndim,
+                           int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                           double wz, double tau, void *stream);
+/* out = a + theta * (a - b): the over-relaxation xbar = x_new + theta (x_new - x)
+ * (primal_dual_solver.py:252-253) with the reference's rounding.  out may alias b. */
+int nsol_extrapolate_f32(float *out, const float *a, const float *b, double theta,
+                         int64_t n, void *stream);
+int nsol_extrapolate_f64(double *out, const double *a, const double *b, double theta,
+                         int64_t n, void *stream);
 /* single-axis D_a (adjoint = 0) or D_a^T (adjoint = 1); dir 0 = x, 1 = y, 2 = z.
  * Replaces linear_operators.py:98-106, 193-247 (get_d{x,y,z}_operators). */
 int nsol_diff_axis_f32(const float *x, float *out, int dir, int adjoint,

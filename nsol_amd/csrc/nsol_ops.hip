@@ -73,16 +73,26 @@ __device__ __forceinline__ void grad_adj_vec(const T *__restrict__ p,
   }
 }
 
-template <typename T, int VEC, int ROWS, bool RAG>
+// AXPY: out = x - tau * K^T p, the argument of prox_f in one pass
+// (primal_dual_solver.py:246-248) when prox_f itself is not one of the fused ones
+template <typename T, int VEC, int ROWS, bool RAG, bool AXPY = false>
 __global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
                                                       T *__restrict__ out,
-                                                      Geom<T> G) {
+                                                      Geom<T> G,
+                                                      const T *__restrict__ x = nullptr,
+                                                      T tau = T(0)) {
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
     T acc[VEC];
     grad_adj_vec<RAG, T, VEC>(p, G, c, acc);
+    if constexpr (AXPY) {
+      T xv[VEC];
+      vl<RAG, T, VEC>(c.nval, x + c.i, xv);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = xv[k] - tau * acc[k];
+    }
     vs<RAG, T, VEC>(c.nval, out + c.i, acc);
   }
 }
@@ -519,6 +529,24 @@ int grad_adj_impl(const T *p, T *out, int ndim, int64_t nz, int64_t ny,
 }
 
 template <typename T>
+int grad_adj_axpy_impl(const T *p, const T *x, T *out, int ndim, int64_t nz, int64_t ny,
+                       int64_t nx, double wx, double wy, double wz, double tau,
+                       void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!p || !x || !out) return NSOL_EINVAL;
+  Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  return dispatch_stencil<T>(nz, ny, nx,
+                             ptr16(p) && ptr16(x) && ptr16(out) && G.n % 4 == 0,
+                             [&](auto vec, auto rows, auto rag) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
+    hipLaunchKernelGGL((k_grad_adj<T, V, R, RG, true>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), p, out, G, x, (T)tau);
+    return launch_status();
+  });
+}
+
+template <typename T>
 int diff_axis_impl(const T *x, T *out, int dir, int adjoint, int64_t nz,
                    int64_t ny, int64_t nx, double w, void *stream) {
   if (dir < 0 || dir > 2 || nz < 1 || ny < 1 || nx < 1 || !x || !out || x == out)
@@ -618,6 +646,20 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
                           int64_t nx, double wx, double wy, double wz,           \
                           void *s) {                                             \
     return grad_adj_impl<T>(p, o, ndim, nz, ny, nx, wx, wy, wz, s);              \
+  }                                                                              \
+  int nsol_grad_adj_axpy_##SUF(const T *p, const T *x, T *o, int ndim,           \
+                               int64_t nz, int64_t ny, int64_t nx, double wx,    \
+                               double wy, double wz, double tau, void *s) {      \
+    return grad_adj_axpy_impl<T>(p, x, o, ndim, nz, ny, nx, wx, wy, wz, tau, s); \
+  }                                                                              \
+  int nsol_extrapolate_##SUF(T *out, const T *a, const T *b, double theta,       \
+                             int64_t n, void *s) {                               \
+    if (n > 0 && (!out || !a || !b)) return NSOL_EINVAL;                         \
+    const T th = (T)theta;                                                       \
+    return launch_map<T>(n, s, [=] __device__(int64_t i) {                       \
+      const T v = a[i];                                                          \
+      out[i] = v + th * (v - b[i]);                                              \
+    });                                                                          \
   }                                                                              \
   int nsol_diff_axis_##SUF(const T *x, T *o, int dir, int adj, int64_t nz,       \
                            int64_t ny, int64_t nx, double w, void *s) {          \

@@ -63,6 +63,11 @@ class LinearSolver(Solver):
         float64 upload per outer iteration."""
         if not is_device_tensor(v) and np.size(v) >= (1 << 20):
             return _LazyScaled(v, self._x_scale)
+        if is_device_tensor(v) and self._borrowed(v) is None:
+            # (a solver built once per outer iteration around the same b:
+            # divided once, proximal_operators.scaled_tensor)
+            from .proximal_operators import scaled_tensor
+            return scaled_tensor(v, self._x_scale, torch_dtype(self._dtype))
         return self._scaled(v)
 
     def _dev(self, v):

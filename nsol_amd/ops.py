@@ -88,6 +88,34 @@ def grad_adj(p, shape, w, out=None):
     return out
 
 
+def grad_adj_axpy(p, x, tau, shape, w, out=None):
+    """x - tau * grad_adj(p) in one pass."""
+    _chk(p)
+    _chk(x)
+    ndim, nz, ny, nx = dims3(shape)
+    if p.dtype != x.dtype or x.numel() != nz * ny * nx or \
+            p.numel() != ndim * x.numel():
+        raise ValueError("operand mismatch: p %s[%d], x %s[%d] for shape %r" %
+                         (str(p.dtype), p.numel(), str(x.dtype), x.numel(),
+                          tuple(shape)))
+    if out is None:
+        out = empty_like(x)
+    _lib.check(_fn("grad_adj_axpy", p)(_p(p), _p(x), _p(out), ndim, nz, ny, nx,
+                                       w[0], w[1], w[2], float(tau),
+                                       stream_ptr()), "nsol_grad_adj_axpy")
+    return out
+
+
+def extrapolate(a, b, theta, out=None):
+    """a + theta * (a - b) (the over-relaxation step, the reference's rounding)."""
+    _same(a, b)
+    if out is None:
+        out = empty_like(a)
+    _lib.check(_fn("extrapolate", a)(_p(out), _p(a), _p(b), float(theta),
+                                     a.numel(), stream_ptr()), "nsol_extrapolate")
+    return out
+
+
 def diff_axis(x, shape, direction, adjoint, w):
     _chk(x)
     _, nz, ny, nx = dims3(shape)

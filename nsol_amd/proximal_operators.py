@@ -33,8 +33,7 @@ def _fingerprint(arr):
 def scaled_data_on_device(x0, x_scale, like):
     """b~ = x0 / x_scale as a device tensor with the dtype of `like`."""
     if is_device_tensor(x0):
-        src = x0.to(like.dtype).contiguous().view(-1)
-        return ops.scale(src, float(x_scale), divide=True)
+        return scaled_tensor(x0, x_scale, like.dtype)
     arr = np.asarray(x0)
     key = (id(x0), arr.__array_interface__["data"][0], arr.size,
            float(x_scale), like.dtype, like.device.index, _fingerprint(arr))
@@ -47,6 +46,26 @@ def scaled_data_on_device(x0, x_scale, like):
     _bt_cache.append((key, x0, bt))
     del _bt_cache[:-4]
     return bt
+
+
+def scaled_tensor(src, x_scale, dtype):
+    """src / x_scale for a device tensor, remembered while src is unchanged
+    (torch counts the in-place writes to a tensor's storage: `_version`) -- a
+    data term b or a start x0 that a caller's lambda hands over on every call
+    (prox_linear_least_squares inside a primal-dual loop builds a Tikhonov
+    solver per iteration) is divided once, not once per call."""
+    flat = src.to(dtype).contiguous().view(-1)
+    if flat.data_ptr() != src.data_ptr():      # converted / compacted: a temporary
+        return ops.scale(flat, float(x_scale), divide=True)
+    key = (src.data_ptr(), src.numel(), str(dtype), src.device.index,
+           int(src._version), float(x_scale))
+    for k, ref, val in _bt_cache:
+        if k == key and ref.data_ptr() == key[0]:
+            return val
+    val = ops.scale(flat, float(x_scale), divide=True)
+    _bt_cache.append((key, src, val))       # (src kept alive: its address is the key)
+    del _bt_cache[:-4]
+    return val
 
 
 def _elementwise(x, fn, desc):
@@ -76,14 +95,16 @@ class ProximalOperators(object):
         if isinstance(x, Sym):
             raise TraceAbort("prox_linear_least_squares is not fused")
         identity = lambda v: v.flatten()
-        if is_device_tensor(b):
-            b_s = ops.scale(b.contiguous().view(-1), float(x_scale), True)
+        if is_device_tensor(x):
+            # the solvers' device path: b / x_scale and x0 / x_scale are formed
+            # on the device once and remembered (scaled_data_on_device)
+            b_s = scaled_data_on_device(b, x_scale, x)
+            x0_s = scaled_data_on_device(x0, x_scale, x)
         else:
-            b_s = np.asarray(b) / float(x_scale)
-        if is_device_tensor(x0):
-            x0_s = ops.scale(x0.contiguous().view(-1), float(x_scale), True)
-        else:
-            x0_s = np.asarray(x0) / float(x_scale)
+            b_s = to_numpy(b) / float(x_scale) if is_device_tensor(b) \
+                else np.asarray(b) / float(x_scale)
+            x0_s = to_numpy(x0) / float(x_scale) if is_device_tensor(x0) \
+                else np.asarray(x0) / float(x_scale)
         tikhonov = tk.TikhonovLinearSolver(
             A=A, A_adj=A_adj, B=identity, B_adj=identity, x0=x0_s, b=b_s,
             b_reg=x, alpha=1. / tau, iter_max=iter_max, verbose=verbose,

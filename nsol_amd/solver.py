@@ -52,9 +52,11 @@ class Solver(object):
             self._x0_host = None
             self._x0_dev = self._borrowed(x0)
             if self._x0_dev is None:
-                self._x0_dev = ops.scale(
-                    x0.to(torch_dtype(self._dtype)).contiguous().view(-1),
-                    self._x_scale, divide=True)
+                # (never written in place by the solvers; a start vector that a
+                # caller hands to one solver after the other is divided once)
+                from .proximal_operators import scaled_tensor
+                self._x0_dev = scaled_tensor(x0, self._x_scale,
+                                             torch_dtype(self._dtype))
         else:
             arr = np.asarray(x0)
             keep = arr.dtype if arr.dtype in (np.float32, np.float64) \

@@ -23,6 +23,7 @@ from .definitions import EPS
 from .device import is_device_tensor, to_device, to_numpy
 from .linear_solver import LinearSolver
 from .lsmr import lsmr, lsmr_fused
+from .solver import Solver
 from .symbolic import trace_operator
 from ._accessors import add_accessors
 
@@ -57,6 +58,27 @@ class TikhonovLinearSolver(LinearSolver):
         # sqrt(alpha) * b_reg (set by ADMMLinearSolver's fused outer step)
         self._prescaled_b_reg = None
 
+    _x0_clip_pending = False
+
+    def _clip_x0(self):
+        self._x0_clip_pending = False
+        self._x0_dev = ops.clip(Solver._x0_device(self), self._bounds[0],
+                                self._bounds[1])
+        if self._x0_host is not None:
+            self._x0_host = np.clip(self._x0_host, self._bounds[0],
+                                    self._bounds[1])
+        return self._x0_dev
+
+    def _x0_device(self):
+        if self._x0_clip_pending:
+            return self._clip_x0()
+        return Solver._x0_device(self)
+
+    def get_x0(self):
+        if self._x0_clip_pending:
+            self._clip_x0()
+        return Solver.get_x0(self)
+
     def get_b_reg(self):
         if is_device_tensor(self._b_reg):
             return to_numpy(ops.scale(self._b_reg, self._x_scale))
@@ -80,14 +102,16 @@ class TikhonovLinearSolver(LinearSolver):
             self._observer.add_x(self.get_x())
 
         x0 = self._x0_device()
+        lsmr_path = self._minimizer == "lsmr" and self._data_loss == "linear"
         if self._bounds is not None:                       # tikhonov :142-143
-            x0 = ops.clip(x0, self._bounds[0], self._bounds[1])
-            self._x0_dev = x0
-            if self._x0_host is not None:
-                self._x0_host = np.clip(self._x0_host, self._bounds[0],
-                                        self._bounds[1])
+            if lsmr_path and self._observer is None and self._x0_host is None:
+                # LSMR starts from zero (SciPy's default): x0 only gives the
+                # shape, so its projection waits until somebody asks for x0
+                self._x0_clip_pending = True
+            else:
+                x0 = self._clip_x0()
 
-        if self._minimizer == "lsmr" and self._data_loss == "linear":
+        if lsmr_path:
             x = self._run_lsmr(x0)
             if self._bounds is not None:
                 x = ops.clip(x, self._bounds[0], self._bounds[1], out=x)

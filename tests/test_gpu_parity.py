@@ -813,6 +813,76 @@ def test_pd_deconvolution_device_path(nsol, golden):
     assert rel_l2(s.get_x(), g["pd_deconv_2d"]) < 1e-9
 
 
+@pytest.mark.parametrize("shape,spacing", [
+    ((1031,), None), ((37, 53), None), ((9, 14, 23), None),
+    ((12, 16, 32), (1.0, 0.7, 2.5)), ((5, 7, 131), None)])
+@pytest.mark.parametrize("reg", ["TV", "Huber"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_foreign_prox_f_keeps_the_regulariser_side_fused(nsol, shape, spacing, reg,
+                                                         dtype):
+    """A prox_f the fused kernels do not know (here: a device callable of its
+    own; in the CLI: prox_linear_least_squares) with nsol_amd's gradient and
+    prox_g_conj: dual update, prox_f's argument and the over-relaxation run as
+    one kernel each (nsol_pd_dual_step_*, nsol_grad_adj_axpy_*,
+    nsol_extrapolate_*) and give the values of the loop that glues every
+    callable with separate axpys (primal_dual_solver.py:242-256), bit for bit."""
+    import nsol_amd.primal_dual_solver as pd
+    from nsol_amd import ops
+    from nsol_amd.proximal_operators import ProximalOperators as prox
+    rng = np.random.default_rng(len(shape) * 100 + shape[-1])
+    obs = (100.0 * rng.random(shape)).astype(np.float64)
+    grad, grad_adj = _lo(len(shape), spacing).get_gradient_operators()
+    Z = grad(obs).shape
+    D = lambda x: grad(x.reshape(*shape)).flatten()
+    Da = lambda x: grad_adj(x.reshape(*Z)).flatten()
+    b = obs.flatten()
+    xs = float(b.max())
+    calls = []
+
+    def pf(x, tau):                       # not one of the recognised proxes
+        calls.append(tau)
+        y = ops.scale(x, 1.0 / (1.0 + 0.25 * tau))
+        return ops.clip(y, 0.0, np.inf)
+    pg = prox.prox_huber_conj if reg == "Huber" else prox.prox_tv_conj
+    outs = []
+    for semi in (True, False):
+        pd.USE_SEMI_FUSED = semi
+        try:
+            s = pd.PrimalDualSolver(prox_f=pf, prox_g_conj=pg, B=D, B_conj=Da,
+                                    L2=4.0 * len(shape), x0=b, alpha=0.05,
+                                    iterations=7, x_scale=xs, dtype=dtype)
+            s.run()
+        finally:
+            pd.USE_SEMI_FUSED = True
+        assert s.get_execution() == "device"
+        outs.append(s.get_x())
+    # (run()'s probe for a fusable configuration calls it too)
+    assert sum(isinstance(t, float) for t in calls) >= 14
+    assert np.array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[0]).all() and np.ptp(outs[0]) > 0
+
+
+def test_scaled_data_term_is_remembered_until_it_changes(nsol):
+    """prox_linear_least_squares inside a primal-dual loop hands the same b and
+    x0 to a new Tikhonov solver every iteration: b / x_scale is formed once per
+    content (torch's in-place version counter is part of the key), never served
+    stale."""
+    import torch
+    from nsol_amd.proximal_operators import scaled_tensor
+    b = torch.arange(1000, dtype=torch.float32, device="cuda")
+    a1 = scaled_tensor(b, 4.0, torch.float32)
+    a2 = scaled_tensor(b.view(-1), 4.0, torch.float32)
+    assert a2 is a1                                     # one division
+    assert torch.equal(a1, b / 4.0)
+    assert scaled_tensor(b, 2.0, torch.float32) is not a1
+    b.mul_(3.0)                                         # in place: a new version
+    a3 = scaled_tensor(b, 4.0, torch.float32)
+    assert a3 is not a1 and torch.equal(a3, b / 4.0)
+    # another dtype is a conversion: a temporary, divided every time
+    d = scaled_tensor(b, 4.0, torch.float64)
+    assert d.dtype == torch.float64 and torch.equal(d, b.double() / 4.0)
+
+
 def test_foreign_numpy_callables_take_the_host_bridge(nsol, golden):
     """A caller may still pass plain NumPy lambdas (the reference contract)."""
     import nsol_amd.primal_dual_solver as pd
