@@ -116,6 +116,99 @@ def cpu_baseline(sample_n, iter_max):
     return 1.0 / (time.time() - t0)
 
 
+def cpu_baseline_lbfgsb(sample_n, iter_max):
+    """The robust-loss branch the way the reference runs it: dense ndimage blur,
+    scipy.optimize.minimize(method="L-BFGS-B", maxiter=iter_max) with the Huber
+    loss (oracle.admm -> oracle.tikhonov, tikhonov_linear_solver.py:197-220) on a
+    bounded sample: ONE ADMM iteration."""
+    import scipy.ndimage
+    from oracle import nsol_oracle as orc
+    n = sample_n
+    shape = (n, n, n)
+    cov = np.diag([4.0, 4.0, 4.0])
+    taps = orc.gaussian_taps(3, cov)
+    conv = scipy.ndimage.convolve
+    A = lambda x: conv(x.reshape(*shape), taps, mode="wrap").flatten()
+    D = lambda x: orc.grad(x.reshape(*shape)).flatten()
+    Da = lambda p: orc.grad_adj(p.reshape(3 * n, n, n)).flatten()
+    y = A(orc.synth_volume(n, 0, "clean"))
+    y = y + 0.02 * y.max() * np.random.default_rng(1).standard_normal(y.size)
+    t0 = time.time()
+    orc.admm(A, A, D, Da, y, y, 3, alpha=0.01, iter_max=iter_max,
+             minimizer="L-BFGS-B", data_loss="huber", rho=0.1, iterations=1,
+             x_scale=float(y.max()))
+    return 1.0 / (time.time() - t0)
+
+
+# algorithmic bytes per voxel of the limited-memory products at c stored pairs
+# (float32 vectors, one mask byte): W' v, W c + base vectors, the subspace matrix
+# with the reduced gradient formed in the same pass
+def lb_bytes(c):
+    return {"k_mdots": 4 * (2 * c + 1) + 1, "k_wcomb": 4 * (2 * c + 2) + 1,
+            "k_masked_gram_dma": 4 * (2 * c + 4) + 1}
+
+
+def time_kernels_lbfgsb(shape, c=10, reps=6):
+    """Average launch duration of the O(m n) kernels of the GPU-resident L-BFGS-B
+    with a full memory (c stored pairs) on vectors of the run's size."""
+    import torch
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    n = int(np.prod(shape))
+    n -= n % 16
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gen = torch.Generator(device=dev).manual_seed(5)
+    r = lambda: torch.rand(n, device=dev, generator=gen)
+    be = DeviceBackend()
+    ws, wy = [r() for _ in range(c)], [r() for _ in range(c)]
+    x, g, z = r(), r() - 0.5, r()
+    free = (torch.rand(n, device=dev, generator=gen) < 0.2).to(torch.int8)
+    coef = list(np.linspace(0.1, 1.0, c))
+    fns = {"k_mdots": lambda: be.dots(wy + ws, x, free),
+           "k_wcomb": lambda: be.subspace_direction(z, ws, wy, coef, coef, 0.7, free),
+           "k_masked_gram_dma": lambda: be.masked_grams_rgrad(
+               ws, wy, free, z, x, g, 0.7, coef, coef)}
+    ev = HipEvents()
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name, fn in fns.items():
+        fn()
+        e0, e1 = ev.create(), ev.create()
+        torch.cuda.synchronize()
+        ev.record(e0, stream)
+        for _ in range(reps):
+            fn()                       # (each reads its reduction back: in-order)
+        ev.record(e1, stream)
+        ms = ev.elapsed_ms(e0, e1) / reps
+        bpv = lb_bytes(c)[name]
+        gbps = bpv * n / (ms * 1e-3) / 1e9
+        out[name] = {"bytes_per_voxel": bpv, "stored_pairs": c, "avg_launch_ms": ms,
+                     "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
+    return out
+
+
+def count_lbfgsb_calls(run):
+    """Calls of the O(m n) products during one (untimed) run."""
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    counts = {"k_mdots": 0, "k_wcomb": 0, "k_masked_gram_dma": 0}
+    orig = {k: getattr(DeviceBackend, k) for k in
+            ("dots", "_wcomb", "masked_grams_rgrad")}
+
+    def wrap(name, key):
+        def f(self, *a, **kw):
+            counts[key] += 1
+            return orig[name](self, *a, **kw)
+        return f
+    DeviceBackend.dots = wrap("dots", "k_mdots")
+    DeviceBackend._wcomb = wrap("_wcomb", "k_wcomb")
+    DeviceBackend.masked_grams_rgrad = wrap("masked_grams_rgrad", "k_masked_gram_dma")
+    try:
+        run()
+    finally:
+        for k, v in orig.items():
+            setattr(DeviceBackend, k, v)
+    return counts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=512)
@@ -179,12 +272,15 @@ def main():
                                                  generator=gen)
     x_scale = float(y.max())
     times = []
-    for _ in range(max(1, args.repeat)):
-        s = admm.ADMMLinearSolver(
+
+    def solver():
+        return admm.ADMMLinearSolver(
             A=A_1D, A_adj=A_adj_1D, b=y, B=D_1D, B_adj=D_adj_1D, x0=y,
             dimension=3, alpha=0.01, rho=0.1, iterations=args.iterations,
             iter_max=args.iter_max, minimizer=args.minimizer,
             data_loss=args.data_loss, x_scale=x_scale, dtype=np.float32)
+    for _ in range(max(1, args.repeat)):
+        s = solver()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         s.run()
@@ -250,6 +346,36 @@ def main():
                 "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
                 "kernel_ms_per_admm_iteration_sum":
                     sum(k["ms_per_admm_iteration"] for k in kern.values())}}
+    if args.minimizer == "L-BFGS-B":
+        kern = time_kernels_lbfgsb(shape)
+        calls = count_lbfgsb_calls(lambda: solver().run())
+        for k in kern:
+            kern[k]["launches_per_run"] = calls[k]
+            kern[k]["ms_per_run_at_full_memory"] = calls[k] * kern[k]["avg_launch_ms"]
+        dom = max(kern, key=lambda k: kern[k]["ms_per_run_at_full_memory"])
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom,
+            "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None,
+            "traffic_source": None, "avg_launch_ms": kern[dom]["avg_launch_ms"],
+            "bytes_per_launch": kern[dom]["bytes_per_voxel"] * (nvox - nvox % 16),
+            "note": "the O(m n) products of the limited-memory matrix (10 stored "
+                    "pairs = 20 vectors per pass) dominate the branch; launch "
+                    "counts are those of one run, durations those of a full "
+                    "memory (the first iterations of every solve hold fewer pairs)",
+            "kernels": kern}
+    if not args.no_cpu_baseline and args.minimizer == "L-BFGS-B":
+        sn = args.cpu_sample
+        its = cpu_baseline_lbfgsb(sn, args.iter_max)
+        out["cpu_baseline"] = {
+            "value": its * (sn ** 3) / float(nvox),
+            "unit": "ADMM iterations/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "oracle admm / tikhonov with scipy.optimize.minimize("
+                      "L-BFGS-B, maxiter=%d), Huber loss, dense 13^3 ndimage "
+                      "blur (reference op sequence), %d^3 volume, ONE ADMM "
+                      "iteration, extrapolated per voxel to %d^3"
+                      % (args.iter_max, sn, n)}
     if not args.no_cpu_baseline and args.minimizer == "lsmr":
         sn = args.cpu_sample
         its = cpu_baseline(sn, args.iter_max)
