@@ -563,6 +563,8 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
       case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
   };
@@ -578,21 +580,40 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
     const int64_t t2 = t + 2 * step;
     int nxt2 = cur + 2; if (nxt2 >= kGram2Bufs) nxt2 -= kGram2Bufs;
     if (t2 < ntiles) stage(t2, nxt2);
-    bool stored = false;                               // (wave-uniform below)
+    int stored = 0;                                    // (wave-uniform) stores of r issued
     if constexpr (RG) {
-      // the first lanes: one 16-byte group of r each (k_wcomb's sum, same order)
+      // One 16-byte group of r per lane and trip (k_wcomb's sum, same order), by the
+      // waves that own no pair block -- 15 block pairs x 64 shares leave the sixteenth
+      // wave free at ten stored pairs.  (On the first lanes instead, two waves did this
+      // on top of their pair blocks and the other fourteen waited at the barrier:
+      // 3.8 ms against 2.9 for the matrix alone.)
       const int64_t base = t * kTile;
       const int64_t left = (n - base) / VEC;            // groups of this tile in range
       const int quads_here = left < kQuads ? (int)left : kQuads;
-      stored = wave * kWave < quads_here;
-      for (int e = tid; e < quads_here; e += kGram2Threads) {
+      const int w0 = (nblk * splits + kWave - 1) / kWave;          // first free wave
+      const int first = w0 < kGram2Waves ? w0 * kWave : 0;
+      const int share = w0 < kGram2Waves ? kGram2Threads - first : kGram2Threads;
+      const int mine = (wave * kWave - first);                      // this wave's first group
+      if (mine >= 0 && mine < quads_here) stored = (quads_here - mine + share - 1) / share;
+      for (int e = tid - first; e >= 0 && e < quads_here; e += share) {
         const unsigned char *bufp = gram_raw + cur * buf_bytes;
         V accv = V(T(0));
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           accv += R.bcoef[k] * *reinterpret_cast<const V *>(bufp + (rows + k) * kPitch + e * 16);
-        for (int k = 0; k < nvec; ++k)
-          accv += R.wcoef[k] * *reinterpret_cast<const V *>(bufp + k * kPitch + e * 16);
+        // four rows at a time: four LDS reads in flight (one after the other, the 23
+        // dependent reads of a group were most of a tile's time); the rows beyond nvec
+        // hold zeros and carry zero coefficients
+        for (int k = 0; k < rows; k += 4) {
+          const V a0 = *reinterpret_cast<const V *>(bufp + k * kPitch + e * 16);
+          const V a1 = *reinterpret_cast<const V *>(bufp + (k + 1) * kPitch + e * 16);
+          const V a2 = *reinterpret_cast<const V *>(bufp + (k + 2) * kPitch + e * 16);
+          const V a3 = *reinterpret_cast<const V *>(bufp + (k + 3) * kPitch + e * 16);
+          accv += R.wcoef[k] * a0;
+          accv += R.wcoef[k + 1] * a1;
+          accv += R.wcoef[k + 2] * a2;
+          accv += R.wcoef[k + 3] * a3;
+        }
         if (iw) {
           const unsigned char *mk = bufp + mask_at;
 #pragma unroll
@@ -641,7 +662,7 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
     // tile t + 2 step (issued above, the youngest operations of this wave) may stay
     // in flight when their number is known
     // (a wave that stored a piece of r has one more operation behind the pieces)
-    sync_keep((t2 < ntiles && full(t2)) ? my_pieces + (stored ? 1 : 0) : 0);
+    sync_keep((t2 < ntiles && full(t2)) ? my_pieces + stored : 0);
     if (++cur == kGram2Bufs) cur = 0;
   }
   // sum the splits of every block entry inside the workgroup (fixed order)
