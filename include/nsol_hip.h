@@ -587,6 +587,27 @@ int nsol_lb_diff_dots_f32(const float *a, const float *b, const float *c, float 
 int nsol_lb_diff_dots_f64(const double *a, const double *b, const double *c,
                           double *out, int64_t n, double *result, double *ws,
                           void *stream);
+/* The subspace step of an iteration in ONE pass over the stored vectors (scipy's
+ * subsm after the solve with the subspace matrix, lnsrlb's d = z - x, matupd's new
+ * row of S'S / S'Y; tikhonov_linear_solver.py:214-220):
+ *   dsub = free ? scale * (r + sum_j wcoef[j] * w[j]) : 0      (nsol_lb_wcomb_*)
+ *   xn   = free ? clip(xcp + dsub, lo, hi) : xcp               (nsol_lb_project_step_*)
+ *   d    = xn - x                                              (nsol_lb_diff_dots_*)
+ *   result = { #{free xn at a bound}, d'd, g'd, w[0]'d, ..., w[nw-1]'d }  (nsol_lb_mdots_*)
+ * with the arithmetic of those four, value for value.  w_host / wcoef_host: HOST
+ * arrays of nw <= 24 device pointers / doubles; result: nw + 3 device doubles; ws:
+ * nsol_lb_gram_ws_doubles() doubles.  Returns -2 (nothing launched) when n is not a
+ * multiple of 16 bytes of elements or an array is not 16-byte aligned, or nw > 24. */
+int nsol_lb_subspace_step_f32(const float *const *w_host, const double *wcoef_host, int nw,
+                              const float *r, const float *xcp, const float *x,
+                              const float *g, const int8_t *iwhere, int64_t n,
+                              double scale, double lo, double hi, float *xn, float *d,
+                              double *result, double *ws, void *stream);
+int nsol_lb_subspace_step_f64(const double *const *w_host, const double *wcoef_host, int nw,
+                              const double *r, const double *xcp, const double *x,
+                              const double *g, const int8_t *iwhere, int64_t n,
+                              double scale, double lo, double hi, double *xn, double *d,
+                              double *result, double *ws, void *stream);
 int64_t nsol_lb_gram_ws_doubles(void);
 int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream);

@@ -1137,6 +1137,126 @@ inline T cast_bound(double b) {
   return (T)b;
 }
 
+// ---- the subspace step in ONE pass over the stored vectors ---------------------
+// After the solve with the subspace matrix an L-BFGS-B iteration forms, one after the
+// other (scipy's subsm, lnsrlb, matupd behind tikhonov_linear_solver.py:214-220):
+//   dsub = free ? scale * (r + sum_j c_j W_j) : 0                  (k_wcomb)
+//   xn   = free ? clip(xcp + dsub) : xcp,  hits = #{xn at a bound}  (k_project_step)
+//   d    = xn - x,  d'd,  g'd                                       (k_diff_dots)
+//   W_j' d for every stored vector (the new row of S'S and S'Y)     (k_mdots)
+// -- four passes, two of them over all 2c stored vectors.  Here a lane keeps its 16
+// bytes of every W_j in registers: the combination, the projection, the difference and
+// the 2c + 3 sums come from one read of W (105 bytes per voxel at ten stored pairs
+// instead of 215).  The arithmetic per value is that of the four kernels, in the same
+// order; the sums are accumulated per lane in the order k_diff_dots / k_mdots use.
+template <typename T>
+struct SubStep {
+  const T *w[kDotsMax];
+  T wcoef[kDotsMax];
+  int nw;
+};
+
+template <typename T, int VEC, int NV>
+__global__ __launch_bounds__(kBlock) void k_subspace_step(
+    SubStep<T> C, const T *__restrict__ r, const T *__restrict__ xcp,
+    const T *__restrict__ x, const T *__restrict__ g, const int8_t *iw, int64_t n,
+    T scale, T lo, T hi, bool has_lo, bool has_hi, T *__restrict__ xn_out,
+    T *__restrict__ d_out, double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
+  double a[NV + 3];                          // hits, d'd, g'd, W_j'd
+#pragma unroll
+  for (int k = 0; k < NV + 3; ++k) a[k] = 0.0;
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    V wv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      wv[k] = k < C.nw ? reinterpret_cast<const V *>(C.w[k])[j] : V(T(0));
+    const V rv = reinterpret_cast<const V *>(r)[j];
+    const V cv = reinterpret_cast<const V *>(xcp)[j];
+    const V xv = reinterpret_cast<const V *>(x)[j];
+    const V gv = reinterpret_cast<const V *>(g)[j];
+    M m = M((int8_t)0);
+    if (iw) m = reinterpret_cast<const M *>(iw)[j];
+    V acc = V(T(0));
+    acc += T(1) * rv;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (k < C.nw) acc += C.wcoef[k] * wv[k];
+    acc *= scale;
+    V xn, dv;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      T v = cv[e];
+      if (m[e] <= 0) {
+        v = v + acc[e];
+        if (has_lo && v < lo) v = lo;
+        if (has_hi && v > hi) v = hi;
+        if ((has_lo && v == lo) || (has_hi && v == hi)) a[0] += 1.0;
+      }
+      xn[e] = v;
+      dv[e] = T(1) * v + T(-1) * xv[e];
+    }
+    reinterpret_cast<V *>(xn_out)[j] = xn;
+    reinterpret_cast<V *>(d_out)[j] = dv;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[1] += (double)dv[e] * (double)dv[e];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[2] += (double)dv[e] * (double)gv[e];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (k < C.nw) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[3 + k] += (double)wv[k][e] * (double)dv[e];
+      }
+    }
+  }
+  block_partials<NV + 3>(a, ws, false);
+}
+
+// returns -2 (nothing launched) where the vector form does not apply
+template <typename T>
+int subspace_step_impl(const T *const *w_host, const double *wcoef_host, int nw,
+                       const T *r, const T *xcp, const T *x, const T *g,
+                       const int8_t *iwhere, int64_t n, double scale, double lo, double hi,
+                       T *xn, T *d, double *result, double *ws, void *stream) {
+  if (n < 1 || nw < 1 || !w_host || !wcoef_host || !r || !xcp || !x || !g || !xn || !d ||
+      !result || !ws)
+    return NSOL_EINVAL;
+  if (nw > kDotsMax) return -2;
+  constexpr int VW = 16 / sizeof(T);
+  uintptr_t bits = reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(xcp) |
+                   reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) |
+                   reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(d);
+  SubStep<T> C;
+  C.nw = nw;
+  for (int k = 0; k < kDotsMax; ++k) {
+    C.w[k] = k < nw ? w_host[k] : nullptr;
+    C.wcoef[k] = k < nw ? (T)wcoef_host[k] : T(0);
+    if (k < nw) {
+      if (!w_host[k]) return NSOL_EINVAL;
+      bits |= reinterpret_cast<uintptr_t>(w_host[k]);
+    }
+  }
+  if (n % VW != 0 || (bits & 15) ||
+      (iwhere && (reinterpret_cast<uintptr_t>(iwhere) & (VW - 1))))
+    return -2;
+  const int gr = rgrid(n / VW);
+  const T tlo = cast_bound<T>(lo), thi = cast_bound<T>(hi);
+  if (nw > 12)
+    hipLaunchKernelGGL((k_subspace_step<T, VW, kDotsMax>), dim3(gr), dim3(kBlock), 0,
+                       as_stream(stream), C, r, xcp, x, g, iwhere, n, (T)scale, tlo, thi,
+                       lo > -INFINITY, hi < INFINITY, xn, d, ws);
+  else
+    hipLaunchKernelGGL((k_subspace_step<T, VW, 12>), dim3(gr), dim3(kBlock), 0,
+                       as_stream(stream), C, r, xcp, x, g, iwhere, n, (T)scale, tlo, thi,
+                       lo > -INFINITY, hi < INFINITY, xn, d, ws);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, gr, nw + 3,
+                     false, result);
+  return launch_status();
+}
+
 template <typename T>
 int gram_rgrad(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
                double *result, double *ws, const T *const *base3,
@@ -1210,6 +1330,22 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
 }
 
 extern "C" {
+int nsol_lb_subspace_step_f32(const float *const *w_host, const double *wcoef_host, int nw,
+                              const float *r, const float *xcp, const float *x,
+                              const float *g, const int8_t *iwhere, int64_t n,
+                              double scale, double lo, double hi, float *xn, float *d,
+                              double *result, double *ws, void *stream) {
+  return subspace_step_impl<float>(w_host, wcoef_host, nw, r, xcp, x, g, iwhere, n, scale,
+                                   lo, hi, xn, d, result, ws, stream);
+}
+int nsol_lb_subspace_step_f64(const double *const *w_host, const double *wcoef_host, int nw,
+                              const double *r, const double *xcp, const double *x,
+                              const double *g, const int8_t *iwhere, int64_t n,
+                              double scale, double lo, double hi, double *xn, double *d,
+                              double *result, double *ws, void *stream) {
+  return subspace_step_impl<double>(w_host, wcoef_host, nw, r, xcp, x, g, iwhere, n, scale,
+                                    lo, hi, xn, d, result, ws, stream);
+}
 int nsol_lb_masked_gram_rgrad_f32(const float *const *vecs, int nvec,
                                   const int8_t *iwhere, int64_t n, double *result,
                                   double *ws, const float *const *base3,

@@ -25,6 +25,10 @@ import numpy as np
 STATS = {"cauchy_calls": 0, "breakpoints": 0, "crossed": 0, "fetches": 0}
 
 EPSMCH = np.finfo(np.float64).eps
+# False: direction, projection, d = z - x and the BFGS update's products with d as
+# separate passes (the A/B reference of the tests) even when the backend offers
+# them fused
+FUSE_SUBSPACE_STEP = True
 BIG = 1.0e10
 FTOL, GTOL, XTOL = 1.0e-3, 0.9, 0.1     # line search constants of L-BFGS-B
 
@@ -379,6 +383,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                                        sbgnrm)
             nfree_all = False
         # ---------------- subspace minimisation ---------------------------
+        step = None
         nfree = be.count_free(iwhere) if not nfree_all else be.size(x)
         if nfree != 0 and col != 0:
             ok = True
@@ -412,7 +417,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                     r = be.reduced_gradient(z, x, g, theta, ws, wy, coef_s,
                                             coef_y, free)
             if ok:
-                z = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free)
+                z, step = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free)
             else:
                 # refresh the memory and restart the iteration
                 cm.reset()
@@ -420,7 +425,11 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 updatd = False
                 continue
         # ---------------- line search --------------------------------------
-        d, dtd, gd = be.diff_dots(z, x, g)        # d = z - x, d'd, g'd
+        if step is not None:
+            d, dtd, gd, wtd_s, wtd_y = step       # (formed with the subspace step)
+        else:
+            d, dtd, gd = be.diff_dots(z, x, g)    # d = z - x, d'd, g'd
+            wtd_s = wtd_y = None
         dnorm = math.sqrt(dtd)
         stpmx = BIG
         if cnstnd:
@@ -517,13 +526,21 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             wy.pop(0)
             cm.ss[:m - 1, :m - 1] = cm.ss[1:, 1:]
             cm.sy[:m - 1, :m - 1] = cm.sy[1:, 1:]
+            if wtd_s is not None:
+                wtd_s, wtd_y = wtd_s[1:], wtd_y[1:]
         ws.append(d)
         wy.append(r)
         c = cm.col
         cm.theta = rr / dr
-        both = be.dots(ws[:c - 1] + wy[:c - 1], d)   # one pass, one read-back
-        sdots = both[:c - 1]                      # S_old^T d
-        ydots = both[c - 1:]                      # d^T Y_old
+        if wtd_s is not None and len(wtd_s) == c - 1:
+            # S_old^T d and d^T Y_old came with the subspace step (for the unit
+            # step; the line search's step length scales both)
+            sdots = wtd_s if stp == 1.0 else stp * wtd_s
+            ydots = wtd_y if stp == 1.0 else stp * wtd_y
+        else:
+            both = be.dots(ws[:c - 1] + wy[:c - 1], d)   # one pass, one read-back
+            sdots = both[:c - 1]                      # S_old^T d
+            ydots = both[c - 1:]                      # d^T Y_old
         for j in range(c - 1):
             cm.sy[c - 1, j] = ydots[j]
             cm.ss[j, c - 1] = sdots[j]
@@ -724,13 +741,26 @@ def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free):
     wv[col:] = theta * both[col:]
     wv = solve_k(fac, wv, col)
     # d = (1/theta) r + (1/theta^2) Z'W wv   (wv already carries theta in S)
+    # A backend may take the rest of the step -- the direction, its projection,
+    # the line search's d = z - x with d'd and g'd, and the products of the stored
+    # vectors with d that the BFGS update will ask for -- from ONE pass over them
+    fused = None
+    if FUSE_SUBSPACE_STEP and hasattr(be, "subspace_step"):
+        fused = be.subspace_step(r, ws, wy, wv[:col] / theta, wv[col:], theta,
+                                 free, xcp, x, g, lo, hi)
+    if fused is not None:
+        xnew, hit, dvec, dtd, gd, sd, yd = fused
+        # (g'd of the projected point IS subsm's directional derivative dd_p)
+        if not hit or gd <= 0.0:
+            return xnew, (dvec, dtd, gd, sd, yd)
     d = be.subspace_direction(r, ws, wy, wv[:col] / theta, wv[col:], theta,
                               free)
-    xnew, hit = be.project_step(xcp, d, lo, hi, free)
-    if not hit:
-        return xnew
-    dd_p = be.dot_diff(xnew, x, g)
-    if dd_p <= 0.0:
-        return xnew
+    if fused is None:
+        xnew, hit = be.project_step(xcp, d, lo, hi, free)
+        if not hit:
+            return xnew, None
+        dd_p = be.dot_diff(xnew, x, g)
+        if dd_p <= 0.0:
+            return xnew, None
     # projected point is not a descent direction: truncate instead
-    return be.truncated_step(xcp, d, lo, hi, free)
+    return be.truncated_step(xcp, d, lo, hi, free), None

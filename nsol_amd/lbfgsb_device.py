@@ -372,6 +372,38 @@ class DeviceBackend(object):
                            list(wy_list) + list(ws_list),
                            list(cy) + list(cs))
 
+    def subspace_step(self, r, ws_list, wy_list, cy, cs, theta, free, xcp, x, g,
+                      lo, hi):
+        """subspace_direction + project_step + diff_dots(xn, x, g) + the products
+        of every stored vector with d = xn - x, from one pass over the stored
+        vectors.  Returns (xn, hit, d, d'd, g'd, S'd, Y'd) or None when the
+        fused kernel does not apply (nothing launched)."""
+        vecs = list(wy_list) + list(ws_list)
+        nw = len(vecs)
+        if nw < 1:
+            return None
+        lib = _lib.load()
+        if self._gram_ws is None or self._gram_ws.device != r.device:
+            self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
+                                        dtype=torch.float64, device=r.device)
+        PW = ctypes.c_void_p * nw
+        wp = PW(*[w.data_ptr() for w in vecs])
+        wc = np.ascontiguousarray(list(cy) + list(cs), dtype=np.float64)
+        out = torch.empty(nw + 3, dtype=torch.float64, device=r.device)
+        xn = torch.empty_like(xcp)
+        d = torch.empty_like(xcp)
+        rc = _fn("subspace_step", r)(
+            ctypes.cast(wp, ctypes.c_void_p), wc.ctypes.data, nw, _p(r), _p(xcp),
+            _p(x), _p(g), _p(free), r.numel(), 1.0 / theta, float(lo), float(hi),
+            _p(xn), _p(d), _p(out), _p(self._gram_ws), stream_ptr())
+        if rc == -2:
+            return None
+        self._check(rc, "subspace_step")
+        res = out.cpu().numpy()
+        c = len(ws_list)
+        return (xn, res[0] > 0, d, float(res[1]), float(res[2]),
+                res[3 + c:3 + 2 * c].copy(), res[3:3 + c].copy())
+
     # ---- subspace step and line-search bound
     def project_step(self, xcp, d, lo, hi, free):
         ws, res = self._bufs(xcp)

@@ -1417,6 +1417,87 @@ def test_gram_pass_also_forms_the_reduced_gradient(nsol, dtype, c, n):
         assert short is None
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("c,n,lo,hi", [(1, 4096, 0.0, np.inf), (3, 70000, 0.0, 1.0),
+                                       (6, 262144, -np.inf, 0.8),
+                                       (10, 300048, 0.0, np.inf),
+                                       (10, 1 << 20, -np.inf, np.inf),
+                                       (12, 65536, 0.1, 0.9)])
+def test_subspace_step_in_one_pass(nsol, dtype, c, n, lo, hi):
+    """nsol_lb_subspace_step_*: direction, projection, d = z - x with d'd and
+    g'd, and the products of all stored vectors with d from one pass -- the
+    vectors bit for bit those of nsol_lb_wcomb_* -> nsol_lb_project_step_* ->
+    nsol_lb_diff_dots_*, the sums those of nsol_lb_diff_dots_* / nsol_lb_mdots_*."""
+    import torch
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(11 * c + n)
+    mk = lambda: torch.randn(n, device="cuda", dtype=td, generator=gen)
+    ws = [mk() for _ in range(c)]
+    wy = [mk() for _ in range(c)]
+    r, g = mk(), mk()
+    x = torch.rand(n, device="cuda", dtype=td, generator=gen)
+    xcp = torch.rand(n, device="cuda", dtype=td, generator=gen)
+    free = None if (lo == -np.inf and hi == np.inf) else \
+        ((torch.rand(n, device="cuda", generator=gen) < 0.3).to(torch.int8) * 2 -
+         (torch.rand(n, device="cuda", generator=gen) < 0.1).to(torch.int8))
+    cy = list(np.linspace(-0.07, 0.09, c))
+    cs = list(np.linspace(0.03, -0.11, c))
+    theta = 0.83
+    be = DeviceBackend()
+    dsub = be.subspace_direction(r, ws, wy, cy, cs, theta, free)
+    xn_ref, hit_ref = be.project_step(xcp, dsub, lo, hi, free)
+    d_ref, dtd_ref, gd_ref = be.diff_dots(xn_ref, x, g)
+    wtd_ref = np.asarray(be.dots(ws + wy, d_ref))
+    got = be.subspace_step(r, ws, wy, cy, cs, theta, free, xcp, x, g, lo, hi)
+    assert got is not None, "the fused kernel did not run"
+    xn, hit, d, dtd, gd, sd, yd = got
+    assert torch.equal(xn, xn_ref) and torch.equal(d, d_ref)
+    assert hit == hit_ref
+    assert abs(dtd - dtd_ref) <= 1e-12 * abs(dtd_ref)
+    assert abs(gd - gd_ref) <= 1e-12 * max(abs(gd_ref), np.sqrt(dtd_ref))
+    scale = np.abs(wtd_ref).max() + 1e-300
+    assert np.abs(np.concatenate([sd, yd]) - wtd_ref).max() <= 1e-12 * scale
+    # lengths / addresses off the 16-byte grid: the caller's separate passes
+    m = n - 3
+    cut = lambda v: v[:m].clone()
+    assert be.subspace_step(cut(r), [cut(w) for w in ws], [cut(w) for w in wy], cy,
+                            cs, theta, None if free is None else cut(free),
+                            cut(xcp), cut(x), cut(g), lo, hi) is None
+
+
+def test_device_lbfgsb_same_iterates_with_and_without_the_fused_step(nsol):
+    """Whole minimisations with the subspace step fused and as separate passes:
+    same iteration / evaluation counts, iterates equal to rounding."""
+    import torch
+    from nsol_amd import lbfgsb
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    for seed, n, lo, hi, iters in ((0, 304, 0.0, np.inf, 12), (1, 2000, 0.0, 1.5, 25),
+                                   (2, 160, -np.inf, np.inf, 10)):
+        rng = np.random.default_rng(seed)
+        A = torch.from_numpy(rng.standard_normal((n + 5, n))).cuda()
+        b = torch.from_numpy(3.0 * rng.standard_normal(n + 5)).cuda()
+        cc = torch.from_numpy(rng.standard_normal(n)).cuda()
+
+        def fg(x):
+            res = A @ x - b
+            z = res * res
+            f = float((torch.sqrt(1 + z) - 1).sum() + 0.05 * ((x - cc) ** 4).sum())
+            return f, A.T @ (res / torch.sqrt(1 + z)) + 0.2 * (x - cc) ** 3
+        x0 = torch.from_numpy(2.0 * rng.standard_normal(n) + 1.0).cuda()
+        outs = []
+        for fused in (True, False):
+            lbfgsb.FUSE_SUBSPACE_STEP = fused
+            try:
+                outs.append(lbfgsb.minimize(fg, x0, lo, hi, DeviceBackend(),
+                                            maxiter=iters))
+            finally:
+                lbfgsb.FUSE_SUBSPACE_STEP = True
+        (xa, ia), (xb, ib) = outs
+        assert ia["nit"] == ib["nit"] and ia["nfev"] == ib["nfev"]
+        assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-10
+
+
 def test_online_tuner_settles_and_stays_bit_identical(nsol):
     """256^3 is large enough for the online footprint tuner: a 240-iteration run
     explores (every launch a different candidate), settles, and must not differ
