@@ -593,9 +593,10 @@ int nsol_lb_diff_dots_f64(const double *a, const double *b, const double *c,
  *   dsub = free ? scale * (r + sum_j wcoef[j] * w[j]) : 0      (nsol_lb_wcomb_*)
  *   xn   = free ? clip(xcp + dsub, lo, hi) : xcp               (nsol_lb_project_step_*)
  *   d    = xn - x                                              (nsol_lb_diff_dots_*)
- *   result = { #{free xn at a bound}, d'd, g'd, w[0]'d, ..., w[nw-1]'d }  (nsol_lb_mdots_*)
- * with the arithmetic of those four, value for value.  w_host / wcoef_host: HOST
- * arrays of nw <= 24 device pointers / doubles; result: nw + 3 device doubles; ws:
+ *   result = { #{free xn at a bound}, d'd, g'd, w[0]'d, ..., w[nw-1]'d,   (nsol_lb_mdots_*)
+ *              -(smallest feasible step ratio along d from x) }        (nsol_lb_ratio_min_*)
+ * with the arithmetic of those five, value for value.  w_host / wcoef_host: HOST
+ * arrays of nw <= 24 device pointers / doubles; result: nw + 4 device doubles; ws:
  * nsol_lb_gram_ws_doubles() doubles.  Returns -2 (nothing launched) when n is not a
  * multiple of 16 bytes of elements or an array is not 16-byte aligned, or nw > 24. */
 int nsol_lb_subspace_step_f32(const float *const *w_host, const double *wcoef_host, int nw,

@@ -1049,8 +1049,7 @@ __global__ __launch_bounds__(kBlock) void k_project_step(
   block_partials<1>(a, ws, false);
 }
 
-// ---- min over (masked) i of the feasible step ratio, with the smallest index
-//      among ties; ratios: d<0: (lo-x)/d (0 if lo-x >= 0); d>0: (hi-x)/d
+// the feasible step ratio of one variable: d<0: (lo-x)/d (0 if lo-x >= 0); d>0: (hi-x)/d
 template <typename T>
 __device__ __forceinline__ double step_ratio(T xv, T dv, T lo, T hi, bool has_lo,
                                              bool has_hi) {
@@ -1064,6 +1063,9 @@ __device__ __forceinline__ double step_ratio(T xv, T dv, T lo, T hi, bool has_lo
   }
   return INFINITY;
 }
+
+// ---- min over (masked) i of the feasible step ratio, with the smallest index
+//      among ties; ratios: d<0: (lo-x)/d (0 if lo-x >= 0); d>0: (hi-x)/d
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_ratio_min(
@@ -1101,16 +1103,27 @@ __global__ __launch_bounds__(kBlock) void k_ratio_min(
   }
 }
 
+// (min, smallest index among ties) over the blocks' partials: 64 lanes stride over
+// them (one thread walking all 1024 took 0.16 ms), then a shuffle reduction with the
+// same ordering rule
 __global__ void k_ratio_final(const double *ws, int nparts, double *result) {
-  if (threadIdx.x == 0) {
-    double v = ws[0], idx = ws[kRed];
-    for (int j = 1; j < nparts; ++j) {
-      const double v2 = ws[j], i2 = ws[kRed + j];
-      if (v2 < v || (v2 == v && i2 >= 0 && (idx < 0 || i2 < idx))) {
-        v = v2;
-        idx = i2;
-      }
+  double v = INFINITY, idx = -1.0;
+  for (int j = threadIdx.x; j < nparts; j += kWave) {
+    const double v2 = ws[j], i2 = ws[kRed + j];
+    if (v2 < v || (v2 == v && i2 >= 0 && (idx < 0 || i2 < idx))) {
+      v = v2;
+      idx = i2;
     }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const double v2 = __shfl_down(v, off, kWave), i2 = __shfl_down(idx, off, kWave);
+    if (v2 < v || (v2 == v && i2 >= 0 && (idx < 0 || i2 < idx))) {
+      v = v2;
+      idx = i2;
+    }
+  }
+  if (threadIdx.x == 0) {
     result[0] = v;
     result[1] = idx;
   }
@@ -1144,6 +1157,7 @@ inline T cast_bound(double b) {
 //   xn   = free ? clip(xcp + dsub) : xcp,  hits = #{xn at a bound}  (k_project_step)
 //   d    = xn - x,  d'd,  g'd                                       (k_diff_dots)
 //   W_j' d for every stored vector (the new row of S'S and S'Y)     (k_mdots)
+//   the largest feasible step along d from x                        (k_ratio_min)
 // -- four passes, two of them over all 2c stored vectors.  Here a lane keeps its 16
 // bytes of every W_j in registers: the combination, the projection, the difference and
 // the 2c + 3 sums come from one read of W (105 bytes per voxel at ten stored pairs
@@ -1167,6 +1181,7 @@ __global__ __launch_bounds__(kBlock) void k_subspace_step(
   double a[NV + 3];                          // hits, d'd, g'd, W_j'd
 #pragma unroll
   for (int k = 0; k < NV + 3; ++k) a[k] = 0.0;
+  double ratio = INFINITY;                   // min over all variables (lnsrlb's stpmx)
   const int64_t nv = n / VEC;
   GRID_STRIDE(j, nv) {
     V wv[NV];
@@ -1197,6 +1212,7 @@ __global__ __launch_bounds__(kBlock) void k_subspace_step(
       }
       xn[e] = v;
       dv[e] = T(1) * v + T(-1) * xv[e];
+      ratio = fmin(ratio, step_ratio(xv[e], dv[e], lo, hi, has_lo, has_hi));
     }
     reinterpret_cast<V *>(xn_out)[j] = xn;
     reinterpret_cast<V *>(d_out)[j] = dv;
@@ -1213,6 +1229,8 @@ __global__ __launch_bounds__(kBlock) void k_subspace_step(
     }
   }
   block_partials<NV + 3>(a, ws, false);
+  double neg[1] = {-ratio};
+  block_partials<1>(neg, ws + (int64_t)(NV + 3) * kRed, true);
 }
 
 // returns -2 (nothing launched) where the vector form does not apply
@@ -1254,6 +1272,10 @@ int subspace_step_impl(const T *const *w_host, const double *wcoef_host, int nw,
                        lo > -INFINITY, hi < INFINITY, xn, d, ws);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, gr, nw + 3,
                      false, result);
+  // result[nw + 3] = -(smallest feasible step ratio), -inf when no variable limits it
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream),
+                     ws + (int64_t)((nw > 12 ? kDotsMax : 12) + 3) * kRed, gr, 1, true,
+                     result + nw + 3);
   return launch_status();
 }
 

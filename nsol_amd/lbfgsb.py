@@ -426,17 +426,18 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 continue
         # ---------------- line search --------------------------------------
         if step is not None:
-            d, dtd, gd, wtd_s, wtd_y = step       # (formed with the subspace step)
+            d, dtd, gd, wtd_s, wtd_y, ratio = step   # (formed with the subspace step)
         else:
             d, dtd, gd = be.diff_dots(z, x, g)    # d = z - x, d'd, g'd
-            wtd_s = wtd_y = None
+            wtd_s = wtd_y = ratio = None
         dnorm = math.sqrt(dtd)
         stpmx = BIG
         if cnstnd:
             if it == 0:
                 stpmx = 1.0
             else:
-                stpmx = be.max_step(x, d, lo, hi, BIG)
+                stpmx = min(BIG, ratio) if ratio is not None else \
+                    be.max_step(x, d, lo, hi, BIG)
         if it == 0 and not boxed:
             stp = min(1.0 / dnorm, stpmx) if dnorm > 0 else stpmx
         else:
@@ -749,10 +750,10 @@ def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free):
         fused = be.subspace_step(r, ws, wy, wv[:col] / theta, wv[col:], theta,
                                  free, xcp, x, g, lo, hi)
     if fused is not None:
-        xnew, hit, dvec, dtd, gd, sd, yd = fused
+        xnew, hit, dvec, dtd, gd, sd, yd, ratio = fused
         # (g'd of the projected point IS subsm's directional derivative dd_p)
         if not hit or gd <= 0.0:
-            return xnew, (dvec, dtd, gd, sd, yd)
+            return xnew, (dvec, dtd, gd, sd, yd, ratio)
     d = be.subspace_direction(r, ws, wy, wv[:col] / theta, wv[col:], theta,
                               free)
     if fused is None:

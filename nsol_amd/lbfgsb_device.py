@@ -376,8 +376,9 @@ class DeviceBackend(object):
                       lo, hi):
         """subspace_direction + project_step + diff_dots(xn, x, g) + the products
         of every stored vector with d = xn - x, from one pass over the stored
-        vectors.  Returns (xn, hit, d, d'd, g'd, S'd, Y'd) or None when the
-        fused kernel does not apply (nothing launched)."""
+        vectors.  Returns (xn, hit, d, d'd, g'd, S'd, Y'd, ratio) -- ratio: the
+        smallest feasible step ratio along d from x (inf when nothing limits the
+        step) -- or None when the fused kernel does not apply (nothing launched)."""
         vecs = list(wy_list) + list(ws_list)
         nw = len(vecs)
         if nw < 1:
@@ -389,7 +390,7 @@ class DeviceBackend(object):
         PW = ctypes.c_void_p * nw
         wp = PW(*[w.data_ptr() for w in vecs])
         wc = np.ascontiguousarray(list(cy) + list(cs), dtype=np.float64)
-        out = torch.empty(nw + 3, dtype=torch.float64, device=r.device)
+        out = torch.empty(nw + 4, dtype=torch.float64, device=r.device)
         xn = torch.empty_like(xcp)
         d = torch.empty_like(xcp)
         rc = _fn("subspace_step", r)(
@@ -402,7 +403,8 @@ class DeviceBackend(object):
         res = out.cpu().numpy()
         c = len(ws_list)
         return (xn, res[0] > 0, d, float(res[1]), float(res[2]),
-                res[3 + c:3 + 2 * c].copy(), res[3:3 + c].copy())
+                res[3 + c:3 + 2 * c].copy(), res[3:3 + c].copy(),
+                -float(res[3 + 2 * c]))
 
     # ---- subspace step and line-search bound
     def project_step(self, xcp, d, lo, hi, free):

@@ -1451,7 +1451,8 @@ def test_subspace_step_in_one_pass(nsol, dtype, c, n, lo, hi):
     wtd_ref = np.asarray(be.dots(ws + wy, d_ref))
     got = be.subspace_step(r, ws, wy, cy, cs, theta, free, xcp, x, g, lo, hi)
     assert got is not None, "the fused kernel did not run"
-    xn, hit, d, dtd, gd, sd, yd = got
+    xn, hit, d, dtd, gd, sd, yd, ratio = got
+    assert min(1.0e10, ratio) == be.max_step(x, d_ref, lo, hi, 1.0e10)
     assert torch.equal(xn, xn_ref) and torch.equal(d, d_ref)
     assert hit == hit_ref
     assert abs(dtd - dtd_ref) <= 1e-12 * abs(dtd_ref)
