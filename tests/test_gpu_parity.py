@@ -986,6 +986,34 @@ def test_misuse_fails_loudly_instead_of_reading_out_of_bounds(nsol):
     with pytest.raises(ValueError):
         ops.lsmr_hx_update(a, a.clone(), a.clone(), torch.ones(7, device="cuda"),
                            0.1, 0.1, 0.1, 0.1)
+    with pytest.raises(ValueError):                    # p is not dim * x long
+        ops.grad_adj_axpy(torch.ones(100, device="cuda"), a, 0.1, (10, 10), (1., 1., 1.))
+    with pytest.raises(ValueError):
+        ops.extrapolate(a, torch.ones(99, device="cuda"), 0.5)
+    # the C entries themselves: null pointers and impossible extents are refused
+    # (NSOL_EINVAL), nothing is launched
+    import ctypes
+    from nsol_amd import _lib
+    lib = _lib.load()
+    p = a.data_ptr()
+    assert lib.nsol_grad_adj_axpy_f32(None, p, p, 2, 1, 10, 10, 1., 1., 1., .1, None) != 0
+    assert lib.nsol_grad_adj_axpy_f32(p, p, p, 4, 1, 10, 10, 1., 1., 1., .1, None) != 0
+    assert lib.nsol_extrapolate_f32(None, p, p, 0.5, 100, None) != 0
+    res = torch.zeros(32, dtype=torch.float64, device="cuda")
+    ptrs = (ctypes.c_void_p * 1)(p)
+    co = (ctypes.c_double * 1)(1.0)
+    assert lib.nsol_lb_subspace_step_f32(ptrs, co, 0, p, p, p, p, None, 96, 1., 0., 1.,
+                                         p, p, res.data_ptr(), res.data_ptr(), None) != 0
+    assert lib.nsol_lb_subspace_step_f32(ptrs, co, 1, p, p, p, p, None, 96, 1., 0., 1.,
+                                         p, None, res.data_ptr(), res.data_ptr(), None) != 0
+    # 25 stored vectors: more than one pass holds -- declined (-2), not an error
+    ptrs25 = (ctypes.c_void_p * 25)(*([p] * 25))
+    co25 = (ctypes.c_double * 25)(*([0.0] * 25))
+    big = torch.zeros(int(lib.nsol_lb_gram_ws_doubles()), dtype=torch.float64,
+                      device="cuda")
+    assert lib.nsol_lb_subspace_step_f32(ptrs25, co25, 25, p, p, p, p, None, 96, 1., 0.,
+                                         1., p, p, res.data_ptr(), big.data_ptr(),
+                                         None) == -2
     wrong = BridgedCallable(lambda t: t.double(), np.float32)
     with pytest.raises(ValueError):
         wrong(a)
