@@ -187,6 +187,10 @@ def parse_args(argv):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--copy-back", action="store_true",
+                    help="copy the final iterate back into x after an odd number "
+                         "of multi-iteration launches instead of letting x and "
+                         "its scratch volume trade storage (A/B runs)")
     ap.add_argument("--reps", type=int, default=5,
                     help="repetitions of the timed K-step region (median is "
                          "reported)")
@@ -339,7 +343,8 @@ def main(argv=None):
         end = ops.pd_run(xbar[a], xbar[1 - a], x, bt, p[a], p[1 - a], shape, w,
                          lmbda, sig[first:first + count],
                          ta[first:first + count], th[first:first + count],
-                         p_is_zero, 0.05, flags, x_alt=x_alt)
+                         p_is_zero, 0.05, flags, x_alt=x_alt,
+                         swap_ok=not args.copy_back)
         state["slot"] = a ^ end
 
     def reset(bt):

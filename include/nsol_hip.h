@@ -62,6 +62,9 @@ extern "C" {
 #define NSOL_PD_REG_HUBER 1 /* proximal_operators.py:156-159 prox_huber_conj */
 #define NSOL_PD_DATA_L2 0   /* proximal_operators.py:117-120 prox_ell2_denoising */
 #define NSOL_PD_DATA_L1 2   /* proximal_operators.py:95-98  prox_ell1_denoising */
+/* nsol_pd_run_* only: the caller can take the final primal iterate from x_alt (see
+ * there) -- no copy back into x after an odd number of multi-iteration launches */
+#define NSOL_PD_RUN_X_MAY_SWAP 0x100
 
 /* loss ids, loss_functions.py:251-266 */
 #define NSOL_LOSS_LINEAR 0
@@ -373,8 +376,11 @@ int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p
  * of iterations use the two-iteration kernel when x_alt (scratch of the size of
  * x, may be NULL) is given and the kernel applies.  On return x holds the final
  * primal iterate and *final_slot_host (may be NULL) the slot holding the final
- * xbar / p.  p0 is treated as zero in iteration 0 when p_is_zero != 0.
- * gamma_huber is the Huber parameter (0.05). */
+ * xbar / p.  With NSOL_PD_RUN_X_MAY_SWAP in flags (and final_slot_host given) the
+ * multi-iteration kernels' ping-pong of x is not undone by a copy: bit 1 of
+ * *final_slot_host says whether the final primal iterate is in x_alt (2) or in x
+ * (0), bit 0 is the slot of xbar / p.  p0 is treated as zero in iteration 0 when
+ * p_is_zero != 0.  gamma_huber is the Huber parameter (0.05). */
 int nsol_pd_run_f32(float *xbar0, float *xbar1, float *x, float *x_alt,
                     const float *bt, float *p0, float *p1, int ndim,
                     int64_t nz, int64_t ny, int64_t nx, double wx, double wy,

@@ -535,6 +535,8 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
              double gamma_huber, int flags, int *final_slot, void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (iterations < 0 || !sig || !tau || !theta || !x) return NSOL_EINVAL;
+  const bool may_swap = (flags & NSOL_PD_RUN_X_MAY_SWAP) != 0 && final_slot != nullptr;
+  flags &= ~NSOL_PD_RUN_X_MAY_SWAP;
   T *xb[2] = {xbar0, xbar1};
   T *pp[2] = {p0, p1};
   T *xcur = x, *xoth = x_alt;
@@ -599,12 +601,12 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
     n += 1;
     slot ^= 1;
   }
-  if (xcur != x) {
+  if (xcur != x && !may_swap) {
     hipError_t e = hipMemcpyAsync(x, xcur, sizeof(T) * (size_t)(nz * ny * nx),
                                   hipMemcpyDeviceToDevice, as_stream(stream));
     if (e != hipSuccess) return (int)e;
   }
-  if (final_slot) *final_slot = slot;
+  if (final_slot) *final_slot = slot | ((xcur != x && may_swap) ? 2 : 0);
   return 0;
 }
 

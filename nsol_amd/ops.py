@@ -552,10 +552,18 @@ def persist_pays(shape, iterations):
     return len(shape) == 3 or n >= (1 << 19)
 
 
+PD_RUN_X_MAY_SWAP = 0x100
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
-           p_is_zero, gamma_huber, flags, x_alt=None):
+           p_is_zero, gamma_huber, flags, x_alt=None, swap_ok=False):
     """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that
-    holds the final state.  x holds the final primal iterate."""
+    holds the final state.  x holds the final primal iterate.
+
+    swap_ok: x and x_alt are whole tensors nobody else aliases -- when the
+    multi-iteration kernels leave the final iterate in x_alt, the two tensors
+    trade their storage (x still names the result) instead of a copy of the
+    volume."""
     import ctypes
     ndim, nz, ny, nx = dims3(shape)
     if PD_PERSIST and persist_pays(shape, np.size(sigma)) and \
@@ -570,9 +578,12 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
         _p(xbar0), _p(xbar1), _p(x), _p(x_alt), _p(bt), _p(p0), _p(p1), ndim,
         nz, ny, nx, w[0], w[1], w[2], float(lmbda), sigma.ctypes.data,
         tau.ctypes.data, theta.ctypes.data, int(sigma.size),
-        int(bool(p_is_zero)), float(gamma_huber), int(flags),
+        int(bool(p_is_zero)), float(gamma_huber),
+        int(flags) | (PD_RUN_X_MAY_SWAP if swap_ok and x_alt is not None else 0),
         ctypes.addressof(slot), stream_ptr()), "nsol_pd_run")
-    return int(slot.value)
+    if slot.value & 2:
+        x.data, x_alt.data = x_alt.data, x.data
+    return int(slot.value) & 1
 
 
 # ----------------------------------------------------------------- ADMM ----

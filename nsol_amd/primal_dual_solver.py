@@ -174,7 +174,7 @@ class PrimalDualSolver(Solver):
             x_alt = torch.empty_like(x) if self._iterations > 1 else None
             ops.pd_run(xbar[0], xbar[1], x, bt, p[0], p[1], plan["shape"],
                        plan["w"], lmbda, sig, ta, th, True, plan["gamma"],
-                       plan["flags"], x_alt=x_alt)
+                       plan["flags"], x_alt=x_alt, swap_ok=True)
             self._x = x
             return
         for i in range(self._iterations):      # observed / verbose: stepwise

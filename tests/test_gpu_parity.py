@@ -1527,6 +1527,41 @@ def test_device_lbfgsb_same_iterates_with_and_without_the_fused_step(nsol):
         assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-10
 
 
+@pytest.mark.parametrize("iters", [1, 2, 3, 5, 8, 20])
+def test_pd_run_hands_the_result_over_without_a_copy(nsol, iters):
+    """NSOL_PD_RUN_X_MAY_SWAP: after an odd number of multi-iteration launches the
+    final primal iterate sits in the scratch volume; ops.pd_run(swap_ok=True) lets
+    x and x_alt trade storage instead of copying it back.  Same values, x names
+    them."""
+    import torch
+    from nsol_amd import ops
+    from nsol_amd.primal_dual_solver import step_schedule
+    shape = (64, 128, 128)                      # 1 Mi voxels: the depth-3 kernel runs
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(iters)
+    bt = torch.rand(n, device="cuda", generator=gen)
+    sig, ta, th = step_schedule("ALG2", 16.0, 1 / 0.03, iters)
+    flags = ops.PD_REG_TV | ops.PD_DATA_L2
+    outs = []
+    for swap in (False, True):
+        x = bt.clone()
+        xa = torch.full_like(bt, -7.0)
+        xb = [bt.clone(), torch.empty_like(bt)]
+        p = [torch.zeros(3 * n, device="cuda") for _ in range(2)]
+        ptr_x, ptr_a = x.data_ptr(), xa.data_ptr()
+        slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, (1., 1., 1.),
+                          1 / 0.03, sig, ta, th, True, 0.05, flags, x_alt=xa,
+                          swap_ok=swap)
+        assert slot in (0, 1)
+        if not swap:
+            assert x.data_ptr() == ptr_x
+        else:
+            assert {x.data_ptr(), xa.data_ptr()} == {ptr_x, ptr_a}
+        outs.append((x.clone(), xb[slot].clone(), p[slot].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_online_tuner_settles_and_stays_bit_identical(nsol):
     """256^3 is large enough for the online footprint tuner: a 240-iteration run
     explores (every launch a different candidate), settles, and must not differ
