@@ -507,6 +507,21 @@ int nsol_lsmr_v_update_f64(const double *Atu, const double *u_bot, double *v,
                            int64_t nx, double wx, double wy, double wz,
                            double c_atu, double c_btu, double c_v,
                            double *result, double *ws, void *stream);
+/* The same update written to v_out, which may be v (in place) or Atu (the new vector
+ * takes the place of A^T u and the old v stays): for a caller that keeps every
+ * Golub-Kahan vector v_k and assembles x = sum_k a_k v_k once at the end instead of
+ * carrying h, hbar and x through every iteration (SciPy lsmr.py:352-364 -- 28 bytes
+ * per element and iteration). */
+int nsol_lsmr_v_update_to_f32(const float *Atu, const float *u_bot, const float *v,
+                              float *v_out, int bmode, int ndim, int64_t nz, int64_t ny,
+                              int64_t nx, double wx, double wy, double wz,
+                              double c_atu, double c_btu, double c_v,
+                              double *result, double *ws, void *stream);
+int nsol_lsmr_v_update_to_f64(const double *Atu, const double *u_bot, const double *v,
+                              double *v_out, int bmode, int ndim, int64_t nz, int64_t ny,
+                              int64_t nx, double wx, double wy, double wz,
+                              double c_atu, double c_btu, double c_v,
+                              double *result, double *ws, void *stream);
 /* hbar = h + c_hbar*hbar;  x = x + c_x*hbar;  h = c_v*v + c_h*h;
  * result[0] = sum x^2   (scipy lsmr.py:367-371, 407) */
 int nsol_lsmr_hx_update_f32(float *hbar, float *x, float *h, const float *v,

@@ -150,8 +150,11 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
 // v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v ; sum of squares
 template <typename T, int VEC, int ROWS, bool RAG>
 __global__ __launch_bounds__(kBlock) void k_lsmr_v(
-    const T *__restrict__ Atu, const T *__restrict__ u_bot, T *__restrict__ v,
+    const T *Atu, const T *__restrict__ u_bot, const T *v, T *v_out,
     Geom<T> G, int bmode, T c_atu, T c_btu, T c_v, double *ws) {
+  // (v_out may be v -- the update in place -- or Atu: the new vector then takes the
+  // place of A^T u and the old one stays, for a caller that keeps every v_k; each
+  // value is read before it is written, by the same lane)
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   double acc = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_v(
       val[k] += c_v * t[k];
       if (!RAG || k < c.nval) acc += (double)val[k] * (double)val[k];
     }
-    vs<RAG, T, VEC>(c.nval, v + c.i, val);
+    vs<RAG, T, VEC>(c.nval, v_out + c.i, val);
     }
   }
   store_partial3(acc, ws);
@@ -336,24 +339,24 @@ int u_impl(const T *Av, const T *v, T *u_top, T *u_bot, int bmode, int ndim,
 }
 
 template <typename T>
-int v_impl(const T *Atu, const T *u_bot, T *v, int bmode, int ndim, int64_t nz,
-           int64_t ny, int64_t nx, double wx, double wy, double wz,
+int v_impl(const T *Atu, const T *u_bot, const T *v, T *v_out, int bmode, int ndim,
+           int64_t nz, int64_t ny, int64_t nx, double wx, double wy, double wz,
            double c_atu, double c_btu, double c_v, double *result, double *ws,
            void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (!Atu || !v || !result || !ws || bmode < 0 || bmode > 2 ||
+  if (!Atu || !v || !v_out || !result || !ws || bmode < 0 || bmode > 2 ||
       (bmode != kBNone && !u_bot))
     return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  const bool al = ptr16(Atu) && ptr16(v) && (!u_bot || ptr16(u_bot)) &&
+  const bool al = ptr16(Atu) && ptr16(v) && ptr16(v_out) && (!u_bot || ptr16(u_bot)) &&
                   G.n % 4 == 0;
   return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
     constexpr bool RG = decltype(rag)::value;
     const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
     hipLaunchKernelGGL((k_lsmr_v<T, V, R, RG>), (stencil_grid<V, R>(nz, ny, nx)),
-                       dim3(kBlock), 0, as_stream(stream), Atu, u_bot, v, G, bmode,
-                       (T)c_atu, (T)c_btu, (T)c_v, ws);
+                       dim3(kBlock), 0, as_stream(stream), Atu, u_bot, v, v_out, G,
+                       bmode, (T)c_atu, (T)c_btu, (T)c_v, ws);
     hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
                        nb, result);
     return launch_status();
@@ -413,8 +416,17 @@ extern "C" {
                                double wx, double wy, double wz, double c_atu,    \
                                double c_btu, double c_v, double *result,         \
                                double *ws, void *s) {                            \
-    return v_impl<T>(Atu, u_bot, v, bmode, ndim, nz, ny, nx, wx, wy, wz, c_atu,  \
-                     c_btu, c_v, result, ws, s);                                 \
+    return v_impl<T>(Atu, u_bot, v, v, bmode, ndim, nz, ny, nx, wx, wy, wz,      \
+                     c_atu, c_btu, c_v, result, ws, s);                          \
+  }                                                                              \
+  int nsol_lsmr_v_update_to_##SUF(const T *Atu, const T *u_bot, const T *v,      \
+                                  T *v_out, int bmode, int ndim, int64_t nz,     \
+                                  int64_t ny, int64_t nx, double wx, double wy,  \
+                                  double wz, double c_atu, double c_btu,         \
+                                  double c_v, double *result, double *ws,        \
+                                  void *s) {                                     \
+    return v_impl<T>(Atu, u_bot, v, v_out, bmode, ndim, nz, ny, nx, wx, wy, wz,  \
+                     c_atu, c_btu, c_v, result, ws, s);                          \
   }                                                                              \
   int nsol_lsmr_hx_update_##SUF(T *hbar, T *x, T *h, const T *v, int64_t n,      \
                                 double c_hbar, double c_x, double c_h,           \

@@ -155,6 +155,24 @@ def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
     return x, istop, itn
 
 
+# lsmr_fused keeps every Golub-Kahan vector v_k (the update writes v_{k+1} into the
+# buffer A^T u came in) and assembles x = sum_k a_k v_k in ONE pass at the end: h,
+# hbar and x are linear combinations of the v_k whose coefficients follow SciPy's
+# recurrences (lsmr.py:352-364) on the host, so the 28 bytes per element and
+# iteration of that update (a quarter of an iteration's traffic) are not moved at
+# all.  Held to DEFER_X_BYTES of stored vectors; False: the three vectors are
+# carried through every iteration (nsol_lsmr_hx_update_*; the A/B reference).
+DEFER_X = True
+DEFER_X_BYTES = 48 << 30
+_MAX_COMBINED = 40           # vectors one nsol_lb_wcomb_* launch combines
+
+
+def _aliases(t, *others):
+    p = t.untyped_storage().data_ptr()
+    return any(o is not None and o.untyped_storage().data_ptr() == p
+               for o in others)
+
+
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
@@ -171,27 +189,53 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     else:
         normb = math.sqrt(ops.dot(ut, ut) +
                           (ops.dot(ub, ub) if ub is not None else 0.0))
-    x = torch.zeros_like(x_like)
+    defer = (DEFER_X and maxiter + 1 <= _MAX_COMBINED and
+             (maxiter + 1) * x_like.numel() * x_like.element_size()
+             <= DEFER_X_BYTES)
+    x = None if defer else torch.zeros_like(x_like)
     beta = normb
     su = beta if beta > 0 else 1.0
+
+    def next_v(atu, v_old, c_atu, c_btu, c_v):
+        """(new vt, its squared norm): into A^T u's own buffer when every v_k is
+        kept (unless the caller's operator handed back one of our vectors)."""
+        if not defer:
+            return v_old, ops.lsmr_v_update(atu, ub, v_old, bmode, shape, w,
+                                            c_atu, c_btu, c_v)
+        out = torch.empty_like(x_like) if _aliases(atu, ut, ub, v_old) else atu
+        return out, ops.lsmr_v_update(atu, ub, v_old, bmode, shape, w, c_atu,
+                                      c_btu, c_v, out=out)
+
     if beta > 0:
-        vt = torch.zeros_like(x_like)
         # vt = A^T ut + sa B^T ub  (raw, = su * A^T u)
-        nv2 = ops.lsmr_v_update(A_adj(ut), ub, vt, bmode, shape, w, 1.0, sa,
-                                0.0)
+        atu = A_adj(ut)
+        if defer:
+            out = torch.empty_like(x_like) if _aliases(atu, ut, ub) else atu
+            nv2 = ops.lsmr_v_update(atu, ub, atu, bmode, shape, w, 1.0, sa, 0.0,
+                                    out=out)
+            vt = out
+        else:
+            vt, nv2 = next_v(atu, torch.zeros_like(x_like), 1.0, sa, 0.0)
         alpha = math.sqrt(nv2) / su
     else:
         vt = torch.zeros_like(x_like)
         alpha = 0.0
     sv = su * alpha if alpha > 0 else 1.0
+    if defer:
+        vts, svs = [vt], [sv]
+        h_c = np.zeros(maxiter + 1)          # h, hbar, x over the normalised v_k
+        hb_c = np.zeros(maxiter + 1)
+        x_c = np.zeros(maxiter + 1)
+        h_c[0] = 1.0
 
     itn = 0
     zetabar = alpha * beta
     alphabar = alpha
     rho = rhobar = cbar = 1.0
     sbar = 0.0
-    h = ops.scale(vt, 1.0 / sv)
-    hbar = torch.zeros_like(x_like)
+    if not defer:
+        h = ops.scale(vt, 1.0 / sv)
+        hbar = torch.zeros_like(x_like)
     betadd, betad = beta, 0.0
     rhodold = 1.0
     tautildeold = thetatilde = zeta = d = 0.0
@@ -200,7 +244,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     istop = 0
     ctol = 1.0 / conlim if conlim > 0 else 0.0
     if alpha * beta == 0 or normb == 0:
-        return x, istop, itn
+        return (torch.zeros_like(x_like) if defer else x), istop, itn
 
     while itn < maxiter:
         itn += 1
@@ -218,10 +262,12 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         su = beta if beta > 0 else 1.0
         if beta > 0:
             # vt <- A^T u - beta v
-            nv2 = ops.lsmr_v_update(A_adj(ut), ub, vt, bmode, shape, w,
-                                    1.0 / beta, sa / beta, -beta / sv)
+            vt, nv2 = next_v(A_adj(ut), vt, 1.0 / beta, sa / beta, -beta / sv)
             alpha = math.sqrt(nv2)
             sv = alpha if alpha > 0 else 1.0
+            if defer:
+                vts.append(vt)
+                svs.append(sv)
 
         chat, shat, alphahat = _sym_ortho(alphabar, 0.0)
         rhoold = rho
@@ -235,9 +281,21 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         zeta = cbar * zetabar
         zetabar = -sbar * zetabar
 
-        normx2 = ops.lsmr_hx_update(
-            hbar, x, h, vt, -(thetabar * rho / (rhoold * rhobarold)),
-            zeta / (rho * rhobar), -(thetanew / rho), 1.0 / sv)
+        c_hbar = -(thetabar * rho / (rhoold * rhobarold))
+        c_x = zeta / (rho * rhobar)
+        c_h = -(thetanew / rho)
+        if defer:
+            # hbar = h + c_hbar hbar; x += c_x hbar; h = v_new + c_h h -- on the
+            # coefficients; ||x||^2 = sum a_k^2 for orthonormal v_k (it only enters
+            # the stopping test that fires when the residual is exactly zero)
+            hb_c = h_c + c_hbar * hb_c
+            x_c = x_c + c_x * hb_c
+            h_c = c_h * h_c
+            h_c[len(vts) - 1] += 1.0
+            normx2 = float(np.dot(x_c, x_c))
+        else:
+            normx2 = ops.lsmr_hx_update(hbar, x, h, vt, c_hbar, c_x, c_h,
+                                        1.0 / sv)
 
         betaacute = chat * betadd
         betacheck = -shat * betadd
@@ -283,4 +341,6 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
             istop = 1
         if istop > 0:
             break
+    if defer:
+        x = ops.lincomb_many(vts, [x_c[j] / svs[j] for j in range(len(vts))])
     return x, istop, itn

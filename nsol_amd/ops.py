@@ -217,6 +217,25 @@ def lincomb3(a, x, b, y, c, z, out=None):
     return out
 
 
+def lincomb_many(vecs, coefs, out=None):
+    """sum_k coefs[k] * vecs[k] in one pass (up to 40 vectors; the terms are added
+    in order): nsol_lb_wcomb_* without base vectors or mask."""
+    import ctypes
+    x = _same(vecs[0], *vecs[1:])
+    if len(vecs) != len(coefs) or len(vecs) > 40:
+        raise ValueError("lincomb_many: %d vectors, %d coefficients"
+                         % (len(vecs), len(coefs)))
+    if out is None:
+        out = empty_like(x)
+    ptrs = (ctypes.c_void_p * len(vecs))(*[v.data_ptr() for v in vecs])
+    co = np.ascontiguousarray(coefs, dtype=np.float64)
+    fn = getattr(_lib.load(), "nsol_lb_wcomb_%s" % suffix(x))
+    _lib.check(fn(_p(out), x.numel(), None, 1.0, 0, None, None, len(vecs),
+                  ctypes.cast(ptrs, ctypes.c_void_p), co.ctypes.data,
+                  stream_ptr()), "nsol_lb_wcomb")
+    return out
+
+
 def scale(x, a, divide=False, out=None):
     _chk(x)
     if out is None:
@@ -670,9 +689,12 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
 
 
 def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
-                  sync=True):
-    """v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v; returns ||v||^2."""
+                  sync=True, out=None):
+    """v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v; returns ||v||^2.  out: where
+    the new vector goes instead of v (may be Atu: v then stays as it was)."""
     _same(Atu, v)
+    if out is not None:
+        _same(Atu, out)
     if u_bot is not None:
         _chk(u_bot)
         rows = (len(tuple(shape)) if bmode == B_GRAD else 1) * Atu.numel()
@@ -681,6 +703,12 @@ def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
                              "expected %d" % (u_bot.numel(), rows))
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Atu.numel())
     ws, res = _workspace(Atu.device)
+    if out is not None:
+        _lib.check(_fn("lsmr_v_update_to", Atu)(
+            _p(Atu), _p(u_bot), _p(v), _p(out), int(bmode), ndim, nz, ny, nx,
+            w[0], w[1], w[2], float(c_atu), float(c_btu), float(c_v), _p(res),
+            _p(ws), stream_ptr()), "nsol_lsmr_v_update_to")
+        return float(res.item()) if sync else res
     _lib.check(_fn("lsmr_v_update", Atu)(
         _p(Atu), _p(u_bot), _p(v), int(bmode), ndim, nz, ny, nx, w[0], w[1],
         w[2], float(c_atu), float(c_btu), float(c_v), _p(res), _p(ws),

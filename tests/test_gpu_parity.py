@@ -497,12 +497,18 @@ def _dec_ops(golden, k):
     return g, shape, A_, Aa_, D_, Da_
 
 
-@pytest.fixture(params=["fused-lsmr", "generic-lsmr"])
+@pytest.fixture(params=["fused-lsmr", "fused-lsmr-carried-x", "generic-lsmr"])
 def lsmr_form(request):
+    """fused-lsmr: the fused kernels with x assembled once from the stored v_k;
+    -carried-x: h, hbar and x carried through every iteration (SciPy's form);
+    generic-lsmr: the operator-callable loop."""
     import nsol_amd.tikhonov_linear_solver as tk
-    tk.USE_FUSED_LSMR = request.param == "fused-lsmr"
+    import nsol_amd.lsmr as lsmr_mod
+    tk.USE_FUSED_LSMR = request.param != "generic-lsmr"
+    lsmr_mod.DEFER_X = request.param == "fused-lsmr"
     yield request.param
     tk.USE_FUSED_LSMR = True
+    lsmr_mod.DEFER_X = True
 
 
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
