@@ -44,13 +44,17 @@ def bytes_per_admm_iteration(iter_max):
     return iter_max * 108 + SETUP_BYTES
 
 
-def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs):
+def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
+                                   deferred_x=True):
     """What the kernels have to move at least with this build's fusions: the
     blur's epilogue saves the write and the read of A v (8 B per LSMR iteration),
     the pre-scaled right-hand side the scaling pass, its norm pass and the norm
-    pass over b (40 B per ADMM iteration)."""
-    return iter_max * (100 if blur_epilogue else 108) + SETUP_BYTES - \
-        (40 if prescaled_rhs else 0)
+    pass over b (40 B per ADMM iteration); with every v_k kept, the h / hbar / x
+    update (28 B per LSMR iteration) is replaced by one pass that reads the
+    iter_max + 1 stored vectors and writes x."""
+    per_it = (100 if blur_epilogue else 108) - (28 if deferred_x else 0)
+    return iter_max * per_it + (4 * (iter_max + 2) if deferred_x else 0) + \
+        SETUP_BYTES - (40 if prescaled_rhs else 0)
 
 
 def time_kernels(shape, reps=20):
@@ -82,9 +86,14 @@ def time_kernels(shape, reps=20):
     blur_out = torch.empty_like(v)
     lib_blur = lambda: ops.corr3_wrap(v, shape, taps, taps, taps, out=blur_out)
     out = {}
+    vts = [v, ut, Av, h, hbar, x, blur_out, r(n), r(n), r(n), r(n)]
+    x_out = torch.empty_like(v)
+    lib_x = lambda: ops.lincomb_many(vts, [0.1 * (k + 1) for k in range(11)],
+                                     out=x_out)
+    BYTES["k_wcomb"] = 4 * (11 + 1)
     for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
                      ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
-                     ("k_admm_vw", lib_vw)):
+                     ("k_admm_vw", lib_vw), ("k_wcomb", lib_x)):
         for _ in range(3):
             fn()
         e0, e1 = ev.create(), ev.create()
@@ -225,6 +234,10 @@ def main():
                     help="scale and norm passes over LSMR's lower right-hand side "
                          "per ADMM iteration instead of taking both from the outer "
                          "step (A/B runs)")
+    ap.add_argument("--carried-x", action="store_true",
+                    help="LSMR carries h, hbar and x through every iteration "
+                         "(SciPy's form) instead of keeping every v_k and "
+                         "assembling x once (A/B runs)")
     ap.add_argument("--lb-capacity", type=int, default=0,
                     help="breakpoints per window of the L-BFGS-B Cauchy search "
                          "(0 = the backend's default; A/B runs)")
@@ -247,6 +260,9 @@ def main():
         LO.USE_BLUR_EPILOGUE = False
     if args.no_prescaled_rhs:
         admm.USE_PRESCALED_RHS = False
+    if args.carried_x:
+        import nsol_amd.lsmr as lsmr_mod
+        lsmr_mod.DEFER_X = False
     if args.lb_capacity:
         from nsol_amd.lbfgsb_device import DeviceBackend
         DeviceBackend.CAPACITY = args.lb_capacity
@@ -311,13 +327,18 @@ def main():
                    "minimizer": args.minimizer, "data_loss": args.data_loss,
                    "knobs": args.param, "blur_epilogue": not args.no_blur_epilogue,
                    "prescaled_rhs": not args.no_prescaled_rhs,
+                   "lsmr_x": "carried" if args.carried_x else "assembled at the end",
                    "execution": execution},
         "rel_change_vs_input": rel_change, "finite": finite}
     if args.minimizer == "lsmr":
         kern = time_kernels(shape)
+        import nsol_amd.lsmr as lsmr_mod
+        deferred = bool(lsmr_mod.DEFER_X)
+        # (k_wcomb: x assembled from the iter_max + 1 stored v_k; timed for 11)
         per_it = {"k_blur3_dma": 2 * args.iter_max + 1,
                   "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
-                  "k_lsmr_hx": args.iter_max, "k_admm_vw": 1}
+                  "k_lsmr_hx": 0 if deferred else args.iter_max,
+                  "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0}
         for k, c in per_it.items():
             kern[k]["launches_per_admm_iteration"] = c
             kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]
@@ -338,10 +359,10 @@ def main():
                 "bytes_moved_per_voxel_per_admm_iteration":
                     bytes_moved_per_admm_iteration(
                         args.iter_max, not args.no_blur_epilogue,
-                        not args.no_prescaled_rhs),
+                        not args.no_prescaled_rhs, deferred),
                 "frac_moved": bytes_moved_per_admm_iteration(
                     args.iter_max, not args.no_blur_epilogue,
-                    not args.no_prescaled_rhs) * nvox * args.iterations / med / 1e9 /
+                    not args.no_prescaled_rhs, deferred) * nvox * args.iterations / med / 1e9 /
                 HBM_PEAK_GBPS,
                 "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
                 "kernel_ms_per_admm_iteration_sum":
