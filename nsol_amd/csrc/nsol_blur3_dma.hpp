@@ -468,7 +468,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
           if (!RAG || e < nvalid) sumsq += (double)val[e] * (double)val[e];
       }
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, own_off, 0, 0);
+    // (non-temporal: the output is not read again by this launch; 0.2285 -> 0.2245 ms)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, own_off, 0, 2);
     if constexpr (RAG) {
       if (tail_tile) {                               // (uniform in the workgroup)
         // the partial vector of the row: its first two elements as one 8-byte store,

@@ -121,6 +121,10 @@ template <> __device__ __forceinline__ double bld1<double>(rsrc_t r, uint32_t vo
 // write (checked in the ISA: at least one instruction separates them); the
 // s_nop below is belt and braces only -- the scheduler is free to move it away
 // from the store.
+// The five output streams are written once and not read again by this launch:
+// non-temporal stores (aux bit 1) leave the L2 to the footprints' overlap rows, which
+// neighbouring workgroups do re-read (+1.1 % on one box, A/B with tools/_probe/ab_lib.sh).
+constexpr int kStoreAux = 2;
 template <typename T, int V>
 __device__ __forceinline__ void bst(rsrc_t r, uint32_t vo, const T (&v)[V]) {
   typedef typename Pack<T, V>::type P;
@@ -130,7 +134,7 @@ __device__ __forceinline__ void bst(rsrc_t r, uint32_t vo, const T (&v)[V]) {
 #if PDK_ABLATE & 2
   if (t[0] != T(123.456)) return;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r, vo, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), r, vo, 0, kStoreAux);
   asm volatile("s_nop 1");
 }
 
