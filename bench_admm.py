@@ -238,6 +238,10 @@ def main():
                     help="LSMR carries h, hbar and x through every iteration "
                          "(SciPy's form) instead of keeping every v_k and "
                          "assembling x once (A/B runs)")
+    ap.add_argument("--lb-separate", action="store_true",
+                    help="L-BFGS-B: the subspace right-hand side and the subspace "
+                         "step as passes of their own over the stored vectors "
+                         "instead of riding on the Gram pass / fused (A/B runs)")
     ap.add_argument("--lb-capacity", type=int, default=0,
                     help="breakpoints per window of the L-BFGS-B Cauchy search "
                          "(0 = the backend's default; A/B runs)")
@@ -260,6 +264,10 @@ def main():
         LO.USE_BLUR_EPILOGUE = False
     if args.no_prescaled_rhs:
         admm.USE_PRESCALED_RHS = False
+    if args.lb_separate:
+        import nsol_amd.lbfgsb as lb_mod
+        lb_mod.USE_GRAM_RHS = False
+        lb_mod.FUSE_SUBSPACE_STEP = False
     if args.carried_x:
         import nsol_amd.lsmr as lsmr_mod
         lsmr_mod.DEFER_X = False

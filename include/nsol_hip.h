@@ -641,7 +641,12 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
  *                  + sum_k wcoef[k]*vecs[k] : 0
  * -- nsol_lb_wcomb_*'s sum, term for term in the same order, without a pass of
  * its own over the nvec vectors.  base3 / bcoef3 / wcoef: HOST arrays (three
- * device pointers, three and nvec doubles).  Returns -2 (nothing launched) where
+ * device pointers, three and nvec doubles).  result holds nvec more doubles behind
+ * the nvec (nvec + 1) / 2 matrix entries: sum_free vecs[k] * b for
+ * b = bcoef3[0]*base3[0] + bcoef3[1]*base3[1] + bcoef3[2]*base3[2] -- with the
+ * matrix they give W'Z r = W'Z b + (W'Z W) wcoef on the host, which saves the
+ * nsol_lb_mdots_* pass that forms the subspace right-hand side (nvec <= 20).
+ * Returns -2 (nothing launched) where
  * the LDS-DMA staged kernel does not apply (n not a multiple of 16, unaligned
  * arrays, no room for the three extra rows): call nsol_lb_masked_gram_* and
  * nsol_lb_wcomb_* then. */

@@ -515,6 +515,14 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
   for (int u = 0; u < kGram2B; ++u)
 #pragma unroll
     for (int v = 0; v < kGram2B; ++v) acc[u][v] = 0.0;
+  // (RG) The owners of the DIAGONAL pair blocks leave out the lower triangle nobody
+  // reads and use four of its slots -- (1,0), (2,0), (2,1), (3,0) for the block's vectors
+  // 0 .. 3 -- for the products of their four vectors with
+  //   b = b0 * base0 + b1 * base1 + b2 * base2   (r without its W part):
+  // W'Z r = W'Z b + (W'Z W) wc then follows on the host from this pass's matrix, and the
+  // pass over the 2c vectors that formed W'Z r on its own (nsol_lb_mdots_*) is not needed.
+  // (Accumulators of their own cost eight registers this kernel does not have.)
+  const bool diag = RG && worker && bi == bj;
   // rows beyond nvec (padding of the last block) stay zero in every buffer
   for (int b = 0; b < kGram2Bufs; ++b)
     for (int v = nvec; v < rows; ++v)
@@ -640,6 +648,14 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
         bool keep[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) keep[k] = !iw || (int8_t)mk[e * VEC + k] <= 0;
+        V bq = V(T(0));
+        if constexpr (RG) {
+          if (diag) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              bq += R.bcoef[k] * *reinterpret_cast<const V *>(bufp + (rows + k) * kPitch + e * 16);
+          }
+        }
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           double ad[kGram2B], bd[kGram2B];
@@ -651,10 +667,22 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
           // one fused multiply-add per product (the library is built without
           // contraction): for float data the product of two widened values is exact
           // in double, so this is bit for bit the multiply and add of k_masked_gram
+          if (RG && diag) {
+            const double bb = (double)bq[k];
 #pragma unroll
-          for (int u = 0; u < kGram2B; ++u)
+            for (int u = 0; u < kGram2B; ++u)
 #pragma unroll
-            for (int v = 0; v < kGram2B; ++v) acc[u][v] = __builtin_fma(ad[u], bd[v], acc[u][v]);
+              for (int v = u; v < kGram2B; ++v) acc[u][v] = __builtin_fma(ad[u], bd[v], acc[u][v]);
+            acc[1][0] = __builtin_fma(ad[0], bb, acc[1][0]);
+            acc[2][0] = __builtin_fma(ad[1], bb, acc[2][0]);
+            acc[2][1] = __builtin_fma(ad[2], bb, acc[2][1]);
+            acc[3][0] = __builtin_fma(ad[3], bb, acc[3][0]);
+          } else {
+#pragma unroll
+            for (int u = 0; u < kGram2B; ++u)
+#pragma unroll
+              for (int v = 0; v < kGram2B; ++v) acc[u][v] = __builtin_fma(ad[u], bd[v], acc[u][v]);
+          }
         }
       }
     }
@@ -687,13 +715,25 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
 __global__ __launch_bounds__(kBlock) void k_gram2_final(const double *ws, int nblocks,
                                                          int nvec, int nb, double *result) {
   __shared__ double s[kBlock / kWave];
+  const int npairs = nvec * (nvec + 1) / 2;
+  int o;
+  if ((int)blockIdx.x >= npairs) {
+    // (RG) product of vector k with b: a lower-triangle slot of k's diagonal block
+    const int k = (int)blockIdx.x - npairs, d = k / kGram2B, u = k % kGram2B;
+    int kb = 0;
+    for (int q2 = 0; q2 < d; ++q2) kb += nb - q2;
+    const int slot = u == 0 ? 1 * kGram2B : (u == 1 ? 2 * kGram2B : (u == 2 ? 2 * kGram2B + 1
+                                                                           : 3 * kGram2B));
+    o = kb * (kGram2B * kGram2B) + slot;
+  } else {
   int vi = 0, r = blockIdx.x;
   while (r >= nvec - vi) { r -= nvec - vi; ++vi; }
   const int vj = vi + r;
   const int bi = vi / kGram2B, bj = vj / kGram2B;
   int kb = bj - bi;                                 // block index of (bi, bj), bi <= bj
   for (int u = 0; u < bi; ++u) kb += nb - u;
-  const int o = kb * (kGram2B * kGram2B) + (vi % kGram2B) * kGram2B + (vj % kGram2B);
+  o = kb * (kGram2B * kGram2B) + (vi % kGram2B) * kGram2B + (vj % kGram2B);
+  }
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   double t = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += kBlock) t += ws[(int64_t)b * kGram2Ent + o];
@@ -737,8 +777,8 @@ int masked_gram_dma_launch_tb(const GramPtrs<T> &P, int nvec, const int8_t *iwhe
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGram2Threads), lds, st, P, nvec,
                      iwhere, n, nb, splits, ws, R);
-  hipLaunchKernelGGL(k_gram2_final, dim3(nvec * (nvec + 1) / 2), dim3(kBlock), 0, st, ws,
-                     (int)blocks, nvec, nb, result);
+  hipLaunchKernelGGL(k_gram2_final, dim3(nvec * (nvec + 1) / 2 + (RG ? nvec : 0)),
+                     dim3(kBlock), 0, st, ws, (int)blocks, nvec, nb, result);
   return launch_status();
 }
 

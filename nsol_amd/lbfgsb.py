@@ -29,6 +29,8 @@ EPSMCH = np.finfo(np.float64).eps
 # separate passes (the A/B reference of the tests) even when the backend offers
 # them fused
 FUSE_SUBSPACE_STEP = True
+# False: [Y S]'Z r by a pass of its own even when the Gram pass delivered it
+USE_GRAM_RHS = True
 BIG = 1.0e10
 FTOL, GTOL, XTOL = 1.0e-3, 0.9, 0.1     # line search constants of L-BFGS-B
 
@@ -403,8 +405,9 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 if hasattr(be, "masked_grams_rgrad"):
                     fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
                                                   coef_s, coef_y)
+            wtzr = None
             if fused is not None:
-                yzzy, szzs, szzy, r = fused
+                yzzy, szzs, szzy, r, wtzr = fused
             else:
                 yzzy, szzs, szzy = be.masked_grams(ws, wy, free)
             fac = form_k(cm, yzzy, szzs, szzy)
@@ -417,7 +420,8 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                     r = be.reduced_gradient(z, x, g, theta, ws, wy, coef_s,
                                             coef_y, free)
             if ok:
-                z, step = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free)
+                z, step = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free,
+                                 wtzr if USE_GRAM_RHS else None)
             else:
                 # refresh the memory and restart the iteration
                 cm.reset()
@@ -732,12 +736,16 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     return xcp, c, iwhere
 
 
-def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free):
+def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free, wtzr=None):
     """Subspace minimisation over the free variables at the Cauchy point with
-    the projection refinement; returns the new point."""
+    the projection refinement; returns the new point.  wtzr: [Y S]'Z r when the
+    backend's Gram pass already produced it."""
     col, theta = cm.col, cm.theta
     wv = np.zeros(2 * col)
-    both = np.asarray(be.dots(wy + ws, r, free))   # one pass, one read-back
+    if wtzr is not None:
+        both = np.asarray(wtzr)
+    else:
+        both = np.asarray(be.dots(wy + ws, r, free))   # one pass, one read-back
     wv[:col] = both[:col]
     wv[col:] = theta * both[col:]
     wv = solve_k(fac, wv, col)

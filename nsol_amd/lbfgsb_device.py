@@ -158,7 +158,8 @@ class DeviceBackend(object):
     def masked_grams_rgrad(self, ws_list, wy_list, free, z, x, g, theta, coef_s,
                            coef_y):
         """masked_grams and reduced_gradient from ONE pass over the 2c vectors
-        (nsol_lb_masked_gram_rgrad_*); None where that kernel does not apply."""
+        (nsol_lb_masked_gram_rgrad_*), with [Y S]'Z r (Y first) for the subspace
+        right-hand side; None where that kernel does not apply."""
         import ctypes
         c = len(ws_list)
         vecs = list(wy_list) + list(ws_list)           # Y first, then S
@@ -170,7 +171,8 @@ class DeviceBackend(object):
         if self._gram_ws is None or self._gram_ws.device != like.device:
             self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
                                         dtype=torch.float64, device=like.device)
-        out = torch.empty(nv * (nv + 1) // 2, dtype=torch.float64, device=like.device)
+        npairs = nv * (nv + 1) // 2
+        out = torch.empty(npairs + nv, dtype=torch.float64, device=like.device)
         r = torch.empty_like(like)
         ptrs = (ctypes.c_void_p * nv)(*[v.data_ptr() for v in vecs])
         base = (ctypes.c_void_p * 3)(z.data_ptr(), x.data_ptr(), g.data_ptr())
@@ -185,9 +187,11 @@ class DeviceBackend(object):
         self._check(rc, "masked_gram_rgrad")
         flat = out.cpu().numpy()
         gm = np.zeros((nv, nv))
-        gm[np.triu_indices(nv)] = flat
+        gm[np.triu_indices(nv)] = flat[:npairs]
         gm = gm + np.triu(gm, 1).T
-        return gm[:c, :c], gm[c:, c:], gm[c:, :c], r
+        # W'Z r for r = Z (b + W wco): from the matrix and the products with b
+        wtzr = flat[npairs:] + gm @ wco
+        return gm[:c, :c], gm[c:, c:], gm[c:, :c], r, wtzr
 
     def _masked_grams_one_pass(self, ws_list, wy_list, free):
         """All entries from ONE pass over the 2c vectors (nsol_lb_masked_gram_*)."""

@@ -1441,6 +1441,11 @@ def test_gram_pass_also_forms_the_reduced_gradient(nsol, dtype, c, n):
     for a, b in zip(fused[:3], grams):
         assert np.abs(a - b).max() <= 1e-12 * (np.abs(b).max() + 1e-300)
     assert torch.equal(fused[3], r_ref)
+    # [Y S]'Z r from the matrix and the products with the base part of r, against the
+    # pass of its own (which sees r rounded to the working precision)
+    wtzr_ref = np.asarray(be.dots(wy + ws, r_ref, free))
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    assert np.abs(fused[4] - wtzr_ref).max() <= tol * (np.abs(wtzr_ref).max() + 1e-300)
     # lengths the LDS-DMA staged kernel does not take: the caller's two-step path
     if n % 16 == 0:
         m = n - 3
@@ -1523,11 +1528,13 @@ def test_device_lbfgsb_same_iterates_with_and_without_the_fused_step(nsol):
         outs = []
         for fused in (True, False):
             lbfgsb.FUSE_SUBSPACE_STEP = fused
+            lbfgsb.USE_GRAM_RHS = fused
             try:
                 outs.append(lbfgsb.minimize(fg, x0, lo, hi, DeviceBackend(),
                                             maxiter=iters))
             finally:
                 lbfgsb.FUSE_SUBSPACE_STEP = True
+                lbfgsb.USE_GRAM_RHS = True
         (xa, ia), (xb, ib) = outs
         assert ia["nit"] == ib["nit"] and ia["nfev"] == ib["nfev"]
         assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-10
