@@ -155,8 +155,8 @@ def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
     return x, istop, itn
 
 
-# lsmr_fused keeps every Golub-Kahan vector v_k (the update writes v_{k+1} into the
-# buffer A^T u came in) and assembles x = sum_k a_k v_k in ONE pass at the end: h,
+# lsmr_fused keeps every Golub-Kahan vector v_k (the update writes v_{k+1} into a
+# buffer of its own) and assembles x = sum_k a_k v_k in ONE pass at the end: h,
 # hbar and x are linear combinations of the v_k whose coefficients follow SciPy's
 # recurrences (lsmr.py:352-364) on the host, so the 28 bytes per element and
 # iteration of that update (a quarter of an iteration's traffic) are not moved at
@@ -165,12 +165,6 @@ def lsmr(matvec, rmatvec, b_parts, x_like, maxiter, atol=0.0, btol=0.0,
 DEFER_X = True
 DEFER_X_BYTES = 48 << 30
 _MAX_COMBINED = 40           # vectors one nsol_lb_wcomb_* launch combines
-
-
-def _aliases(t, *others):
-    p = t.untyped_storage().data_ptr()
-    return any(o is not None and o.untyped_storage().data_ptr() == p
-               for o in others)
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
@@ -195,14 +189,17 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     x = None if defer else torch.zeros_like(x_like)
     beta = normb
     su = beta if beta > 0 else 1.0
+    vts, svs = [], []
 
     def next_v(atu, v_old, c_atu, c_btu, c_v):
-        """(new vt, its squared norm): into A^T u's own buffer when every v_k is
-        kept (unless the caller's operator handed back one of our vectors)."""
+        """(new vt, its squared norm).  When every v_k is kept the new vector
+        goes to a buffer of its own (the same bytes move as for the update in
+        place) -- never into the one A^T u came in: a caller's operator may hand
+        back its argument or a buffer it reuses from call to call."""
         if not defer:
             return v_old, ops.lsmr_v_update(atu, ub, v_old, bmode, shape, w,
                                             c_atu, c_btu, c_v)
-        out = torch.empty_like(x_like) if _aliases(atu, ut, ub, v_old) else atu
+        out = torch.empty_like(x_like)
         return out, ops.lsmr_v_update(atu, ub, v_old, bmode, shape, w, c_atu,
                                       c_btu, c_v, out=out)
 
@@ -210,10 +207,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         # vt = A^T ut + sa B^T ub  (raw, = su * A^T u)
         atu = A_adj(ut)
         if defer:
-            out = torch.empty_like(x_like) if _aliases(atu, ut, ub) else atu
-            nv2 = ops.lsmr_v_update(atu, ub, atu, bmode, shape, w, 1.0, sa, 0.0,
-                                    out=out)
-            vt = out
+            vt, nv2 = next_v(atu, atu, 1.0, sa, 0.0)
         else:
             vt, nv2 = next_v(atu, torch.zeros_like(x_like), 1.0, sa, 0.0)
         alpha = math.sqrt(nv2) / su
@@ -222,7 +216,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         alpha = 0.0
     sv = su * alpha if alpha > 0 else 1.0
     if defer:
-        vts, svs = [vt], [sv]
+        vts.append(vt)
+        svs.append(sv)
         h_c = np.zeros(maxiter + 1)          # h, hbar, x over the normalised v_k
         hb_c = np.zeros(maxiter + 1)
         x_c = np.zeros(maxiter + 1)

@@ -889,6 +889,43 @@ def test_scaled_data_term_is_remembered_until_it_changes(nsol):
     assert d.dtype == torch.float64 and torch.equal(d, b.double() / 4.0)
 
 
+def test_lsmr_keeps_its_vectors_apart_whatever_the_operator_returns(nsol):
+    """lsmr_fused writes v_{k+1} into the buffer A^T u came in and keeps every
+    v_k.  An operator that hands back its argument (the identity) or a buffer it
+    reuses from call to call must not make two stored vectors share memory: same
+    solution as with x carried through the iterations."""
+    import torch
+    import nsol_amd.lsmr as L
+    from nsol_amd import ops
+    n = 4096
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    b = torch.randn(n, device="cuda", dtype=torch.float64, generator=gen)
+    b2 = torch.randn(n, device="cuda", dtype=torch.float64, generator=gen)
+    dvec = 0.5 + torch.rand(n, device="cuda", dtype=torch.float64, generator=gen)
+    scratch = [torch.empty_like(b), torch.empty_like(b)]
+    calls = [0]
+
+    def pingpong(v):                       # a diagonal operator with two reused outputs
+        out = scratch[calls[0] % 2]
+        calls[0] += 1
+        torch.mul(v, dvec, out=out)
+        return out
+    for A in (lambda v: v, pingpong, lambda v: v * dvec):
+        outs = []
+        for defer in (True, False):
+            L.DEFER_X = defer
+            try:
+                # [A; 0.7 grad] x = [b; b']: not solved by one step even for A = I
+                x, istop, itn = L.lsmr_fused(A, A, b.clone(), b2.clone(), ops.B_GRAD,
+                                             (n,), (1.0, 1.0, 1.0), 0.7,
+                                             torch.empty_like(b), 8)
+            finally:
+                L.DEFER_X = True
+            outs.append(x.clone())
+        assert float((outs[0] - outs[1]).abs().max()) <= 1e-11 * float(outs[1].abs().max())
+        assert float(outs[0].abs().max()) > 0
+
+
 def test_foreign_numpy_callables_take_the_host_bridge(nsol, golden):
     """A caller may still pass plain NumPy lambdas (the reference contract)."""
     import nsol_amd.primal_dual_solver as pd
