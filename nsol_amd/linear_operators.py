@@ -197,15 +197,18 @@ class ConvolutionOperator(DeviceOperator):
                 and p[0][1].size % 2 == 1
                 and all(c == t.size // 2 for _, t, c in p))
 
-    def apply_axpby(self, x, io, in_shape, ca, cb):
+    def apply_axpby(self, x, io, in_shape, ca, cb, result=None):
         """io = ca * A(x) + cb * io in place with the sum of squares of the
         result (flat device tensors; the top block of LSMR's u update as the
-        epilogue of the one-pass blur).  None when that kernel does not apply."""
+        epilogue of the one-pass blur).  None when that kernel does not apply.
+        result: the caller's one-element float64 device tensor for the sum (then
+        nothing is read back)."""
         if not (USE_FUSED_BLUR3 and USE_BLUR_EPILOGUE and self._passes and
                 len(in_shape) == 3 and self._fusable3()):
             return None
         return ops.corr3_wrap_axpby(x, io, in_shape, self._passes[0][1],
-                                    self._passes[1][1], self._passes[2][1], ca, cb)
+                                    self._passes[1][1], self._passes[2][1], ca, cb,
+                                    result=result)
 
     def _apply(self, x, in_shape):
         if len(in_shape) != self.dimension:

@@ -190,6 +190,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     beta = normb
     su = beta if beta > 0 else 1.0
     vts, svs = [], []
+    slots = torch.zeros(2, dtype=torch.float64, device=x_like.device)
 
     def next_v(atu, v_old, c_atu, c_btu, c_v):
         """(new vt, its squared norm).  When every v_k is kept the new vector
@@ -243,21 +244,26 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
 
     while itn < maxiter:
         itn += 1
-        # ut <- A v - alpha u   (v = vt/sv, u = ut/su)
-        top2 = None
+        # ut <- A v - alpha u   (v = vt/sv, u = ut/su).  The two sums of squares
+        # stay on the device until A^T ut -- which needs no scalar -- is enqueued:
+        # one read-back for both, hidden behind that blur
+        top = None
         if A_axpby is not None and bmode != ops.B_NONE:
-            top2 = A_axpby(vt, ut, 1.0 / sv, -alpha / su)
-        if top2 is not None:
-            nu2 = top2 + ops.lsmr_u_update(None, vt, ut, ub, bmode, shape, w,
-                                           1.0 / sv, sa / sv, -alpha / su)
+            top = A_axpby(vt, ut, 1.0 / sv, -alpha / su, result=slots[0:1])
+        if top is not None:
+            ops.lsmr_u_update(None, vt, ut, ub, bmode, shape, w, 1.0 / sv,
+                              sa / sv, -alpha / su, result=slots[1:2])
         else:
-            nu2 = ops.lsmr_u_update(A(vt), vt, ut, ub, bmode, shape, w, 1.0 / sv,
-                                    sa / sv, -alpha / su)
+            ops.lsmr_u_update(A(vt), vt, ut, ub, bmode, shape, w, 1.0 / sv,
+                              sa / sv, -alpha / su, result=slots[1:2])
+        atu = A_adj(ut)
+        sums = slots.cpu()
+        nu2 = float(sums[1]) + (float(sums[0]) if top is not None else 0.0)
         beta = math.sqrt(nu2)
         su = beta if beta > 0 else 1.0
         if beta > 0:
             # vt <- A^T u - beta v
-            vt, nv2 = next_v(A_adj(ut), vt, 1.0 / beta, sa / beta, -beta / sv)
+            vt, nv2 = next_v(atu, vt, 1.0 / beta, sa / beta, -beta / sv)
             alpha = math.sqrt(nv2)
             sv = alpha if alpha > 0 else 1.0
             if defer:

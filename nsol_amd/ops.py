@@ -160,10 +160,13 @@ def corr3_wrap(x, shape, taps_z, taps_y, taps_x, out=None):
     return out
 
 
-def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True):
+def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True,
+                     result=None):
     """io = ca * blur(x) + cb * io in place (the blur's epilogue; A x never goes
     to memory); returns the sum of squares of the new io, or None when the
-    LDS-DMA staged kernel does not apply (nothing was launched)."""
+    LDS-DMA staged kernel does not apply (nothing was launched).  result: a
+    one-element float64 device tensor of the caller's that receives the sum
+    instead (returned as it is, not read back)."""
     _same(x, io)
     _, nz, ny, nx = dims3(shape)
     tz, ty, tx = (np.ascontiguousarray(t, dtype=np.float64)
@@ -171,6 +174,8 @@ def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True):
     if not (tz.size == ty.size == tx.size):
         return None
     ws, res = _workspace(x.device)
+    if result is not None:
+        res, sync = result, False
     rc = _fn("corr3_wrap_axpby", x)(
         _p(x), _p(io), nz, ny, nx, tz.ctypes.data, ty.ctypes.data, tx.ctypes.data,
         int(tz.size), float(ca), float(cb), _p(res), _p(ws), int(ws.numel()),
@@ -663,7 +668,7 @@ def _bgeom(bmode, shape, w, n):
 
 
 def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
-                  sync=True):
+                  sync=True, result=None):
     """u_top = c_av*Av + c_u*u_top; u_bot = c_bv*B(v) + c_u*u_bot;
     returns ||[u_top; u_bot]||^2 (sync=False: the device scalar, not read
     back)."""
@@ -681,6 +686,8 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
                              "expected %d" % (u_bot.numel(), rows))
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, nn)
     ws, res = _workspace(u_top.device)
+    if result is not None:       # the caller's slot: not read back here
+        res, sync = result, False
     _lib.check(_fn("lsmr_u_update", u_top)(
         _p(Av_ptr), _p(v), _p(u_top), _p(u_bot), int(bmode), ndim, nz, ny, nx,
         w[0], w[1], w[2], float(c_av), float(c_bv), float(c_u), _p(res),

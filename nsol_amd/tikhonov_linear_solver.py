@@ -179,7 +179,8 @@ class TikhonovLinearSolver(LinearSolver):
         op, shape = d[1], tuple(d[2])
         if not hasattr(op, "apply_axpby"):
             return None
-        return lambda v, io, ca, cb: op.apply_axpby(v, io, shape, ca, cb)
+        return lambda v, io, ca, cb, result=None: op.apply_axpby(
+            v, io, shape, ca, cb, result=result)
 
     def _fused_lsmr_setup(self, x0):
         """Arguments for lsmr_fused when the regulariser operator is
