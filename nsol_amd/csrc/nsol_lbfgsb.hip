@@ -848,38 +848,60 @@ int masked_gram_impl(const T *const *vecs, int nvec, const int8_t *iwhere, int64
 }
 
 // ---- Cauchy set-up: classify, d = -g on moving variables, breakpoints
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_cauchy_setup(
     const T *__restrict__ x, const T *__restrict__ g, int64_t n, T lo, T hi,
     bool has_lo, bool has_hi, int8_t *iw, T *__restrict__ d,
     T *__restrict__ tbk, double *ws) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  typedef int8_t M __attribute__((ext_vector_type(VEC)));
   double a[4] = {0.0, 0.0, 0.0, 0.0};  // sum d^2, #breakpoints, #unbounded movers, #movers
   const T inf = (T)INFINITY;
-  GRID_STRIDE(i, n) {
-    const T neg = -g[i];
-    int w = iw[i];
-    const T tl = has_lo ? x[i] - lo : inf;
-    const T tu = has_hi ? hi - x[i] : inf;
-    if (w != 3 && w != -1) {
-      const bool xlower = has_lo && tl <= T(0);
-      const bool xupper = has_hi && tu <= T(0);
-      w = 0;
-      if (xlower) { if (neg <= T(0)) w = 1; }
-      else if (xupper) { if (neg >= T(0)) w = 2; }
-      else if (t_abs(neg) <= T(0)) w = -3;
-      iw[i] = (int8_t)w;
+  const int64_t nv = n / VEC;
+  GRID_STRIDE(j, nv) {
+    V xv, gv, dv, tv;
+    M wv;
+    if constexpr (VEC == 1) {
+      xv[0] = x[j]; gv[0] = g[j]; wv[0] = iw[j];
+    } else {
+      xv = reinterpret_cast<const V *>(x)[j];
+      gv = reinterpret_cast<const V *>(g)[j];
+      wv = reinterpret_cast<const M *>(iw)[j];
     }
-    T di = T(0), tb = inf;
-    if (w == 0 || w == -1) {
-      di = neg;
-      a[0] += (double)neg * (double)neg;
-      a[3] += 1.0;
-      if (has_lo && neg < T(0)) { tb = tl / (-neg); a[1] += 1.0; }
-      else if (has_hi && neg > T(0)) { tb = tu / neg; a[1] += 1.0; }
-      else if (t_abs(neg) > T(0)) a[2] += 1.0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const T neg = -gv[e];
+      int w = wv[e];
+      const T tl = has_lo ? xv[e] - lo : inf;
+      const T tu = has_hi ? hi - xv[e] : inf;
+      if (w != 3 && w != -1) {
+        const bool xlower = has_lo && tl <= T(0);
+        const bool xupper = has_hi && tu <= T(0);
+        w = 0;
+        if (xlower) { if (neg <= T(0)) w = 1; }
+        else if (xupper) { if (neg >= T(0)) w = 2; }
+        else if (t_abs(neg) <= T(0)) w = -3;
+        wv[e] = (int8_t)w;
+      }
+      T di = T(0), tb = inf;
+      if (w == 0 || w == -1) {
+        di = neg;
+        a[0] += (double)neg * (double)neg;
+        a[3] += 1.0;
+        if (has_lo && neg < T(0)) { tb = tl / (-neg); a[1] += 1.0; }
+        else if (has_hi && neg > T(0)) { tb = tu / neg; a[1] += 1.0; }
+        else if (t_abs(neg) > T(0)) a[2] += 1.0;
+      }
+      dv[e] = di;
+      tv[e] = tb;
     }
-    d[i] = di;
-    tbk[i] = tb;
+    if constexpr (VEC == 1) {
+      iw[j] = wv[0]; d[j] = dv[0]; tbk[j] = tv[0];
+    } else {
+      reinterpret_cast<M *>(iw)[j] = wv;
+      reinterpret_cast<V *>(d)[j] = dv;
+      reinterpret_cast<V *>(tbk)[j] = tv;
+    }
   }
   block_partials<4>(a, ws, false);
 }
@@ -1468,11 +1490,22 @@ int nsol_lb_masked_gram_rgrad_f64(const double *const *vecs, int nvec,
                                  double *result, double *ws, void *s) {          \
     if (n < 1 || !x || !g || !iwhere || !d || !tbk || !result || !ws)            \
       return NSOL_EINVAL;                                                        \
-    const int gr = rgrid(n);                                                     \
-    hipLaunchKernelGGL(k_cauchy_setup<T>, dim3(gr), dim3(kBlock), 0,             \
-                       as_stream(s), x, g, n, cast_bound<T>(lo),                 \
-                       cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY, iwhere, \
-                       d, tbk, ws);                                              \
+    constexpr int VW = 16 / sizeof(T);                                           \
+    const bool vec = n % VW == 0 &&                                              \
+        !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) |     \
+           reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(tbk)) & 15) && \
+        !(reinterpret_cast<uintptr_t>(iwhere) & (VW - 1));                       \
+    const int gr = rgrid(vec ? n / VW : n);                                      \
+    if (vec)                                                                     \
+      hipLaunchKernelGGL((k_cauchy_setup<T, VW>), dim3(gr), dim3(kBlock), 0,     \
+                         as_stream(s), x, g, n, cast_bound<T>(lo),               \
+                         cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY,       \
+                         iwhere, d, tbk, ws);                                    \
+    else                                                                         \
+      hipLaunchKernelGGL((k_cauchy_setup<T, 1>), dim3(gr), dim3(kBlock), 0,      \
+                         as_stream(s), x, g, n, cast_bound<T>(lo),               \
+                         cast_bound<T>(hi), lo > -INFINITY, hi < INFINITY,       \
+                         iwhere, d, tbk, ws);                                    \
     hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(s), ws, gr,  \
                        4, false, result);                                        \
     return launch_status();                                                      \
