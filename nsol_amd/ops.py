@@ -318,11 +318,15 @@ def norm2(x):
     return float(np.sqrt(dot(x, x)))
 
 
-def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None, minus=None):
+def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None, minus=None,
+                   result=None):
     """(0.5*sum rho(r^2), rho'(r^2)*r); with `minus` the residual is r - minus,
-    formed in the same pass."""
+    formed in the same pass.  result: the caller's one-element float64 device
+    tensor for the cost (then nothing is read back and it is returned as it is)."""
     _chk(r)
     ws, res = _workspace(r.device)
+    if result is not None:
+        res = result
     g = None
     if want_grad:
         g = empty_like(r) if out is None else out
@@ -335,22 +339,24 @@ def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None, minus=None):
         _lib.check(_fn("loss_residual_cost_grad", r)(
             _p(r), _p(minus), _p(g), r.numel(), LOSSES[loss], float(f_scale),
             _p(res), _p(ws), stream_ptr()), "nsol_loss_residual_cost_grad")
-    return float(res.item()), g
+    return (res if result is not None else float(res.item())), g
 
 
-def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None):
+def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None, result=None):
     """(sum |grad x|^2, g + alpha * grad_adj(grad x)) in one pass over x
     (the regulariser's share of tikhonov_linear_solver.py:201-208 with
-    B = gradient).  out may be g."""
+    B = gradient).  out may be g.  result: as in loss_cost_grad."""
     _same(x, g)
     ndim, nz, ny, nx = dims3(shape)
     if out is None:
         out = empty_like(g)
     ws, res = _workspace(x.device)
+    if result is not None:
+        res = result
     _lib.check(_fn("tk1_reg_cost_grad", x)(
         _p(x), _p(g), _p(out), ndim, nz, ny, nx, w[0], w[1], w[2], float(alpha),
         _p(res), _p(ws), stream_ptr()), "nsol_tk1_reg_cost_grad")
-    return float(res.item()), out
+    return (res if result is not None else float(res.item())), out
 
 
 _ws8 = {}

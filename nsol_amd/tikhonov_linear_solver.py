@@ -289,21 +289,34 @@ class TikhonovLinearSolver(LinearSolver):
         native = self._native_gradient(b.numel()) \
             if use_reg and USE_FUSED_TK1_REG else None
 
+        slots = []
+
         def fun_and_grad(x):
             r = A(x)
             # in place unless A handed x itself back (an identity operator)
             own = r.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()
+            if native is not None:
+                # B = gradient, B_adj its adjoint: 1/2||Bx||^2 and B_adj(Bx)
+                # from one pass over x (same values as the branch below).  The
+                # two sums wait in device slots until all four kernels are
+                # enqueued: one read-back instead of two, behind them
+                import torch
+                if not slots:
+                    slots.append(torch.empty(2, dtype=torch.float64,
+                                             device=r.device))
+                _, g = ops.loss_cost_grad(r, loss, fscale,
+                                          out=r if own else None, minus=b,
+                                          result=slots[0][0:1])
+                grad = A_adj(g)
+                shape, w = native
+                _, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
+                                                out=grad, result=slots[0][1:2])
+                sums = slots[0].cpu()
+                return float(sums[0]) + alpha * (0.5 * float(sums[1])), grad
             cost, g = ops.loss_cost_grad(r, loss, fscale, out=r if own else None,
                                          minus=b)
             grad = A_adj(g)
-            if native is not None:
-                # B = gradient, B_adj its adjoint: 1/2||Bx||^2 and B_adj(Bx)
-                # from one pass over x (same values as the branch below)
-                shape, w = native
-                e, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
-                                                out=grad)
-                cost = cost + alpha * (0.5 * e)
-            elif use_reg:
+            if use_reg:
                 Bx = B(x)
                 # reference quirk kept: 1/2||Bx||^2, b_reg is ignored here
                 cost = cost + alpha * (0.5 * ops.dot(Bx, Bx))
