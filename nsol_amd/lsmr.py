@@ -167,6 +167,31 @@ DEFER_X_BYTES = 48 << 30
 _MAX_COMBINED = 40           # vectors one nsol_lb_wcomb_* launch combines
 
 
+class SolutionCoefficients(object):
+    """h, hbar and x of SciPy's loop (lsmr.py:352-364) as coefficient vectors over
+    the normalised Golub-Kahan vectors v_1 .. v_K:
+        hbar <- h + c_hbar * hbar ;  x <- x + c_x * hbar ;  h <- v_new + c_h * h
+    with h_1 = v_1, hbar_0 = x_0 = 0.  `newest` is the index of v_new among the
+    kept vectors (the last one; unchanged when the bidiagonalisation broke down
+    and no new vector was formed)."""
+
+    def __init__(self, capacity):
+        self.h = np.zeros(capacity)
+        self.hbar = np.zeros(capacity)
+        self.x = np.zeros(capacity)
+        self.h[0] = 1.0
+
+    def step(self, c_hbar, c_x, c_h, newest):
+        self.hbar = self.h + c_hbar * self.hbar
+        self.x = self.x + c_x * self.hbar
+        self.h = c_h * self.h
+        self.h[newest] += 1.0
+
+    def normx2(self):
+        """||x||^2 for orthonormal v_k."""
+        return float(np.dot(self.x, self.x))
+
+
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
@@ -219,10 +244,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     if defer:
         vts.append(vt)
         svs.append(sv)
-        h_c = np.zeros(maxiter + 1)          # h, hbar, x over the normalised v_k
-        hb_c = np.zeros(maxiter + 1)
-        x_c = np.zeros(maxiter + 1)
-        h_c[0] = 1.0
+        coef = SolutionCoefficients(maxiter + 1)
 
     itn = 0
     zetabar = alpha * beta
@@ -289,11 +311,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
             # hbar = h + c_hbar hbar; x += c_x hbar; h = v_new + c_h h -- on the
             # coefficients; ||x||^2 = sum a_k^2 for orthonormal v_k (it only enters
             # the stopping test that fires when the residual is exactly zero)
-            hb_c = h_c + c_hbar * hb_c
-            x_c = x_c + c_x * hb_c
-            h_c = c_h * h_c
-            h_c[len(vts) - 1] += 1.0
-            normx2 = float(np.dot(x_c, x_c))
+            coef.step(c_hbar, c_x, c_h, len(vts) - 1)
+            normx2 = coef.normx2()
         else:
             normx2 = ops.lsmr_hx_update(hbar, x, h, vt, c_hbar, c_x, c_h,
                                         1.0 / sv)
@@ -343,5 +362,5 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         if istop > 0:
             break
     if defer:
-        x = ops.lincomb_many(vts, [x_c[j] / svs[j] for j in range(len(vts))])
+        x = ops.lincomb_many(vts, [coef.x[j] / svs[j] for j in range(len(vts))])
     return x, istop, itn

@@ -420,3 +420,32 @@ def test_persistent_kernel_tiling_rules():
     assert ops.persist_pays((1024, 1024), 100)
     assert not ops.persist_pays((64, 64, 64), 8)    # too few iterations
     assert not ops.persist_pays((128, 128, 128), 100)   # K = 3 kernel's range
+
+
+def test_lsmr_solution_coefficients_follow_the_vector_recurrences():
+    """lsmr_fused assembles x = sum_k a_k v_k once at the end instead of carrying
+    h, hbar and x through every iteration (SciPy lsmr.py:352-364): the coefficient
+    recurrences against the vector recurrences on random data, with a breakdown
+    step (no new vector) in between."""
+    import sys
+    sys.modules.setdefault("torch", __import__("torch"))
+    from nsol_amd.lsmr import SolutionCoefficients
+    rng = np.random.default_rng(4)
+    n, K = 50, 9
+    V = rng.standard_normal((K + 1, n))
+    coef = SolutionCoefficients(K + 1)
+    h, hbar, x = V[0].copy(), np.zeros(n), np.zeros(n)
+    newest = 0
+    for k in range(K):
+        c_hbar, c_x, c_h = rng.standard_normal(3)
+        if k != 4:
+            newest += 1                       # (k == 4: breakdown, v stays)
+        hbar = h + c_hbar * hbar
+        x = x + c_x * hbar
+        h = V[newest] + c_h * h
+        coef.step(c_hbar, c_x, c_h, newest)
+        assert np.allclose(coef.x @ V, x, rtol=1e-12, atol=1e-12)
+        assert np.allclose(coef.h @ V, h, rtol=1e-12, atol=1e-12)
+        assert np.allclose(coef.hbar @ V, hbar, rtol=1e-12, atol=1e-12)
+    Q, _ = np.linalg.qr(V.T)                  # orthonormal columns: ||x||^2 = sum a^2
+    assert np.isclose(coef.normx2(), np.sum((Q @ coef.x) ** 2))
