@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
     {
     T a[VEC], u[VEC];
     if (Av) {      // (null: the top block was updated elsewhere -- the blur's epilogue)
-      vl<RAG, T, VEC>(c.nval, Av + c.i, a);
-      vl<RAG, T, VEC>(c.nval, u_top + c.i, u);
+      vlc<RAG, T, VEC>(c, Av + c.i, a);
+      vlc<RAG, T, VEC>(c, u_top + c.i, u);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         u[k] = c_av * a[k] + c_u * u[k];
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
       vs<RAG, T, VEC>(c.nval, u_top + c.i, u);
     }
     if (bmode == kBIdentity) {
-      vl<RAG, T, VEC>(c.nval, v + c.i, a);
-      vl<RAG, T, VEC>(c.nval, u_bot + c.i, u);
+      vlc<RAG, T, VEC>(c, v + c.i, a);
+      vlc<RAG, T, VEC>(c, u_bot + c.i, u);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         u[k] = c_bv * a[k] + c_u * u[k];
@@ -119,21 +119,21 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_u(
       vs<RAG, T, VEC>(c.nval, u_bot + c.i, u);
     } else if (bmode == kBGrad) {
       T vc[VEC], hi[VEC], d[VEC];
-      vl<RAG, T, VEC>(c.nval, v + c.i, vc);
+      vlc<RAG, T, VEC>(c, v + c.i, vc);
       for (int dir = 0; dir < G.ndim; ++dir) {
         if (dir == 0) {
           const T right = (c.ix + VEC < G.nx) ? v[c.i + VEC] : T(0);
           fwd_diff_x<T, VEC>(vc, right, G.wx, d);
         } else if (dir == 1) {
           vzero(hi);
-          if (c.iy + 1 < G.ny) vl<RAG, T, VEC>(c.nval, v + c.i + G.sy, hi);
+          if (c.iy + 1 < G.ny) vlc<RAG, T, VEC>(c, v + c.i + G.sy, hi);
           fwd_diff<T, VEC>(vc, hi, G.wy, d);
         } else {
           vzero(hi);
-          if (c.iz + 1 < G.nz) vl<RAG, T, VEC>(c.nval, v + c.i + G.sz, hi);
+          if (c.iz + 1 < G.nz) vlc<RAG, T, VEC>(c, v + c.i + G.sz, hi);
           fwd_diff<T, VEC>(vc, hi, G.wz, d);
         }
-        vl<RAG, T, VEC>(c.nval, u_bot + dir * G.n + c.i, u);
+        vlc<RAG, T, VEC>(c, u_bot + dir * G.n + c.i, u);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           u[k] = c_bv * d[k] + c_u * u[k];
@@ -162,16 +162,16 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_v(
     if (!c.ok) continue;
     {
     T val[VEC], t[VEC], lo[VEC];
-    vl<RAG, T, VEC>(c.nval, Atu + c.i, t);
+    vlc<RAG, T, VEC>(c, Atu + c.i, t);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) val[k] = c_atu * t[k];
     if (bmode == kBIdentity) {
-      vl<RAG, T, VEC>(c.nval, u_bot + c.i, t);
+      vlc<RAG, T, VEC>(c, u_bot + c.i, t);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) val[k] += c_btu * t[k];
     } else if (bmode == kBGrad) {
       T kt[VEC];
-      vl<RAG, T, VEC>(c.nval, u_bot + c.i, t);
+      vlc<RAG, T, VEC>(c, u_bot + c.i, t);
       const T left = (c.ix > 0) ? u_bot[c.i - 1] : T(0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -180,24 +180,24 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_v(
       }
       if (G.ndim >= 2) {
         const T *py = u_bot + G.n;
-        vl<RAG, T, VEC>(c.nval, py + c.i, t);
+        vlc<RAG, T, VEC>(c, py + c.i, t);
         vzero(lo);
-        if (c.iy > 0) vl<RAG, T, VEC>(c.nval, py + c.i - G.sy, lo);
+        if (c.iy > 0) vlc<RAG, T, VEC>(c, py + c.i - G.sy, lo);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) kt[k] += t[k] * (-G.wy) + lo[k] * G.wy;
       }
       if (G.ndim >= 3) {
         const T *pz = u_bot + 2 * G.n;
-        vl<RAG, T, VEC>(c.nval, pz + c.i, t);
+        vlc<RAG, T, VEC>(c, pz + c.i, t);
         vzero(lo);
-        if (c.iz > 0) vl<RAG, T, VEC>(c.nval, pz + c.i - G.sz, lo);
+        if (c.iz > 0) vlc<RAG, T, VEC>(c, pz + c.i - G.sz, lo);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) kt[k] += t[k] * (-G.wz) + lo[k] * G.wz;
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) val[k] += c_btu * kt[k];
     }
-    vl<RAG, T, VEC>(c.nval, v + c.i, t);
+    vlc<RAG, T, VEC>(c, v + c.i, t);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       val[k] += c_v * t[k];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
     T v[VEC], nb[VEC], d[VEC], dp[VEC], out[VEC];
-    vl<RAG, T, VEC>(c.nval, x + c.i, v);
+    vlc<RAG, T, VEC>(c, x + c.i, v);
     // x: forward differences at the lane's voxels and at the voxel to the left
     const T right = (c.ix + VEC < G.nx) ? x[c.i + VEC] : T(0);
     fwd_diff_x<T, VEC>(v, right, G.wx, d);
@@ -261,11 +261,11 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     }
     if (G.ndim >= 2) {
       vzero(nb);
-      if (c.iy + 1 < G.ny) vl<RAG, T, VEC>(c.nval, x + c.i + G.sy, nb);
+      if (c.iy + 1 < G.ny) vlc<RAG, T, VEC>(c, x + c.i + G.sy, nb);
       fwd_diff<T, VEC>(v, nb, G.wy, d);
       vzero(dp);
       if (c.iy > 0) {
-        vl<RAG, T, VEC>(c.nval, x + c.i - G.sy, nb);
+        vlc<RAG, T, VEC>(c, x + c.i - G.sy, nb);
         fwd_diff<T, VEC>(nb, v, G.wy, dp);
       }
 #pragma unroll
@@ -276,11 +276,11 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     }
     if (G.ndim >= 3) {
       vzero(nb);
-      if (c.iz + 1 < G.nz) vl<RAG, T, VEC>(c.nval, x + c.i + G.sz, nb);
+      if (c.iz + 1 < G.nz) vlc<RAG, T, VEC>(c, x + c.i + G.sz, nb);
       fwd_diff<T, VEC>(v, nb, G.wz, d);
       vzero(dp);
       if (c.iz > 0) {
-        vl<RAG, T, VEC>(c.nval, x + c.i - G.sz, nb);
+        vlc<RAG, T, VEC>(c, x + c.i - G.sz, nb);
         fwd_diff<T, VEC>(nb, v, G.wz, dp);
       }
 #pragma unroll
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
         if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
       }
     }
-    vl<RAG, T, VEC>(c.nval, g + c.i, nb);
+    vlc<RAG, T, VEC>(c, g + c.i, nb);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) out[k] = T(1) * nb[k] + alpha * out[k];
     vs<RAG, T, VEC>(c.nval, grad + c.i, out);

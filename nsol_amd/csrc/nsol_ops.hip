@@ -22,19 +22,19 @@ __global__ __launch_bounds__(kBlock) void k_grad(const T *__restrict__ x,
   const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
   if (!c.ok) continue;
   T v[VEC], hi[VEC], d[VEC];
-  vl<RAG, T, VEC>(c.nval, x + c.i, v);
+  vlc<RAG, T, VEC>(c, x + c.i, v);
   const T right = (c.ix + VEC < G.nx) ? x[c.i + VEC] : T(0);
   fwd_diff_x<T, VEC>(v, right, G.wx, d);
   vs<RAG, T, VEC>(c.nval, g + c.i, d);
   if (G.ndim >= 2) {
     vzero(hi);
-    if (c.iy + 1 < G.ny) vl<RAG, T, VEC>(c.nval, x + c.i + G.sy, hi);
+    if (c.iy + 1 < G.ny) vlc<RAG, T, VEC>(c, x + c.i + G.sy, hi);
     fwd_diff<T, VEC>(v, hi, G.wy, d);
     vs<RAG, T, VEC>(c.nval, g + G.n + c.i, d);
   }
   if (G.ndim >= 3) {
     vzero(hi);
-    if (c.iz + 1 < G.nz) vl<RAG, T, VEC>(c.nval, x + c.i + G.sz, hi);
+    if (c.iz + 1 < G.nz) vlc<RAG, T, VEC>(c, x + c.i + G.sz, hi);
     fwd_diff<T, VEC>(v, hi, G.wz, d);
     vs<RAG, T, VEC>(c.nval, g + 2 * G.n + c.i, d);
   }
@@ -48,7 +48,7 @@ __device__ __forceinline__ void grad_adj_vec(const T *__restrict__ p,
                                              const Geom<T> &G, const Voxel &c,
                                              T (&acc)[VEC]) {
   T v[VEC], lo[VEC];
-  vl<RAG, T, VEC>(c.nval, p + c.i, v);
+  vlc<RAG, T, VEC>(c, p + c.i, v);
   const T left = (c.ix > 0) ? p[c.i - 1] : T(0);
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
@@ -57,17 +57,17 @@ __device__ __forceinline__ void grad_adj_vec(const T *__restrict__ p,
   }
   if (G.ndim >= 2) {
     const T *py = p + G.n;
-    vl<RAG, T, VEC>(c.nval, py + c.i, v);
+    vlc<RAG, T, VEC>(c, py + c.i, v);
     vzero(lo);
-    if (c.iy > 0) vl<RAG, T, VEC>(c.nval, py + c.i - G.sy, lo);
+    if (c.iy > 0) vlc<RAG, T, VEC>(c, py + c.i - G.sy, lo);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k] * (-G.wy) + lo[k] * G.wy;
   }
   if (G.ndim >= 3) {
     const T *pz = p + 2 * G.n;
-    vl<RAG, T, VEC>(c.nval, pz + c.i, v);
+    vlc<RAG, T, VEC>(c, pz + c.i, v);
     vzero(lo);
-    if (c.iz > 0) vl<RAG, T, VEC>(c.nval, pz + c.i - G.sz, lo);
+    if (c.iz > 0) vlc<RAG, T, VEC>(c, pz + c.i - G.sz, lo);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] += v[k] * (-G.wz) + lo[k] * G.wz;
   }
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_adj(const T *__restrict__ p,
     grad_adj_vec<RAG, T, VEC>(p, G, c, acc);
     if constexpr (AXPY) {
       T xv[VEC];
-      vl<RAG, T, VEC>(c.nval, x + c.i, xv);
+      vlc<RAG, T, VEC>(c, x + c.i, xv);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] = xv[k] - tau * acc[k];
     }
@@ -214,25 +214,25 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
   if (!q.ok) continue;
   T xc[VEC], hi[VEC];
   T t[3][VEC], cc[3][VEC];
-  vl<RAG, T, VEC>(q.nval, x + q.i, xc);
+  vlc<RAG, T, VEC>(q, x + q.i, xc);
   const T right = (q.ix + VEC < G.nx) ? x[q.i + VEC] : T(0);
   fwd_diff_x<T, VEC>(xc, right, G.wx, t[0]);
   if (G.ndim >= 2) {
     vzero(hi);
-    if (q.iy + 1 < G.ny) vl<RAG, T, VEC>(q.nval, x + q.i + G.sy, hi);
+    if (q.iy + 1 < G.ny) vlc<RAG, T, VEC>(q, x + q.i + G.sy, hi);
     fwd_diff<T, VEC>(xc, hi, G.wy, t[1]);
   }
   if (G.ndim >= 3) {
     vzero(hi);
-    if (q.iz + 1 < G.nz) vl<RAG, T, VEC>(q.nval, x + q.i + G.sz, hi);
+    if (q.iz + 1 < G.nz) vlc<RAG, T, VEC>(q, x + q.i + G.sz, hi);
     fwd_diff<T, VEC>(xc, hi, G.wz, t[2]);
   }
   T n2[VEC];
   for (int a = 0; a < G.ndim; ++a) {
     T wv[VEC];
     vzero(cc[a]);
-    if (c) vl<RAG, T, VEC>(q.nval, c + a * G.n + q.i, cc[a]);
-    vl<RAG, T, VEC>(q.nval, w + a * G.n + q.i, wv);
+    if (c) vlc<RAG, T, VEC>(q, c + a * G.n + q.i, cc[a]);
+    vlc<RAG, T, VEC>(q, w + a * G.n + q.i, wv);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       t[a][k] = t[a][k] + wv[k] - cc[a][k];

@@ -52,6 +52,9 @@ struct Voxel {
   int64_t ix, iy, iz, i;
   bool ok;
   int nval;   // elements of the lane's vector that lie inside the row (VEC unless ragged)
+  bool wide;  // a whole vector may be READ at this voxel and at its forward neighbours
+              // (next row / plane) even when nval < VEC: the bytes behind the row's end
+              // belong to the same array
 };
 
 // Rows that are not a multiple of the vector width (RAG kernels): vectors start
@@ -71,6 +74,28 @@ __device__ __forceinline__ void vl(int n, const T *p, T (&v)[V]) {
     } else {
 #pragma unroll
       for (int k = 0; k < V; ++k) v[k] = k < n ? p[k] : T(0);
+    }
+  }
+}
+
+// The same load for a kernel's hot path: the row's last, partial vector is fetched
+// whole wherever that stays inside the array (everywhere but near its very end) and
+// the elements past the row are zeroed in registers -- no branch, so a wave that holds
+// a row end no longer runs the vector and the element-by-element path one after the
+// other for every operand.
+template <bool RAG, typename T, int V>
+__device__ __forceinline__ void vlc(const Voxel &c, const T *p, T (&v)[V]) {
+  if constexpr (!RAG) {
+    vload<T, V>(p, v);
+  } else {
+    if (c.nval >= V || c.wide) {
+      typedef T P __attribute__((ext_vector_type(V), aligned(sizeof(T))));
+      const P t = *reinterpret_cast<const P *>(p);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = k < c.nval ? t[k] : T(0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = k < c.nval ? p[k] : T(0);
     }
   }
 }
@@ -130,6 +155,9 @@ __device__ __forceinline__ Voxel voxel_at(const Geom<T> &G, int64_t rg) {
   c.i = (c.iz * G.ny + c.iy) * G.nx + c.ix;
   const int64_t left = G.nx - c.ix;
   c.nval = left >= VEC ? VEC : (int)left;
+  // forward neighbours are read at + sy (2-D, 3-D) and + sz (3-D)
+  const int64_t fwd = G.ndim >= 3 ? G.sz + G.sy : (G.ndim == 2 ? G.sy : 0);
+  c.wide = c.i + fwd + VEC <= G.n;
   return c;
 }
 
