@@ -497,18 +497,23 @@ def _dec_ops(golden, k):
     return g, shape, A_, Aa_, D_, Da_
 
 
-@pytest.fixture(params=["fused-lsmr", "fused-lsmr-carried-x", "generic-lsmr"])
+@pytest.fixture(params=["fused-lsmr", "fused-lsmr-bidiag", "fused-lsmr-carried-x",
+                        "generic-lsmr"])
 def lsmr_form(request):
-    """fused-lsmr: the fused kernels with x assembled once from the stored v_k;
-    -carried-x: h, hbar and x carried through every iteration (SciPy's form);
-    generic-lsmr: the operator-callable loop."""
+    """fused-lsmr: the default -- Lanczos on the normal equations where a
+    regulariser makes that safe, else as -bidiag; -bidiag: Golub-Kahan on the fused
+    kernels with x assembled once from the stored v_k; -carried-x: h, hbar and x
+    carried through every iteration (SciPy's form); generic-lsmr: the
+    operator-callable loop."""
     import nsol_amd.tikhonov_linear_solver as tk
     import nsol_amd.lsmr as lsmr_mod
     tk.USE_FUSED_LSMR = request.param != "generic-lsmr"
-    lsmr_mod.DEFER_X = request.param == "fused-lsmr"
+    lsmr_mod.USE_NORMAL_EQUATIONS = request.param == "fused-lsmr"
+    lsmr_mod.DEFER_X = request.param != "fused-lsmr-carried-x"
     yield request.param
     tk.USE_FUSED_LSMR = True
     lsmr_mod.DEFER_X = True
+    lsmr_mod.USE_NORMAL_EQUATIONS = True
 
 
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
