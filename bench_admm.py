@@ -36,7 +36,11 @@ sys.path.insert(0, ROOT)
 from bench import HipEvents, HBM_PEAK_GBPS  # noqa: E402
 
 BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
-         "k_admm_vw": 52}
+         "k_admm_vw": 52,
+         # the normal-equations form: the blur with its sum of squares (reads the io
+         # tile it overwrites), sa^2 grad^T grad y added to A^T A y with sum |grad y|^2,
+         # the three-term Lanczos update with its norm
+         "k_blur3_dma_epi": 12, "k_tk1_reg": 12, "k_lsmr_v_lanczos": 16}
 SETUP_BYTES = 156
 
 
@@ -45,13 +49,19 @@ def bytes_per_admm_iteration(iter_max):
 
 
 def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
-                                   deferred_x=True):
+                                   deferred_x=True, normal_equations=False):
     """What the kernels have to move at least with this build's fusions: the
     blur's epilogue saves the write and the read of A v (8 B per LSMR iteration),
     the pre-scaled right-hand side the scaling pass, its norm pass and the norm
     pass over b (40 B per ADMM iteration); with every v_k kept, the h / hbar / x
     update (28 B per LSMR iteration) is replaced by one pass that reads the
     iter_max + 1 stored vectors and writes x."""
+    if normal_equations:
+        # per Lanczos step: t = A y (12), A^T t (8), + sa^2 grad^T grad y (12), the
+        # three-term update (16); the right-hand side A^T b + sa B^T c once (8 + 24);
+        # x from the iter_max stored vectors; the outer step as before
+        return iter_max * 48 + 32 + 4 * (iter_max + 1) + SETUP_BYTES - 64 - \
+            (40 if prescaled_rhs else 0)
     per_it = (100 if blur_epilogue else 108) - (28 if deferred_x else 0)
     return iter_max * per_it + (4 * (iter_max + 2) if deferred_x else 0) + \
         SETUP_BYTES - (40 if prescaled_rhs else 0)
@@ -91,9 +101,18 @@ def time_kernels(shape, reps=20):
     lib_x = lambda: ops.lincomb_many(vts, [0.1 * (k + 1) for k in range(11)],
                                      out=x_out)
     BYTES["k_wcomb"] = 4 * (11 + 1)
+    slot = torch.zeros(1, dtype=torch.float64, device=dev)
+    lib_epi = lambda: ops.corr3_wrap_axpby(v, blur_out, shape, taps, taps, taps, 1.0,
+                                           0.0, result=slot)
+    lib_reg = lambda: ops.tk1_reg_cost_grad(v, Av, shape, w, 0.1, out=Av,
+                                            result=slot)
+    lib_lz = lambda: ops.lsmr_v_update(h, hbar, x, ops.B_IDENTITY, (n,), w, -0.3,
+                                       -0.2, 0.5, sync=False, out=x_out)
     for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
                      ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
-                     ("k_admm_vw", lib_vw), ("k_wcomb", lib_x)):
+                     ("k_admm_vw", lib_vw), ("k_wcomb", lib_x),
+                     ("k_blur3_dma_epi", lib_epi), ("k_tk1_reg", lib_reg),
+                     ("k_lsmr_v_lanczos", lib_lz)):
         for _ in range(3):
             fn()
         e0, e1 = ev.create(), ev.create()
@@ -234,6 +253,10 @@ def main():
                     help="scale and norm passes over LSMR's lower right-hand side "
                          "per ADMM iteration instead of taking both from the outer "
                          "step (A/B runs)")
+    ap.add_argument("--bidiag", action="store_true",
+                    help="LSMR by Golub-Kahan bidiagonalisation of the augmented "
+                         "operator (SciPy's form) instead of Lanczos on the normal "
+                         "equations (A/B runs)")
     ap.add_argument("--carried-x", action="store_true",
                     help="LSMR carries h, hbar and x through every iteration "
                          "(SciPy's form) instead of keeping every v_k and "
@@ -268,6 +291,9 @@ def main():
         import nsol_amd.lbfgsb as lb_mod
         lb_mod.USE_GRAM_RHS = False
         lb_mod.FUSE_SUBSPACE_STEP = False
+    if args.bidiag or args.carried_x:
+        import nsol_amd.lsmr as lsmr_mod
+        lsmr_mod.USE_NORMAL_EQUATIONS = False
     if args.carried_x:
         import nsol_amd.lsmr as lsmr_mod
         lsmr_mod.DEFER_X = False
@@ -336,17 +362,28 @@ def main():
                    "knobs": args.param, "blur_epilogue": not args.no_blur_epilogue,
                    "prescaled_rhs": not args.no_prescaled_rhs,
                    "lsmr_x": "carried" if args.carried_x else "assembled at the end",
+                   "lsmr_form": "bidiagonalisation" if (args.bidiag or args.carried_x)
+                   else "Lanczos on the normal equations",
                    "execution": execution},
         "rel_change_vs_input": rel_change, "finite": finite}
     if args.minimizer == "lsmr":
         kern = time_kernels(shape)
         import nsol_amd.lsmr as lsmr_mod
         deferred = bool(lsmr_mod.DEFER_X)
-        # (k_wcomb: x assembled from the iter_max + 1 stored v_k; timed for 11)
-        per_it = {"k_blur3_dma": 2 * args.iter_max + 1,
-                  "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
-                  "k_lsmr_hx": 0 if deferred else args.iter_max,
-                  "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0}
+        normal = bool(lsmr_mod.USE_NORMAL_EQUATIONS) and deferred and \
+            0.1 >= lsmr_mod.NE_MIN_WEIGHT[4] and args.iter_max <= lsmr_mod.NE_MAX_ITER
+        # (k_wcomb: x assembled from the stored vectors; timed for 11)
+        if normal:
+            per_it = {"k_blur3_dma": args.iter_max + 1, "k_blur3_dma_epi": args.iter_max,
+                      "k_tk1_reg": args.iter_max, "k_lsmr_v_lanczos": args.iter_max,
+                      "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0, "k_admm_vw": 1,
+                      "k_wcomb": 1}
+        else:
+            per_it = {"k_blur3_dma": 2 * args.iter_max + 1,
+                      "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
+                      "k_lsmr_hx": 0 if deferred else args.iter_max,
+                      "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0,
+                      "k_blur3_dma_epi": 0, "k_tk1_reg": 0, "k_lsmr_v_lanczos": 0}
         for k, c in per_it.items():
             kern[k]["launches_per_admm_iteration"] = c
             kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]
@@ -367,10 +404,10 @@ def main():
                 "bytes_moved_per_voxel_per_admm_iteration":
                     bytes_moved_per_admm_iteration(
                         args.iter_max, not args.no_blur_epilogue,
-                        not args.no_prescaled_rhs, deferred),
+                        not args.no_prescaled_rhs, deferred, normal),
                 "frac_moved": bytes_moved_per_admm_iteration(
                     args.iter_max, not args.no_blur_epilogue,
-                    not args.no_prescaled_rhs, deferred) * nvox * args.iterations / med / 1e9 /
+                    not args.no_prescaled_rhs, deferred, normal) * nvox * args.iterations / med / 1e9 /
                 HBM_PEAK_GBPS,
                 "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
                 "kernel_ms_per_admm_iteration_sum":
