@@ -547,6 +547,29 @@ int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
                                int ndim, int64_t nz, int64_t ny, int64_t nx,
                                double wx, double wy, double wz, double alpha,
                                double *result, double *ws, void *stream);
+/* The same stencil for LSMR run as Lanczos on the normal equations
+ * M = A^T A + alpha K^T K (lsmr_normal in nsol_amd/lsmr.py, behind
+ * tikhonov_linear_solver.py:146-158):
+ *   nsol_tk1_grad_norm_*: result[0] = sum |K x|^2 alone (x'K'K x of the Lanczos
+ *     coefficient alfa; nothing but x is read, nothing written);
+ *   nsol_tk1_lanczos_*:   out = c_g g + alpha K^T(K x) + c_x x + c_z z (z may be NULL)
+ *     and result[0] = sum out^2 -- the three-term recurrence
+ *     y_{j+1} = (A^T A y_j + alpha K'K y_j)/beta_j - (alfa/beta_j) y_j - (beta_j/beta_{j-1}) y_{j-1}
+ *     and beta_{j+1}^2 in one pass.  g may alias out; x and z may not. */
+int nsol_tk1_grad_norm_f32(const float *x, int ndim, int64_t nz, int64_t ny, int64_t nx,
+                           double wx, double wy, double wz, double *result, double *ws,
+                           void *stream);
+int nsol_tk1_grad_norm_f64(const double *x, int ndim, int64_t nz, int64_t ny, int64_t nx,
+                           double wx, double wy, double wz, double *result, double *ws,
+                           void *stream);
+int nsol_tk1_lanczos_f32(const float *x, const float *g, const float *z, float *out,
+                         int ndim, int64_t nz, int64_t ny, int64_t nx, double wx,
+                         double wy, double wz, double alpha, double c_g, double c_x,
+                         double c_z, double *result, double *ws, void *stream);
+int nsol_tk1_lanczos_f64(const double *x, const double *g, const double *z, double *out,
+                         int ndim, int64_t nz, int64_t ny, int64_t nx, double wx,
+                         double wy, double wz, double alpha, double c_g, double c_x,
+                         double c_z, double *result, double *ws, void *stream);
 
 /* ---------------------------------------------------------------------- *
  * Pair statistics for the evaluation measures of similarity_measures.py:26-120

@@ -238,10 +238,16 @@ __global__ __launch_bounds__(kBlock) void k_lsmr_hx(T *__restrict__ hbar,
 // robust-loss objective (tikhonov_linear_solver.py:201-208 with B = grad).
 // Every difference is rounded as k_grad stores it and combined in the order of
 // k_grad_adj and nsol_lincomb2, so grad equals the three-kernel result bit for bit.
-template <typename T, int VEC, int ROWS, bool RAG>
+template <typename T, int VEC, int ROWS, bool RAG, int MODE = 0>
 __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
                                                      const T *g, T *grad, Geom<T> G,
-                                                     T alpha, double *ws) {
+                                                     T alpha, double *ws,
+                                                     const T *z = nullptr, T c_g = T(1),
+                                                     T c_x = T(0), T c_z = T(0)) {
+  // MODE 0: grad = g + alpha K'K x, sum |K x|^2.  MODE 1: the sum only (nothing read
+  // but x, nothing written).  MODE 2: the three-term Lanczos update of the normal
+  // equations, grad = c_g g + alpha K'K x + c_x x + c_z z (z may be null) with the
+  // sum of squares of the RESULT -- one pass where MODE 0 and a combination took two.
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
   double acc = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     for (int k = 0; k < VEC; ++k) {
       const T l = (k > 0) ? d[(k + VEC - 1) % VEC] : dleft;
       out[k] = d[k] * (-G.wx) + l * G.wx;
-      if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
+      if (MODE != 2 && (!RAG || k < c.nval)) acc += (double)d[k] * (double)d[k];
     }
     if (G.ndim >= 2) {
       vzero(nb);
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         out[k] += d[k] * (-G.wy) + dp[k] * G.wy;
-        if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
+        if (MODE != 2 && (!RAG || k < c.nval)) acc += (double)d[k] * (double)d[k];
       }
     }
     if (G.ndim >= 3) {
@@ -286,12 +292,26 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         out[k] += d[k] * (-G.wz) + dp[k] * G.wz;
-        if (!RAG || k < c.nval) acc += (double)d[k] * (double)d[k];
+        if (MODE != 2 && (!RAG || k < c.nval)) acc += (double)d[k] * (double)d[k];
       }
     }
+    if constexpr (MODE == 1) continue;
     vlc<RAG, T, VEC>(c, g + c.i, nb);
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) out[k] = T(1) * nb[k] + alpha * out[k];
+      for (int k = 0; k < VEC; ++k) out[k] = T(1) * nb[k] + alpha * out[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) out[k] = c_g * nb[k] + alpha * out[k] + c_x * v[k];
+      if (z) {
+        vlc<RAG, T, VEC>(c, z + c.i, nb);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] += c_z * nb[k];
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        if (!RAG || k < c.nval) acc += (double)out[k] * (double)out[k];
+    }
     vs<RAG, T, VEC>(c.nval, grad + c.i, out);
   }
   store_partial3(acc, ws);
@@ -399,6 +419,49 @@ int tk1_reg_impl(const T *x, const T *g, T *grad, int ndim, int64_t nz, int64_t 
   });
 }
 
+// MODE 1 / 2 of k_tk1_reg (see there)
+template <typename T>
+int tk1_norm_impl(const T *x, int ndim, int64_t nz, int64_t ny, int64_t nx, double wx,
+                  double wy, double wz, double *result, double *ws, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !result || !ws) return NSOL_EINVAL;
+  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  const bool al = ptr16(x) && G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
+    hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG, 1>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), x, (const T *)nullptr,
+                       (T *)nullptr, G, T(0), ws);
+    hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
+                       nb, result);
+    return launch_status();
+  });
+}
+
+template <typename T>
+int tk1_lanczos_impl(const T *x, const T *g, const T *z, T *out, int ndim, int64_t nz,
+                     int64_t ny, int64_t nx, double wx, double wy, double wz,
+                     double alpha, double c_g, double c_x, double c_z, double *result,
+                     double *ws, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !g || !out || !result || !ws || x == out || z == out) return NSOL_EINVAL;
+  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  const bool al = ptr16(x) && ptr16(g) && ptr16(out) && (!z || ptr16(z)) && G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
+    hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG, 2>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), x, g, out, G, (T)alpha, ws, z,
+                       (T)c_g, (T)c_x, (T)c_z);
+    hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
+                       nb, result);
+    return launch_status();
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -450,4 +513,20 @@ int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
   return tk1_reg_impl<double>(x, g, grad, ndim, nz, ny, nx, wx, wy, wz, alpha, result,
                               ws, stream);
 }
+#define NSOL_TK1_DEF(T, SUF)                                                     \
+  int nsol_tk1_grad_norm_##SUF(const T *x, int ndim, int64_t nz, int64_t ny,     \
+                               int64_t nx, double wx, double wy, double wz,      \
+                               double *result, double *ws, void *stream) {       \
+    return tk1_norm_impl<T>(x, ndim, nz, ny, nx, wx, wy, wz, result, ws, stream); \
+  }                                                                              \
+  int nsol_tk1_lanczos_##SUF(const T *x, const T *g, const T *z, T *out,         \
+                             int ndim, int64_t nz, int64_t ny, int64_t nx,       \
+                             double wx, double wy, double wz, double alpha,      \
+                             double c_g, double c_x, double c_z, double *result, \
+                             double *ws, void *stream) {                         \
+    return tk1_lanczos_impl<T>(x, g, z, out, ndim, nz, ny, nx, wx, wy, wz,       \
+                               alpha, c_g, c_x, c_z, result, ws, stream);        \
+  }
+NSOL_TK1_DEF(float, f32)
+NSOL_TK1_DEF(double, f64)
 }

@@ -272,12 +272,23 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                 A_axpby=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
-    b_top / b_bot are consumed.  Returns (x, istop, itn)."""
+    b_top / b_bot are consumed.  Returns (x, istop, itn).
+
+    Per step, on the unnormalised Lanczos vector y_j (nothing here needs beta_j):
+        t = A y_j with ||t||^2            (the blur's epilogue form)
+        sum |grad y_j|^2                   (nsol_tk1_grad_norm_*; B = gradient)
+        y' = A^T t                         (the blur)
+    -- the three scalars of the step (the two sums and beta_j^2 from the previous
+    update) travel to the host on a side stream while that last blur runs -- then
+        y_{j+1} = (y' + sa^2 K'K y_j)/beta_j - (alfa/beta_j) y_j - (beta_j/beta_{j-1}) y_{j-1}
+    with its sum of squares in one pass (nsol_tk1_lanczos_* / nsol_lsmr_v_update_to_*).
+    The GPU never waits for the host."""
     import torch
     rho = sa * sa
     n = x_like.numel()
     flat = (n,)
     one = (1.0, 1.0, 1.0)
+    grad_mode = bmode == ops.B_GRAD
     # g = A^T b_top + sa B^T b_bot
     atu = A_adj(b_top)
     g = torch.empty_like(x_like)
@@ -289,52 +300,54 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     ys, betas = [g], [beta1]
     co = MinresCoefficients(maxiter + 1, beta1)
     t = torch.zeros_like(x_like)
-    slots = torch.zeros(2, dtype=torch.float64, device=x_like.device)
+    slots = torch.zeros(3, dtype=torch.float64, device=x_like.device)
+    fetch = ops.ScalarFetch(x_like.device, 3)
     istop = 7
+    alfa_prev = None
     for itn in range(1, maxiter + 1):
-        yj, beta = ys[-1], betas[-1]
-        # t = A y_j with ||t||^2 (the blur's epilogue form: io = 1 * A y_j + 0 * io)
+        yj = ys[-1]
         got = None
         if A_axpby is not None:
             got = A_axpby(yj, t, 1.0, 0.0, result=slots[0:1])
         if got is None:
             t = A(yj)
-            tt = None
+            ops.lsmr_v_update(t, None, t, ops.B_NONE, flat, one, 1.0, 0.0, 0.0,
+                              out=torch.empty_like(t), result=slots[0:1])
+        if grad_mode:
+            ops.tk1_grad_norm(yj, shape, w, result=slots[1:2])
+        fetch.start(slots)
         yp = A_adj(t)                                    # A^T A y_j
-        if bmode == ops.B_GRAD and _aliases(yp, t, *ys):
-            yp = yp.clone()          # (an operator that hands back its argument)
-        if bmode == ops.B_GRAD:
-            # y' += sa^2 grad^T grad y_j, with sum |grad y_j|^2
-            ops.tk1_reg_cost_grad(yj, yp, shape, w, rho, out=yp,
-                                  result=slots[1:2])
-        if got is None:
-            tt = ops.dot(t, t)
-        sums = slots.cpu()
-        if got is not None:
-            tt = float(sums[0])
-        if bmode == ops.B_GRAD:
-            alfa = (tt + rho * float(sums[1])) / (beta * beta)
-            c_j = -alfa / beta
+        vals = fetch.wait()
+        tt, gg, nb2 = float(vals[0]), float(vals[1]), float(vals[2])
+        if alfa_prev is not None:
+            beta_j = math.sqrt(nb2) if nb2 > 0 else 0.0
+            co.step(alfa_prev, beta_j)
+            if beta_j == 0 or not math.isfinite(beta_j):  # Krylov space exhausted
+                ys.pop()
+                alfa_prev = None
+                istop = 1
+                break
+            betas.append(beta_j)
+        beta = betas[-1]
+        prev = ys[-2] if len(ys) >= 2 else None
+        c_prev = -beta / betas[-2] if prev is not None else 0.0
+        ynew = torch.empty_like(x_like)
+        if grad_mode:
+            alfa = (tt + rho * gg) / (beta * beta)
+            ops.tk1_lanczos(yj, yp, prev, shape, w, rho / beta, 1.0 / beta,
+                            -alfa / beta, c_prev, out=ynew, result=slots[2:3])
         else:                                            # B = identity: B'B y_j = y_j
             alfa = tt / (beta * beta) + rho
-            c_j = (rho - alfa) / beta
-        # y_{j+1} = y'/beta + c_j y_j - (beta/oldb) y_{j-1}, into a buffer of our own
-        # (y' may live in a buffer the caller's operator reuses)
-        ynew = torch.empty_like(x_like)
-        if len(ys) >= 2:
-            nb2 = ops.lsmr_v_update(yj, ys[-2], yp, ops.B_IDENTITY, flat, one, c_j,
-                                    -beta / betas[-2], 1.0 / beta, out=ynew)
-        else:
-            nb2 = ops.lsmr_v_update(yj, None, yp, ops.B_NONE, flat, one, c_j, 0.0,
-                                    1.0 / beta, out=ynew)
+            ops.lsmr_v_update(yj, prev, yp,
+                              ops.B_IDENTITY if prev is not None else ops.B_NONE,
+                              flat, one, (rho - alfa) / beta, c_prev, 1.0 / beta,
+                              out=ynew, result=slots[2:3])
         del yp
-        beta_new = math.sqrt(nb2)
-        co.step(alfa, beta_new)
-        if beta_new == 0 or not math.isfinite(beta_new):  # Krylov space exhausted
-            istop = 1
-            break
         ys.append(ynew)
-        betas.append(beta_new)
+        alfa_prev = alfa
+    if alfa_prev is not None:                            # the last step's beta
+        nb2 = float(slots[2].item())
+        co.step(alfa_prev, math.sqrt(nb2) if nb2 > 0 else 0.0)
     k = co.itn
     x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)])
     return x, istop, k

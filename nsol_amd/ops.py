@@ -359,6 +359,60 @@ def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None, result=None):
     return (res if result is not None else float(res.item())), out
 
 
+def tk1_grad_norm(x, shape, w, result=None):
+    """sum |grad x|^2 alone (one read of x); result: the caller's device slot."""
+    _chk(x)
+    ndim, nz, ny, nx = dims3(shape)
+    ws, res = _workspace(x.device)
+    if result is not None:
+        res = result
+    _lib.check(_fn("tk1_grad_norm", x)(
+        _p(x), ndim, nz, ny, nx, w[0], w[1], w[2], _p(res), _p(ws), stream_ptr()),
+        "nsol_tk1_grad_norm")
+    return res if result is not None else float(res.item())
+
+
+def tk1_lanczos(x, g, z, shape, w, alpha, c_g, c_x, c_z, out, result=None):
+    """out = c_g g + alpha grad_adj(grad x) + c_x x + c_z z (z may be None) with the
+    sum of squares of out: the Lanczos update of the normal equations."""
+    _same(x, g, out)
+    if z is not None:
+        _same(x, z)
+    ndim, nz, ny, nx = dims3(shape)
+    ws, res = _workspace(x.device)
+    if result is not None:
+        res = result
+    _lib.check(_fn("tk1_lanczos", x)(
+        _p(x), _p(g), _p(z), _p(out), ndim, nz, ny, nx, w[0], w[1], w[2],
+        float(alpha), float(c_g), float(c_x), float(c_z), _p(res), _p(ws),
+        stream_ptr()), "nsol_tk1_lanczos")
+    return res if result is not None else float(res.item())
+
+
+class ScalarFetch(object):
+    """Device scalars to the host while later kernels run: an event behind the
+    kernels that produce them, a copy into pinned memory on a side stream, and a
+    wait on that copy alone -- the stream the solver enqueues on is not drained
+    (a `.cpu()` on it would wait for everything enqueued so far)."""
+
+    def __init__(self, device, count):
+        self.host = torch.empty(count, dtype=torch.float64).pin_memory()
+        self.side = torch.cuda.Stream(device=device)
+        self.ready = torch.cuda.Event()
+        self.done = torch.cuda.Event()
+
+    def start(self, dev_scalars):
+        self.ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ready)
+            self.host[:dev_scalars.numel()].copy_(dev_scalars, non_blocking=True)
+            self.done.record(self.side)
+
+    def wait(self):
+        self.done.synchronize()
+        return self.host.numpy()
+
+
 _ws8 = {}
 
 
@@ -702,7 +756,7 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
 
 
 def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
-                  sync=True, out=None):
+                  sync=True, out=None, result=None):
     """v = c_atu*Atu + c_btu*B^T(u_bot) + c_v*v; returns ||v||^2.  out: where
     the new vector goes instead of v (may be Atu: v then stays as it was)."""
     _same(Atu, v)
@@ -716,6 +770,8 @@ def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
                              "expected %d" % (u_bot.numel(), rows))
     (ndim, nz, ny, nx), w = _bgeom(bmode, shape, w, Atu.numel())
     ws, res = _workspace(Atu.device)
+    if result is not None:       # the caller's slot: not read back here
+        res, sync = result, False
     if out is not None:
         _lib.check(_fn("lsmr_v_update_to", Atu)(
             _p(Atu), _p(u_bot), _p(v), _p(out), int(bmode), ndim, nz, ny, nx,
