@@ -38,9 +38,9 @@ from bench import HipEvents, HBM_PEAK_GBPS  # noqa: E402
 BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
          "k_admm_vw": 52,
          # the normal-equations form: the blur with its sum of squares (reads the io
-         # tile it overwrites), sa^2 grad^T grad y added to A^T A y with sum |grad y|^2,
-         # the three-term Lanczos update with its norm
-         "k_blur3_dma_epi": 12, "k_tk1_reg": 12, "k_lsmr_v_lanczos": 16}
+         # tile it overwrites), sum |grad y|^2 from one read of y, the three-term
+         # Lanczos update with the regulariser's stencil and its norm
+         "k_blur3_dma_epi": 12, "k_tk1_norm": 4, "k_tk1_lanczos": 16}
 SETUP_BYTES = 156
 
 
@@ -57,10 +57,10 @@ def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
     update (28 B per LSMR iteration) is replaced by one pass that reads the
     iter_max + 1 stored vectors and writes x."""
     if normal_equations:
-        # per Lanczos step: t = A y (12), A^T t (8), + sa^2 grad^T grad y (12), the
-        # three-term update (16); the right-hand side A^T b + sa B^T c once (8 + 24);
-        # x from the iter_max stored vectors; the outer step as before
-        return iter_max * 48 + 32 + 4 * (iter_max + 1) + SETUP_BYTES - 64 - \
+        # per Lanczos step: t = A y (12), sum |grad y|^2 (4), A^T t (8), the three-term
+        # update with sa^2 grad^T grad y (16); the right-hand side A^T b + sa B^T c
+        # once (8 + 24); x from the iter_max stored vectors; the outer step as before
+        return iter_max * 40 + 32 + 4 * (iter_max + 1) + SETUP_BYTES - 64 - \
             (40 if prescaled_rhs else 0)
     per_it = (100 if blur_epilogue else 108) - (28 if deferred_x else 0)
     return iter_max * per_it + (4 * (iter_max + 2) if deferred_x else 0) + \
@@ -104,15 +104,14 @@ def time_kernels(shape, reps=20):
     slot = torch.zeros(1, dtype=torch.float64, device=dev)
     lib_epi = lambda: ops.corr3_wrap_axpby(v, blur_out, shape, taps, taps, taps, 1.0,
                                            0.0, result=slot)
-    lib_reg = lambda: ops.tk1_reg_cost_grad(v, Av, shape, w, 0.1, out=Av,
-                                            result=slot)
-    lib_lz = lambda: ops.lsmr_v_update(h, hbar, x, ops.B_IDENTITY, (n,), w, -0.3,
-                                       -0.2, 0.5, sync=False, out=x_out)
+    lib_reg = lambda: ops.tk1_grad_norm(v, shape, w, result=slot)
+    lib_lz = lambda: ops.tk1_lanczos(h, Av, hbar, shape, w, 0.1, 0.5, -0.3, -0.2,
+                                     out=x_out, result=slot)
     for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
                      ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
                      ("k_admm_vw", lib_vw), ("k_wcomb", lib_x),
-                     ("k_blur3_dma_epi", lib_epi), ("k_tk1_reg", lib_reg),
-                     ("k_lsmr_v_lanczos", lib_lz)):
+                     ("k_blur3_dma_epi", lib_epi), ("k_tk1_norm", lib_reg),
+                     ("k_tk1_lanczos", lib_lz)):
         for _ in range(3):
             fn()
         e0, e1 = ev.create(), ev.create()
@@ -375,7 +374,7 @@ def main():
         # (k_wcomb: x assembled from the stored vectors; timed for 11)
         if normal:
             per_it = {"k_blur3_dma": args.iter_max + 1, "k_blur3_dma_epi": args.iter_max,
-                      "k_tk1_reg": args.iter_max, "k_lsmr_v_lanczos": args.iter_max,
+                      "k_tk1_norm": args.iter_max, "k_tk1_lanczos": args.iter_max,
                       "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0, "k_admm_vw": 1,
                       "k_wcomb": 1}
         else:
@@ -383,7 +382,7 @@ def main():
                       "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
                       "k_lsmr_hx": 0 if deferred else args.iter_max,
                       "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0,
-                      "k_blur3_dma_epi": 0, "k_tk1_reg": 0, "k_lsmr_v_lanczos": 0}
+                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_tk1_lanczos": 0}
         for k, c in per_it.items():
             kern[k]["launches_per_admm_iteration"] = c
             kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]

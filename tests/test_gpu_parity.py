@@ -931,6 +931,42 @@ def test_lsmr_keeps_its_vectors_apart_whatever_the_operator_returns(nsol):
         assert float(outs[0].abs().max()) > 0
 
 
+@pytest.mark.parametrize("shape,spacing", [((1031,), None), ((37, 53), None),
+                                           ((9, 14, 24), None), ((12, 16, 31), (1.0, 0.7, 2.5)),
+                                           ((20, 33, 64), None)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lanczos_stencil_kernels_match_their_parts(nsol, shape, spacing, dtype):
+    """nsol_tk1_grad_norm_* (sum |grad x|^2 from one read of x) and nsol_tk1_lanczos_*
+    (c_g g + alpha grad^T grad x + c_x x + c_z z with the sum of squares of the result)
+    against nsol_tk1_reg_cost_grad_* followed by the combinations they replace."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x, g, z = (torch.randn(n, device="cuda", dtype=td, generator=gen) for _ in range(3))
+    w = tuple(1.0 / s for s in (spacing or (1.0,) * len(shape)))[::-1] + (1.0,) * (3 - len(shape))
+    w = (w + (1.0, 1.0, 1.0))[:3]
+    e_ref, mid = ops.tk1_reg_cost_grad(x, g, shape, w, 1.0, out=None)
+    lap = ops.lincomb2(1.0, mid, -1.0, g)                    # grad^T grad x
+    rel = 1e-13 if dtype == np.float64 else 1e-5
+    assert abs(ops.tk1_grad_norm(x, shape, w) - e_ref) <= 1e-12 * e_ref
+    slot = torch.zeros(1, dtype=torch.float64, device="cuda")
+    assert ops.tk1_grad_norm(x, shape, w, result=slot) is slot
+    assert abs(float(slot.item()) - e_ref) <= 1e-12 * e_ref
+    for zz, c_z in ((z, -0.6), (None, 0.0)):
+        want = 0.8 * g.double() + 0.37 * lap.double() - 1.3 * x.double()
+        if zz is not None:
+            want = want + c_z * zz.double()
+        out = torch.empty_like(x)
+        nb2 = ops.tk1_lanczos(x, g, zz, shape, w, 0.37, 0.8, -1.3, c_z, out=out)
+        scale = float(want.abs().max())
+        assert float((out.double() - want).abs().max()) <= rel * scale
+        assert abs(nb2 - float((out.double() ** 2).sum())) <= 1e-12 * nb2
+    with pytest.raises(Exception):
+        ops.tk1_lanczos(x, g, None, shape, w, 0.1, 1.0, 0.0, 0.0, out=x)   # x may not alias out
+
+
 def test_foreign_numpy_callables_take_the_host_bridge(nsol, golden):
     """A caller may still pass plain NumPy lambdas (the reference contract)."""
     import nsol_amd.primal_dual_solver as pd
