@@ -270,9 +270,10 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-                A_axpby=None):
+                A_axpby=None, atb=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
-    b_top / b_bot are consumed.  Returns (x, istop, itn).
+    b_top is only read, b_bot too.  atb: a callable that returns A^T b_top (a caller
+    that solves around the same b again and again keeps it).  Returns (x, istop, itn).
 
     Per step, on the unnormalised Lanczos vector y_j (nothing here needs beta_j):
         t = A y_j with ||t||^2            (the blur's epilogue form)
@@ -290,7 +291,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     one = (1.0, 1.0, 1.0)
     grad_mode = bmode == ops.B_GRAD
     # g = A^T b_top + sa B^T b_bot
-    atu = A_adj(b_top)
+    atu = atb() if atb is not None else A_adj(b_top)
     g = torch.empty_like(x_like)
     beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0, sa,
                                         0.0, out=g))
@@ -354,19 +355,24 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None):
+               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None,
+               own_b=True, atb=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
     A, A_adj: device callables (flat tensor -> flat tensor).  A_axpby(v, io, ca,
     cb) -> sum of squares or None: io = ca * A v + cb * io formed by the blur
     itself (its epilogue), when A is nsol_amd's one-pass blur.  normb2: the squared
-    norm of the right-hand side when the caller has it already."""
+    norm of the right-hand side when the caller has it already.  own_b: b_top may be
+    consumed (False: it is the caller's and gets copied where the bidiagonalisation
+    overwrites it).  atb: see lsmr_normal."""
     import torch
     if atol == 0.0 and btol == 0.0 and \
             normal_equations_ok(bmode, sa, maxiter, x_like):
         return lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like,
-                           maxiter, A_axpby=A_axpby)
+                           maxiter, A_axpby=A_axpby, atb=atb)
+    if not own_b:                 # (the caller's b: consumed below, so work in a copy)
+        b_top = b_top.clone()
     ut, ub = b_top, b_bot
     if normb2 is not None:           # ||[b_top; b_bot]||^2 known to the caller
         normb = math.sqrt(normb2)

@@ -39,6 +39,24 @@ USE_DEVICE_LBFGSB = True
 USE_FUSED_TK1_REG = True
 
 
+# A^T b for the (operator, data) pairs seen last: an outer loop (ADMM, primal-dual
+# with prox_linear_least_squares) builds one solver per iteration around the same b
+_atb_cache = []
+
+
+def _adjoint_of_data(key_op, A_adj, b):
+    key = (id(key_op), b.data_ptr(), int(b._version), b.numel(), str(b.dtype))
+    for k, refs, val in _atb_cache:
+        if k == key and refs[0] is key_op:
+            return val
+    val = A_adj(b)
+    if val.untyped_storage().data_ptr() == b.untyped_storage().data_ptr():
+        val = val.clone()                   # (an operator that hands back its argument)
+    _atb_cache.append((key, (key_op, b), val))
+    del _atb_cache[:-2]
+    return val
+
+
 class TikhonovLinearSolver(LinearSolver):
 
     def __init__(self, A, A_adj, b, B, B_adj, x0, alpha=0.01, b_reg=0,
@@ -158,9 +176,16 @@ class TikhonovLinearSolver(LinearSolver):
         fused = self._fused_lsmr_setup(x0) if USE_FUSED_LSMR else None
         pre = self._prescaled_b_reg
         if fused is not None:
+            # (b is handed over as it is: the bidiagonalisation takes a copy to work
+            # in, the normal-equations form only reads it -- and A^T b, the same in
+            # every solve of an outer loop around one b, is kept)
+            b_top = fused[2]
             x, _, _ = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
                                  A_axpby=self._blur_epilogue(x0.numel()),
-                                 normb2=None if pre is None else pre[1] + pre[2])
+                                 normb2=None if pre is None else pre[1] + pre[2],
+                                 own_b=False,
+                                 atb=lambda: _adjoint_of_data(self._A_adj, fused[1],
+                                                              b_top))
             return x
         if pre is not None:            # (not expected: undo the pre-multiplication)
             self._b_reg = ops.scale(self._dev(self._b_reg), 1.0 / pre[0])
@@ -194,7 +219,7 @@ class TikhonovLinearSolver(LinearSolver):
         if not (self._alpha > EPS):
             if not flat_ok:
                 return None
-            return (A, A_adj, b.clone(), None, ops.B_NONE, (n,),
+            return (A, A_adj, b, None, ops.B_NONE, (n,),
                     (1.0, 1.0, 1.0), 0.0)
         dB = trace_operator(self._B, n)
         if dB is None:
@@ -236,7 +261,7 @@ class TikhonovLinearSolver(LinearSolver):
             import torch
             lower = torch.full((rows,), sa * float(self._b_reg),
                                dtype=x0.dtype, device=x0.device)
-        return (A, A_adj, b.clone(), lower, bmode, shape, w, sa)
+        return (A, A_adj, b, lower, bmode, shape, w, sa)
 
     # ------------------------------------------------------------------
     def _host_linear_operator(self, x0):
