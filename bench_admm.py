@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from bench import HipEvents, HBM_PEAK_GBPS  # noqa: E402
 
 BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
-         "k_admm_vw": 52,
+         "k_admm_vw": 40,          # (52 when v itself is stored)
          # the normal-equations form: the blur with its sum of squares (reads the io
          # tile it overwrites), sum |grad y|^2 from one read of y, the three-term
          # Lanczos update with the regulariser's stencil and its norm
@@ -89,7 +89,7 @@ def time_kernels(shape, reps=20):
                                       0.1, -0.5, sync=False)
     lib_hx = lambda: ops.lsmr_hx_update(hbar, x, h, v, -0.3, 0.2, -0.4, 0.5,
                                         sync=False)
-    lib_vw = lambda: ops.admm_vw_update(x, vv, ww, None, rhs, shape, w, 0.1,
+    lib_vw = lambda: ops.admm_vw_update(x, None, ww, None, rhs, shape, w, 0.1,
                                         1.0)
     import nsol_amd.kernels as K
     taps = K.Kernels1D().get_gaussian(4.0)           # sigma = 2: 13 taps per axis

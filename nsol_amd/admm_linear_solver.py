@@ -101,12 +101,14 @@ class ADMMLinearSolver(LinearSolver):
             if self._verbose:
                 print("ADMM iteration %d/%d" % (i + 1, self._iterations))
             x = self._solve_tikhonov_least_squares(x, breg, hint)
+            # (v is read only through the next right-hand side: the fused step
+            # does not store it)
             if fused and prescale:
-                n2 = ops.admm_vw_update(x, v, w, c, breg, desc[2], desc[1].w, thr,
-                                        sa, want_norm=True)
+                n2 = ops.admm_vw_update(x, None, w, c, breg, desc[2], desc[1].w,
+                                        thr, sa, want_norm=True)
                 hint = (sa, b2, n2)        # breg holds sqrt(rho) * (v - w + c)
             elif fused:
-                ops.admm_vw_update(x, v, w, c, breg, desc[2], desc[1].w, thr,
+                ops.admm_vw_update(x, None, w, c, breg, desc[2], desc[1].w, thr,
                                    1.0)
             else:
                 Bx = B(x)

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
       ra[k] = rhs_scale * (va[k] - wa[k] + cc[a][k]);
       if (NORM && (!RAG || k < q.nval)) acc += (double)ra[k] * (double)ra[k];
     }
-    vs<RAG, T, VEC>(q.nval, v + a * G.n + q.i, va);
+    if (v) vs<RAG, T, VEC>(q.nval, v + a * G.n + q.i, va);   // (v itself may be unwanted)
     vs<RAG, T, VEC>(q.nval, w + a * G.n + q.i, wa);
     if (rhs) vs<RAG, T, VEC>(q.nval, rhs + a * G.n + q.i, ra);
   }
@@ -575,9 +575,9 @@ int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
                  double wz, double thr, double rhs_scale, void *stream,
                  double *result = nullptr, double *ws = nullptr) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (!x || !v || !w || (result && (!ws || !rhs))) return NSOL_EINVAL;
+  if (!x || !w || (!v && !rhs) || (result && (!ws || !rhs))) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  const bool al = ptr16(x) && ptr16(v) && ptr16(w) && (!c || ptr16(c)) &&
+  const bool al = ptr16(x) && (!v || ptr16(v)) && ptr16(w) && (!c || ptr16(c)) &&
                   (!rhs || ptr16(rhs)) && G.n % 4 == 0;
   return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
