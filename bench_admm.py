@@ -270,6 +270,9 @@ def main():
     ap.add_argument("--param", action="append", default=[],
                     help="library knob name=value (A/B runs, e.g. "
                          "corr_blur3_dma=0 for the register-window blur)")
+    ap.add_argument("--set", action="append", default=[], dest="py_set",
+                    help="module switch of the host code, nsol_amd.<module>.<NAME>="
+                         "<int> (A/B runs, e.g. lsmr.CONCURRENT_NORM=0)")
     ap.add_argument("--cpu-sample", type=int, default=64,
                     help="edge length of the CPU baseline's volume (64: about "
                          "15 s for one ADMM iteration of LSMR(10))")
@@ -302,6 +305,14 @@ def main():
     for kv in args.param:
         k, v = kv.split("=")
         _lib.set_param(k, int(v))
+    import importlib
+    for kv in args.py_set:
+        path, v = kv.split("=")
+        mod, name = path.rsplit(".", 1)
+        m = importlib.import_module("nsol_amd." + mod)
+        if not hasattr(m, name):
+            raise SystemExit("no switch %s" % path)
+        setattr(m, name, type(getattr(m, name))(int(v)))
     n = args.size
     shape = (n, n, n)
     nvox = n ** 3
