@@ -214,9 +214,20 @@ class SolutionCoefficients(object):
 # NE_MAX_ITER iterations -- BASELINE config 4 (rho = 0.1), the ADMM goldens
 # (rho = 0.5) and primal-dual deconvolution (weight 1 / tau >= 1) qualify; everything
 # else runs the bidiagonalisation.
+# The weight is taken RELATIVE to the operator's own scale (a caller's blur kernel need
+# not sum to one): against ||A v_1||^2 of the first, data-like Lanczos vector, which the
+# first step measures anyway (1 for a normalised blur; a run that fails the test has
+# spent three kernels and continues as a bidiagonalisation).  Large weights are
+# harmless (gradient, weight 1 / 4 / 16: 9e-8 / 1e-7 / 1.5e-7 in float32).  The
+# rotations' condition estimate (Paige-Saunders' Acond) is kept as a net for
+# pathological operators only -- it does not track the error closely (2.6 - 3.7 on
+# config 4 at 1.4e-7 - 2.9e-7, 4.2 on the weight-0.05 case at 1.3e-6, 16 on a harmless
+# weight of 4).
 USE_NORMAL_EQUATIONS = True
-NE_MIN_WEIGHT = {4: 0.1 * (1 - 1e-12), 8: 1.0e-2}   # by element size
+NE_MIN_WEIGHT = {4: 0.1 * (1 - 1e-9), 8: 1.0e-2}   # by element size
+NE_MAX_COND = {4: 1.0e3, 8: 1.0e7}
 NE_MAX_ITER = 32
+LAST_NE_COND = [None]        # (diagnostics: the estimate of the last run)
 
 
 def _aliases(t, *others):
@@ -237,6 +248,7 @@ class MinresCoefficients(object):
         self.w2 = np.zeros(capacity)
         self.x = np.zeros(capacity)
         self.itn = 0
+        self.gmax, self.gmin = 0.0, np.inf
 
     def step(self, alfa, beta_new):
         """v_{itn} has been multiplied: alfa = v'Mv, beta_new = the next beta."""
@@ -250,6 +262,7 @@ class MinresCoefficients(object):
         self.dbar = -self.cs * self.beta
         gamma = max(math.sqrt(gbar * gbar + self.beta * self.beta),
                     np.finfo(np.float64).eps)
+        self.gmax, self.gmin = max(self.gmax, gamma), min(self.gmin, gamma)
         self.cs, self.sn = gbar / gamma, self.beta / gamma
         phi = self.cs * self.phibar
         self.phibar = self.sn * self.phibar
@@ -261,8 +274,7 @@ class MinresCoefficients(object):
 
 
 def normal_equations_ok(bmode, sa, maxiter, x_like):
-    return (USE_NORMAL_EQUATIONS and bmode != ops.B_NONE and
-            sa * sa >= NE_MIN_WEIGHT[x_like.element_size()] and
+    return (USE_NORMAL_EQUATIONS and bmode != ops.B_NONE and sa > 0 and
             1 <= maxiter <= NE_MAX_ITER and
             maxiter + 1 <= _MAX_COMBINED and
             (maxiter + 2) * x_like.numel() * x_like.element_size()
@@ -330,6 +342,8 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                 break
             betas.append(beta_j)
         beta = betas[-1]
+        if itn == 1 and rho < NE_MIN_WEIGHT[x_like.element_size()] * tt / (beta * beta):
+            return None, -1, 0         # regulariser too weak against ||A||^2
         prev = ys[-2] if len(ys) >= 2 else None
         c_prev = -beta / betas[-2] if prev is not None else 0.0
         ynew = torch.empty_like(x_like)
@@ -350,6 +364,9 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         nb2 = float(slots[2].item())
         co.step(alfa_prev, math.sqrt(nb2) if nb2 > 0 else 0.0)
     k = co.itn
+    LAST_NE_COND[0] = co.gmax / co.gmin if co.gmin > 0 else np.inf
+    if LAST_NE_COND[0] > NE_MAX_COND[x_like.element_size()]:
+        return None, -1, k             # too ill-conditioned for this form
     x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)])
     return x, istop, k
 
@@ -369,8 +386,11 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     import torch
     if atol == 0.0 and btol == 0.0 and \
             normal_equations_ok(bmode, sa, maxiter, x_like):
-        return lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like,
-                           maxiter, A_axpby=A_axpby, atb=atb)
+        x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
+                                    x_like, maxiter, A_axpby=A_axpby, atb=atb)
+        if x is not None:
+            return x, istop, itn
+        # (the condition estimate came out too high: nothing was consumed, go on)
     if not own_b:                 # (the caller's b: consumed below, so work in a copy)
         b_top = b_top.clone()
     ut, ub = b_top, b_bot

@@ -967,6 +967,51 @@ def test_lanczos_stencil_kernels_match_their_parts(nsol, shape, spacing, dtype):
         ops.tk1_lanczos(x, g, None, shape, w, 0.1, 1.0, 0.0, 0.0, out=x)   # x may not alias out
 
 
+@pytest.mark.parametrize("weight,scale,takes", [(0.1, 1.0, True), (0.5, 1.0, True),
+                                                (10.0, 10.0, True), (0.05, 1.0, False),
+                                                (0.1, 10.0, False)])
+def test_normal_equations_form_is_taken_by_relative_weight(nsol, weight, scale, takes):
+    """LSMR runs as Lanczos on the normal equations only where the regulariser's weight
+    is at least a tenth of ||A v_1||^2 (float32) -- whatever the operator's own scale;
+    otherwise the first step's three kernels are dropped and the bidiagonalisation runs,
+    with the result it always gave."""
+    import torch
+    import nsol_amd.lsmr as L
+    import nsol_amd.tikhonov_linear_solver as tk
+    from nsol_amd.synthetic import synth_volume
+    n = 48
+    shape = (n, n, n)
+    lo = _lo(3)
+    A, Aa = lo.get_gaussian_blurring_operators(np.diag([4.0] * 3))
+    grad, grad_adj = lo.get_gradient_operators()
+    A_ = lambda x: scale * A(x.reshape(*shape)).flatten()
+    Aa_ = lambda x: scale * Aa(x.reshape(*shape)).flatten()
+    D_ = lambda x: grad(x.reshape(*shape)).flatten()
+    Da_ = lambda x: grad_adj(x.reshape(3 * n, n, n)).flatten()
+    y = A_(torch.from_numpy(synth_volume(n, 0, "clean", np.float32)).cuda())
+    y = y + 0.02 * float(y.max()) * torch.randn(
+        y.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    outs = []
+    for ne in (True, False):
+        L.USE_NORMAL_EQUATIONS = ne
+        L.LAST_NE_COND[0] = None
+        try:
+            s = tk.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=D_, B_adj=Da_, b=y, x0=y,
+                                        alpha=weight, b_reg=D_(y / float(y.max())),
+                                        iter_max=10, x_scale=float(y.max()),
+                                        dtype=np.float32)
+            s.run()
+        finally:
+            L.USE_NORMAL_EQUATIONS = True
+        if ne:
+            assert (L.LAST_NE_COND[0] is not None) == takes
+        outs.append(s.get_x())
+    if takes:
+        assert rel_l2(outs[0], outs[1]) < 1e-6
+    else:
+        assert np.array_equal(outs[0], outs[1])
+
+
 def test_foreign_numpy_callables_take_the_host_bridge(nsol, golden):
     """A caller may still pass plain NumPy lambdas (the reference contract)."""
     import nsol_amd.primal_dual_solver as pd
