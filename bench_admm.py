@@ -40,7 +40,9 @@ BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
          # the normal-equations form: the blur with its sum of squares (reads the io
          # tile it overwrites), sum |grad y|^2 from one read of y, the three-term
          # Lanczos update with the regulariser's stencil and its norm
-         "k_blur3_dma_epi": 12, "k_tk1_norm": 4, "k_tk1_lanczos": 16}
+         "k_blur3_dma_epi": 12, "k_tk1_norm": 4, "k_tk1_lanczos": 16,
+         # ... or the blur that takes both sums itself (no io tile, no second read of y)
+         "k_blur3_dma_norms": 8}
 SETUP_BYTES = 156
 
 
@@ -49,7 +51,8 @@ def bytes_per_admm_iteration(iter_max):
 
 
 def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
-                                   deferred_x=True, normal_equations=False):
+                                   deferred_x=True, normal_equations=False,
+                                   blur_norms=False):
     """What the kernels have to move at least with this build's fusions: the
     blur's epilogue saves the write and the read of A v (8 B per LSMR iteration),
     the pre-scaled right-hand side the scaling pass, its norm pass and the norm
@@ -60,8 +63,9 @@ def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
         # per Lanczos step: t = A y (12), sum |grad y|^2 (4), A^T t (8), the three-term
         # update with sa^2 grad^T grad y (16); the right-hand side A^T b + sa B^T c
         # once (8 + 24); x from the iter_max stored vectors; the outer step as before
-        return iter_max * 40 + 32 + 4 * (iter_max + 1) + SETUP_BYTES - 64 - \
-            (40 if prescaled_rhs else 0)
+        # (blur_norms: t = A y with both sums in 8)
+        return iter_max * (32 if blur_norms else 40) + 32 + 4 * (iter_max + 1) + \
+            SETUP_BYTES - 64 - (40 if prescaled_rhs else 0)
     per_it = (100 if blur_epilogue else 108) - (28 if deferred_x else 0)
     return iter_max * per_it + (4 * (iter_max + 2) if deferred_x else 0) + \
         SETUP_BYTES - (40 if prescaled_rhs else 0)
@@ -105,13 +109,16 @@ def time_kernels(shape, reps=20):
     lib_epi = lambda: ops.corr3_wrap_axpby(v, blur_out, shape, taps, taps, taps, 1.0,
                                            0.0, result=slot)
     lib_reg = lambda: ops.tk1_grad_norm(v, shape, w, result=slot)
+    slot2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    lib_norms = lambda: ops.corr3_wrap_norms(v, blur_out, shape, taps, taps, taps, w,
+                                             slot2)
     lib_lz = lambda: ops.tk1_lanczos(h, Av, hbar, shape, w, 0.1, 0.5, -0.3, -0.2,
                                      out=x_out, result=slot)
     for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
                      ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
                      ("k_admm_vw", lib_vw), ("k_wcomb", lib_x),
                      ("k_blur3_dma_epi", lib_epi), ("k_tk1_norm", lib_reg),
-                     ("k_tk1_lanczos", lib_lz)):
+                     ("k_tk1_lanczos", lib_lz), ("k_blur3_dma_norms", lib_norms)):
         for _ in range(3):
             fn()
         e0, e1 = ev.create(), ev.create()
@@ -383,9 +390,13 @@ def main():
         normal = bool(lsmr_mod.USE_NORMAL_EQUATIONS) and deferred and \
             0.1 >= lsmr_mod.NE_MIN_WEIGHT[4] and args.iter_max <= lsmr_mod.NE_MAX_ITER
         # (k_wcomb: x assembled from the stored vectors; timed for 11)
+        blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS) and n % 4 == 0
         if normal:
-            per_it = {"k_blur3_dma": args.iter_max + 1, "k_blur3_dma_epi": args.iter_max,
-                      "k_tk1_norm": args.iter_max, "k_tk1_lanczos": args.iter_max,
+            per_it = {"k_blur3_dma": args.iter_max + 1,
+                      "k_blur3_dma_epi": 0 if blur_norms else args.iter_max,
+                      "k_tk1_norm": 0 if blur_norms else args.iter_max,
+                      "k_blur3_dma_norms": args.iter_max if blur_norms else 0,
+                      "k_tk1_lanczos": args.iter_max,
                       "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0, "k_admm_vw": 1,
                       "k_wcomb": 1}
         else:
@@ -393,7 +404,8 @@ def main():
                       "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
                       "k_lsmr_hx": 0 if deferred else args.iter_max,
                       "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0,
-                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_tk1_lanczos": 0}
+                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_tk1_lanczos": 0,
+                      "k_blur3_dma_norms": 0}
         for k, c in per_it.items():
             kern[k]["launches_per_admm_iteration"] = c
             kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]
@@ -414,10 +426,10 @@ def main():
                 "bytes_moved_per_voxel_per_admm_iteration":
                     bytes_moved_per_admm_iteration(
                         args.iter_max, not args.no_blur_epilogue,
-                        not args.no_prescaled_rhs, deferred, normal),
+                        not args.no_prescaled_rhs, deferred, normal, blur_norms),
                 "frac_moved": bytes_moved_per_admm_iteration(
                     args.iter_max, not args.no_blur_epilogue,
-                    not args.no_prescaled_rhs, deferred, normal) * nvox * args.iterations / med / 1e9 /
+                    not args.no_prescaled_rhs, deferred, normal, blur_norms) * nvox * args.iterations / med / 1e9 /
                 HBM_PEAK_GBPS,
                 "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
                 "kernel_ms_per_admm_iteration_sum":

@@ -167,6 +167,26 @@ int nsol_corr3_wrap_axpby_f64(const double *x, double *io, int64_t nz, int64_t n
                               const double *taps_x, int ntaps, double ca, double cb,
                               double *result, double *ws, int64_t ws_doubles,
                               void *stream);
+/* The same blur with the two sums of a Lanczos step on the normal equations
+ * A^T A + rho grad^T grad (how nsol_amd runs the LSMR solve of
+ * tikhonov_linear_solver.py:146-158 with a first-order Tikhonov regulariser,
+ * nsol_amd/lsmr.py): out = A x, result[0] = sum (A x)^2 and result[1] =
+ * sum |grad x|^2 of the INPUT -- forward differences with weights wx, wy, wz (the
+ * inverse spacings) and zero behind the last voxel of an axis, exactly
+ * nsol_tk1_grad_norm_*'s sum, taken from the tiles of x the blur stages anyway
+ * instead of a second pass over x.  ws: >= 2 doubles per tile.  Returns -2 (nothing
+ * launched) where nsol_corr3_wrap_axpby_* does, and for rows that are not whole
+ * 16-byte vectors or operands off the 16-byte grid. */
+int nsol_corr3_wrap_norms_f32(const float *x, float *out, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double wx, double wy,
+                              double wz, double *result, double *ws, int64_t ws_doubles,
+                              void *stream);
+int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double wx, double wy,
+                              double wz, double *result, double *ws, int64_t ws_doubles,
+                              void *stream);
 /* dense N-D correlation with DEVICE taps [kz][ky][kx] and centre (cz,cy,cx):
  *   out[i] = sum_t taps[t] * x[i + t - c].  Replaces linear_operators.py:60-68
  * (scipy.ndimage.convolve with an arbitrary kernel; the host flips the kernel

@@ -51,18 +51,21 @@ inline int blur3_cu_count() {
 }
 
 // what nsol_conv.hip calls: -2 when the kernel does not apply (nothing launched).
-// epi: io = ca * blur(x) + cb * io in place (out = io) and *result = the sum of
-// squares of the new io (part: >= tiles doubles of scratch)
+// epi 1: io = ca * blur(x) + cb * io in place (out = io) and *result = the sum of
+// squares of the new io (part: >= tiles doubles of scratch).  epi 2: out = blur(x),
+// result[0] = the sum of squares of out and result[1] = ca * sum (d_x x)^2 +
+// cb * sum (d_y x)^2 + cc * sum (d_z x)^2 (forward differences, zero behind the last
+// voxel of an axis) of the INPUT (part: >= 2 * tiles doubles)
 __attribute__((visibility("hidden")))
 int blur3_dma_run(const float *x, float *out, int64_t nz, int64_t ny, int64_t nx,
                   const Taps<float> &tz, const Taps<float> &ty, const Taps<float> &tx,
-                  int ntaps, bool epi, double ca, double cb, double *result, double *part,
-                  int64_t part_doubles, hipStream_t st);
+                  int ntaps, int epi, double ca, double cb, double cc, double *result,
+                  double *part, int64_t part_doubles, hipStream_t st);
 __attribute__((visibility("hidden")))
 int blur3_dma_run(const double *x, double *out, int64_t nz, int64_t ny, int64_t nx,
                   const Taps<double> &tz, const Taps<double> &ty, const Taps<double> &tx,
-                  int ntaps, bool epi, double ca, double cb, double *result, double *part,
-                  int64_t part_doubles, hipStream_t st);
+                  int ntaps, int epi, double ca, double cb, double cc, double *result,
+                  double *part, int64_t part_doubles, hipStream_t st);
 
 }  // namespace nsol_blur3
 
@@ -137,6 +140,15 @@ __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
 // one phase ahead, issued BEFORE that phase's raw-tile pieces: the counted wait at
 // the end of the phase leaves only younger operations in flight, so it has landed.
 //
+// EPI == 2: A x is stored as it is, with its sum of squares (part[tile]) and, from the
+// raw tiles the x pass reads anyway, the weighted sum of squares of the forward
+// differences of the INPUT, ca |d_x x|^2 + cb |d_y x|^2 + cc |d_z x|^2 (part[tiles +
+// tile]; zero behind the last voxel of an axis, as nsol_grad_* has it, not the blur's
+// periodic wrap) -- the two sums of a Lanczos step on A'A + rho grad'grad
+// (nsol_amd/lsmr.py, lsmr_normal) without a second read of x.  A lane reads its own
+// vector of plane st + 1, the vector to its right and the one below from the raw tile
+// and keeps its own vector of the plane before in registers for d_z.
+//
 // RAG: rows that are not a multiple of 16 bytes (or operands that are not 16-byte
 // aligned).  LDS-DMA takes 16-byte pieces from any 4-byte aligned source and honours
 // EXEC (tools/_probe/dma_probe.hip), so the raw tile is staged as before from
@@ -147,11 +159,12 @@ __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
 // row end.  The row's last, partial output vector is stored element by element (its
 // 16-byte store carries the out-of-range offset): VEC - 1 more stores per wave and
 // plane in the last tile column, all of them counted by the waits.
-template <typename T, int VEC, int NT, int NW, bool ISO, bool EPI = false, bool RAG = false>
+template <typename T, int VEC, int NT, int NW, bool ISO, int EPI = 0, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
     Taps<T> tz_, Taps<T> ty_, Taps<T> tx, int ntx, int nty, int nzc, int zchunk,
-    int per_xcd, T ca = T(1), T cb = T(0), double *__restrict__ part = nullptr) {
+    int per_xcd, T ca = T(1), T cb = T(0), T cc = T(0),
+    double *__restrict__ part = nullptr) {
   const Taps<T> &tz = ISO ? tx : tz_;
   const Taps<T> &ty = ISO ? tx : ty_;
   typedef typename VecOf<T, VEC>::type V;
@@ -444,10 +457,17 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   const bool tail = RAG && owner && nvalid < VEC;
   const int rot = RAG ? (int)(VEC - nx % VEC) % VEC : 0;   // (EPI) see stage_old
   double sumsq = 0.0;
+  // (EPI == 2) weights of the squared differences, zero in lanes that own no voxel;
+  // 0 / 1 factors that blank the neighbour behind the volume's last column and row
+  double gsum = 0.0;
+  V prev_own = splat<V, T>(T(0));
+  const T gx2 = owner ? ca : T(0), gy2 = owner ? cb : T(0), gz2 = owner ? cc : T(0);
+  const T xm = (xv + 1 < nxv) ? T(1) : T(0);
+  const T ym = (y0 + row + 1 < ny) ? T(1) : T(0);
   auto put = [&](int64_t z, V val, int ob) {
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + z * plane, 0, plane_bytes,
                                                         0x00020000);
-    if constexpr (EPI) {
+    if constexpr (EPI == 1) {
       V old = obuf[(size_t)ob * tile_vecs + (size_t)row * lxb + lx];
       if constexpr (RAG) {
         if (tail) {                                  // staged from nx - VEC: old[e] = L[e + rot]
@@ -462,6 +482,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         }
       }
       val = splat<V, T>(ca) * val + splat<V, T>(cb) * old;
+    }
+    if constexpr (EPI != 0) {
       if (owner) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
@@ -498,7 +520,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   // (EPI) the io tile of one output plane -> obuf[ob]: one 1-KiB piece per wave; lanes
   // whose tile position lies outside the volume re-read a valid neighbour
   uint32_t old_off = 0;
-  if constexpr (EPI) {
+  if constexpr (EPI == 1) {
     const int i = wave * 64 + lane;
     int64_t yy = y0 + i / lxb;
     if (yy >= ny) yy = ny - 1;
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     old_off = (uint32_t)(yy * nx + xe);
   }
   auto stage_old = [&](int64_t z, int ob) {
-    if constexpr (EPI)
+    if constexpr (EPI == 1)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void *)(out + z * plane + old_off),
           (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     constexpr int u = decltype(U)::value;           // = st mod M
     constexpr int q = u & 1;                        // = st & 1 (M is even)
     const bool more = st + 3 < nsteps;
-    if (EPI && st + 1 >= 2 * R && st + 1 < nsteps)
+    if (EPI == 1 && st + 1 >= 2 * R && st + 1 < nsteps)
       stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io of the next output plane
     if (more) stage(next_plane(), r_cur);           // plane st + 3, two phases ahead
     // (The x pass of plane st + 1 and the y / z passes of plane st are independent,
@@ -563,6 +585,36 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       ring[u] = v;                                  // replaces plane st - M
     };
     if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+    if constexpr (EPI == 2) {
+      if (st + 1 < nsteps) {
+        // plane j of the chunk's nsteps planes is one of its own for R <= j < nsteps - R
+        const V *o = raw + (size_t)r_next + (size_t)(row + R) * rl + lx + NBH;
+        const V own = o[0];
+        if (st + 1 >= R && st + 1 < nsteps - R) {          // d_x, d_y of plane st + 1
+          const V right = o[1];
+          const V down = o[rl];
+          const V dy = __builtin_elementwise_fma(down, splat<V, T>(ym), -own);
+          T sx = T(0), sy = T(0);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const T dx = (k + 1 < VEC) ? own[(k + 1) % VEC] - own[k]
+                                       : fma1(right[0], xm, -own[k]);
+            sx = fma1(dx, dx, sx);
+            sy = fma1(dy[k], dy[k], sy);
+          }
+          gsum += (double)fma1(gx2, sx, gy2 * sy);
+        }
+        if (st >= R && st < nsteps - R) {                  // d_z of plane st
+          const T zm = (zbeg + (st - R) + 1 < nz) ? T(1) : T(0);
+          const V dz = __builtin_elementwise_fma(own, splat<V, T>(zm), -prev_own);
+          T sz = T(0);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) sz = fma1(dz[k], dz[k], sz);
+          gsum += (double)(gz2 * sz);
+        }
+        prev_own = own;
+      }
+    }
     yz();
     const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
     // plane st + 2 (staged in the previous phase) must have landed; younger than
@@ -571,25 +623,36 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   };
 #pragma unroll 1
   for (int st0 = 0; st0 < nsteps; st0 += M) blur3_phases<0, M>(st0, nsteps, phase);
-  if constexpr (EPI) {
+  if constexpr (EPI != 0) {
     // (the last phase ended with a barrier: the LDS is free)
     double *red = reinterpret_cast<double *>(smem_raw);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sumsq += __shfl_down(sumsq, o, 64);
     if (lane == 0) red[wave] = sumsq;
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gsum += __shfl_down(gsum, o, 64);
+      if (lane == 0) red[NW + wave] = gsum;
+    }
     __syncthreads();
     if (tid == 0) {
       double t = 0.0;
       for (int w2 = 0; w2 < NW; ++w2) t += red[w2];
       part[logical] = t;
     }
+    if (EPI == 2 && tid == 64) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < NW; ++w2) t += red[NW + w2];
+      part[total + logical] = t;
+    }
   }
 }
 
-// sum of the per-tile partials in a fixed order
+// sum of the per-tile partials in a fixed order (block b: the b-th run of n partials)
 __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, int n,
                                                             double *result) {
   __shared__ double s[kBlock];
+  part += (size_t)blockIdx.x * n;
   double t = 0.0;
   for (int i = threadIdx.x; i < n; i += kBlock) t += part[i];
   s[threadIdx.x] = t;
@@ -597,18 +660,19 @@ __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, 
   if (threadIdx.x == 0) {
     double r = 0.0;
     for (int i = 0; i < kBlock; ++i) r += s[i];
-    *result = r;
+    result[blockIdx.x] = r;
   }
 }
 
 
 // LDS-DMA staged kernel: tiles of kDmaLxb lanes per row whatever the row length;
-// returns -2 when it does not apply.  EPI (out = io, in place): io = ca * blur(x) +
-// cb * io and *result = sum of squares of the new io (part: >= tiles doubles).
-template <typename T, int VEC, int NT, int NWD, bool EPI = false>
+// returns -2 when it does not apply.  EPI 1 (out = io, in place): io = ca * blur(x) +
+// cb * io and *result = sum of squares of the new io (part: >= tiles doubles).  EPI 2:
+// see the kernel (result[0 .. 1], part: >= 2 * tiles doubles; whole 16-byte rows only).
+template <typename T, int VEC, int NT, int NWD, int EPI = 0>
 int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                      const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
-                     hipStream_t st, double ca = 1.0, double cb = 0.0,
+                     hipStream_t st, double ca = 1.0, double cb = 0.0, double cc = 0.0,
                      double *result = nullptr, double *part = nullptr,
                      int64_t part_doubles = 0) {
   constexpr int R = NT / 2;
@@ -618,11 +682,13 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   constexpr int frows = dtyr + 2 * R;
   constexpr int npieces = (frows * (dl + 2 * NBH) + 63) / 64;
   constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl +
-                           (EPI ? 2 * (size_t)dtyr * dl : 0)) * 16;
+                           (EPI == 1 ? 2 * (size_t)dtyr * dl : 0)) * 16;
   constexpr size_t lds_patch = 3 * (size_t)((frows * 4 + 63) / 64) * 16 * 16;   // (RAG)
-  if constexpr (lds0 > 160 * 1024) {
-    static_assert(EPI, "LDS-DMA blur tile does not fit");
-    return -2;                                           // (no room for the io tiles)
+  if constexpr (lds0 > 160 * 1024 || (EPI == 2 && sizeof(T) == 8 && NT >= 15)) {
+    static_assert(EPI != 0, "LDS-DMA blur tile does not fit");
+    // (no room for the io tiles; the difference sums of 15 / 17 taps in double would
+    // need more than the 128 registers of a 16-wave workgroup)
+    return -2;
   } else {
   if (dtyr < 2 * R) return -2;
   // rows that are not whole vectors, or operands off the 16-byte grid: the RAG form
@@ -653,12 +719,16 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t tiles = dntx * dnty * nzc;
   if (tiles >= ((int64_t)1 << 28)) return -2;
-  if (EPI && tiles > part_doubles) return -2;
+  if (EPI != 0 && tiles * (EPI == 2 ? 2 : 1) > part_doubles) return -2;
   const int per_xcd = (int)((tiles + 7) / 8);
   bool iso = true;
   for (int t = 0; t < NT; ++t) iso = iso && tz.w[t] == tx.w[t] && ty.w[t] == tx.w[t];
-  auto kern = rag ? (iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI, true>
-                         : k_blur3_dma<T, VEC, NT, NWD, false, EPI, true>)
+  // (the difference sums are not instantiated for ragged rows: the caller takes
+  // nsol_tk1_grad_norm_* beside the epilogue form there)
+  if (EPI == 2 && rag) return -2;
+  constexpr bool RG = EPI != 2;
+  auto kern = rag ? (iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI, RG>
+                         : k_blur3_dma<T, VEC, NT, NWD, false, EPI, RG>)
                   : (iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI, false>
                          : k_blur3_dma<T, VEC, NT, NWD, false, EPI, false>);
   if (lds > 64 * 1024) {
@@ -669,10 +739,10 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
                      nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
-                     per_xcd, (T)ca, (T)cb, part);
-  if (EPI)
-    hipLaunchKernelGGL(k_blur3_epi_final, dim3(1), dim3(kBlock), 0, st, part, (int)tiles,
-                       result);
+                     per_xcd, (T)ca, (T)cb, (T)cc, part);
+  if (EPI != 0)
+    hipLaunchKernelGGL(k_blur3_epi_final, dim3(EPI == 2 ? 2 : 1), dim3(kBlock), 0, st, part,
+                       (int)tiles, result);
   return launch_status();
   }
 }
@@ -680,14 +750,18 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
 template <typename T>
 int blur3_dma_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                        const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, int ntaps,
-                       bool epi, double ca, double cb, double *result, double *part,
-                       int64_t part_doubles, hipStream_t st) {
+                       int epi, double ca, double cb, double cc, double *result,
+                       double *part, int64_t part_doubles, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
 #define NSOL_B3D_CASE(N)                                                                  \
   case N:                                                                                 \
-    return epi ? launch_blur3_dma<T, VEC, N, 16, true>(x, out, nz, ny, nx, tz, ty, tx, st, \
-                                                        ca, cb, result, part, part_doubles) \
-               : launch_blur3_dma<T, VEC, N, 16, false>(x, out, nz, ny, nx, tz, ty, tx, st);
+    return epi == 2 ? launch_blur3_dma<T, VEC, N, 16, 2>(x, out, nz, ny, nx, tz, ty, tx, st, \
+                                                         ca, cb, cc, result, part,         \
+                                                         part_doubles)                     \
+           : epi    ? launch_blur3_dma<T, VEC, N, 16, 1>(x, out, nz, ny, nx, tz, ty, tx, st, \
+                                                         ca, cb, 0.0, result, part,        \
+                                                         part_doubles)                     \
+                    : launch_blur3_dma<T, VEC, N, 16, 0>(x, out, nz, ny, nx, tz, ty, tx, st);
   switch (ntaps) {
     NSOL_B3D_CASE(3) NSOL_B3D_CASE(5) NSOL_B3D_CASE(7) NSOL_B3D_CASE(9)
     NSOL_B3D_CASE(11) NSOL_B3D_CASE(13) NSOL_B3D_CASE(15) NSOL_B3D_CASE(17)

@@ -5,9 +5,10 @@
 namespace nsol_blur3 {
 int blur3_dma_run(const float *x, float *out, int64_t nz, int64_t ny, int64_t nx,
                   const Taps<float> &tz, const Taps<float> &ty, const Taps<float> &tx, int ntaps,
-                  bool epi, double ca, double cb, double *result, double *part,
+                  int epi, double ca, double cb, double cc, double *result, double *part,
                   int64_t part_doubles, hipStream_t st) {
-  return blur3_dma_dispatch<float>(x, out, nz, ny, nx, tz, ty, tx, ntaps, epi, ca, cb, result,
+  return blur3_dma_dispatch<float>(x, out, nz, ny, nx, tz, ty, tx, ntaps, epi, ca, cb, cc,
+                                result,
                                 part, part_doubles, st);
 }
 }  // namespace nsol_blur3

@@ -673,11 +673,14 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_wrap_pp(
 // nsol_corr3_wrap_axpby_*: io = ca * A x + cb * io in place with the sum of squares
 // of the result; -2 when the LDS-DMA kernel does not apply (the caller then blurs
 // and combines in two steps)
+// nsol_corr3_wrap_norms_* (epi == 2): io = A x stored as it is, result[0] = its sum
+// of squares, result[1] = the sum of squares of the weighted forward differences of x
+// (ca, cb, cc = the squared weights of d_x, d_y, d_z)
 template <typename T>
 int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
                      const double *tz_host, const double *ty_host, const double *tx_host,
                      int ntaps, double ca, double cb, double *result, double *ws,
-                     int64_t ws_doubles, void *stream) {
+                     int64_t ws_doubles, void *stream, int epi = 1, double cc = 0.0) {
   if (!x || !io || x == io || !tz_host || !ty_host || !tx_host || !result || !ws ||
       nz < 1 || ny < 1 || nx < 1 || ntaps < 1)
     return NSOL_EINVAL;
@@ -698,7 +701,7 @@ int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
                 ty.w[t] == ty.w[ntaps - 1 - t] && tx.w[t] == tx.w[ntaps - 1 - t];
   if (!symmetric) return -2;
   hipStream_t st = as_stream(stream);
-  return blur3_dma_run(x, io, nz, ny, nx, tz, ty, tx, ntaps, true, ca, cb, result, ws,
+  return blur3_dma_run(x, io, nz, ny, nx, tz, ty, tx, ntaps, epi, ca, cb, cc, result, ws,
                        ws_doubles, st);
 }
 
@@ -737,8 +740,8 @@ int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   if (blocks > 0x7fffffff) return -2;
   if (g_blur3_dma && symmetric && g_blur3_lxb == kDmaLxb) {
     int rc = -2;
-    rc = blur3_dma_run(x, out, nz, ny, nx, tz, ty, tx, NT, false, 1.0, 0.0, nullptr, nullptr, 0,
-                       st);
+    rc = blur3_dma_run(x, out, nz, ny, nx, tz, ty, tx, NT, 0, 1.0, 0.0, 0.0, nullptr, nullptr,
+                       0, st);
     if (rc != -2) return rc;
   }
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) return -2;
@@ -896,6 +899,22 @@ int nsol_corr3_wrap_axpby_f64(const double *x, double *io, int64_t nz, int64_t n
                               void *stream) {
   return corr3_axpby_impl<double>(x, io, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, ca, cb,
                                   result, ws, ws_doubles, stream);
+}
+int nsol_corr3_wrap_norms_f32(const float *x, float *out, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double wx, double wy,
+                              double wz, double *result, double *ws, int64_t ws_doubles,
+                              void *stream) {
+  return corr3_axpby_impl<float>(x, out, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, wx * wx,
+                                 wy * wy, result, ws, ws_doubles, stream, 2, wz * wz);
+}
+int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t ny,
+                              int64_t nx, const double *taps_z, const double *taps_y,
+                              const double *taps_x, int ntaps, double wx, double wy,
+                              double wz, double *result, double *ws, int64_t ws_doubles,
+                              void *stream) {
+  return corr3_axpby_impl<double>(x, out, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, wx * wx,
+                                  wy * wy, result, ws, ws_doubles, stream, 2, wz * wz);
 }
 int nsol_corr_dense_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const float *taps, int kz, int ky, int kx,

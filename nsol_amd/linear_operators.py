@@ -210,6 +210,16 @@ class ConvolutionOperator(DeviceOperator):
                                     self._passes[1][1], self._passes[2][1], ca, cb,
                                     result=result)
 
+    def apply_norms(self, x, out, in_shape, w, result):
+        """out = A(x) with result[0] = sum out^2 and result[1] = sum |grad x|^2 of
+        the input (w: the gradient's weights), both from the one-pass blur; None
+        when that kernel does not apply."""
+        if not (USE_FUSED_BLUR3 and USE_BLUR_EPILOGUE and self._passes and
+                len(in_shape) == 3 and self._fusable3()):
+            return None
+        return ops.corr3_wrap_norms(x, out, in_shape, self._passes[0][1],
+                                    self._passes[1][1], self._passes[2][1], w, result)
+
     def _apply(self, x, in_shape):
         if len(in_shape) != self.dimension:
             raise RuntimeError("%dD convolution applied to %d axes" %

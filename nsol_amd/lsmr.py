@@ -227,6 +227,8 @@ USE_NORMAL_EQUATIONS = True
 NE_MIN_WEIGHT = {4: 0.1 * (1 - 1e-9), 8: 1.0e-2}   # by element size
 NE_MAX_COND = {4: 1.0e3, 8: 1.0e7}
 NE_MAX_ITER = 32
+# the blur takes sum |grad y_j|^2 of its input itself (nsol_corr3_wrap_norms_*)
+USE_BLUR_NORMS = True
 LAST_NE_COND = [None]        # (diagnostics: the estimate of the last run)
 
 
@@ -290,6 +292,8 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     Per step, on the unnormalised Lanczos vector y_j (nothing here needs beta_j):
         t = A y_j with ||t||^2            (the blur's epilogue form)
         sum |grad y_j|^2                   (nsol_tk1_grad_norm_*; B = gradient)
+    -- both sums from the blur itself where A is nsol_amd's one-pass blur on the
+    regulariser's grid (nsol_corr3_wrap_norms_*: it holds y_j with a halo anyway) --
         y' = A^T t                         (the blur)
     -- the three scalars of the step (the two sums and beta_j^2 from the previous
     update) travel to the host on a side stream while that last blur runs -- then
@@ -302,6 +306,10 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     flat = (n,)
     one = (1.0, 1.0, 1.0)
     grad_mode = bmode == ops.B_GRAD
+    norms = None
+    if USE_BLUR_NORMS and grad_mode and len(shape) == 3 and \
+            tuple(getattr(A_axpby, "shape", ())) == tuple(shape):
+        norms = getattr(A_axpby, "norms", None)
     # g = A^T b_top + sa B^T b_bot
     atu = atb() if atb is not None else A_adj(b_top)
     g = torch.empty_like(x_like)
@@ -319,14 +327,17 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     alfa_prev = None
     for itn in range(1, maxiter + 1):
         yj = ys[-1]
-        got = None
-        if A_axpby is not None:
+        got, have_gg = None, False
+        if norms is not None:
+            got = norms(yj, t, w, slots[0:2])
+            have_gg = got is not None
+        if got is None and A_axpby is not None:
             got = A_axpby(yj, t, 1.0, 0.0, result=slots[0:1])
         if got is None:
             t = A(yj)
             ops.lsmr_v_update(t, None, t, ops.B_NONE, flat, one, 1.0, 0.0, 0.0,
                               out=torch.empty_like(t), result=slots[0:1])
-        if grad_mode:
+        if grad_mode and not have_gg:
             ops.tk1_grad_norm(yj, shape, w, result=slots[1:2])
         fetch.start(slots)
         yp = A_adj(t)                                    # A^T A y_j

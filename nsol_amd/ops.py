@@ -186,6 +186,34 @@ def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True,
     return float(res.item()) if sync else res
 
 
+def corr3_wrap_norms(x, out, shape, taps_z, taps_y, taps_x, w, result):
+    """out = blur(x) with result[0] = sum out^2 and result[1] = sum |grad x|^2 of the
+    INPUT (weights w = inverse spacings as for tk1_grad_norm), both taken by the blur
+    itself; result: a two-element float64 device tensor of the caller's (returned, not
+    read back).  None when that kernel does not apply (nothing was launched)."""
+    _same(x, out)
+    _chk(result)
+    if result.numel() != 2 or str(result.dtype) != "torch.float64":
+        raise ValueError("corr3_wrap_norms: result must hold two float64 values")
+    ndim, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(t, dtype=np.float64)
+                  for t in (taps_z, taps_y, taps_x))
+    if nz * ny * nx != x.numel():
+        raise ValueError("corr3_wrap_norms: %d elements for shape %r" %
+                         (x.numel(), tuple(shape)))
+    if ndim != 3 or not (tz.size == ty.size == tx.size):
+        return None
+    ws, _ = _workspace(x.device)
+    rc = _fn("corr3_wrap_norms", x)(
+        _p(x), _p(out), nz, ny, nx, tz.ctypes.data, ty.ctypes.data, tx.ctypes.data,
+        int(tz.size), float(w[0]), float(w[1]), float(w[2]), _p(result), _p(ws),
+        int(ws.numel()), stream_ptr())
+    if rc == -2:
+        return None
+    _lib.check(rc, "nsol_corr3_wrap_norms")
+    return result
+
+
 def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
     _chk(x)
     _chk(taps_dev)

@@ -204,8 +204,14 @@ class TikhonovLinearSolver(LinearSolver):
         op, shape = d[1], tuple(d[2])
         if not hasattr(op, "apply_axpby"):
             return None
-        return lambda v, io, ca, cb, result=None: op.apply_axpby(
-            v, io, shape, ca, cb, result=result)
+        def epilogue(v, io, ca, cb, result=None):
+            return op.apply_axpby(v, io, shape, ca, cb, result=result)
+        # (for lsmr_normal: the blur that also takes sum |grad v|^2 of its input,
+        # where the regulariser's gradient runs over the same 3-D grid)
+        epilogue.shape = shape
+        epilogue.norms = lambda v, out, w, result: op.apply_norms(v, out, shape, w,
+                                                                  result)
+        return epilogue
 
     def _fused_lsmr_setup(self, x0):
         """Arguments for lsmr_fused when the regulariser operator is

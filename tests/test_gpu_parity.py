@@ -190,6 +190,80 @@ def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
     assert abs(got2 - ops.dot(io, io)) / ref2 < 1e-12
 
 
+@pytest.mark.parametrize("shape,sigma2,spacing,dtype,zchunk", [
+    ((20, 37, 64), 2.0, None, np.float64, 0), ((9, 5, 16), 4.0, (1.0, 0.7, 2.5), np.float64, 0),
+    ((33, 70, 132), 1.0, None, np.float32, 0), ((64, 64, 64), 4.0, (0.5, 2.0, 1.25), np.float32, 0),
+    ((40, 48, 512), 4.0, None, np.float32, 0), ((130, 66, 72), 4.0, None, np.float32, 0),
+    ((7, 100, 24), 0.5, None, np.float64, 0), ((16, 16, 16), 7.0, None, np.float32, 0),
+    ((1, 64, 32), 1.0, None, np.float32, 0), ((5, 1, 48), 1.0, None, np.float64, 0),
+    # z-chunk seams: a plane's d_z pairs it with the first plane of the next chunk
+    ((23, 40, 64), 2.0, (1.0, 3.0, 0.5), np.float32, 4), ((17, 64, 20), 4.0, None, np.float64, 7),
+    ((12, 16, 16), 1.0, None, np.float32, 1)])
+def test_blur_norms_match_blur_and_gradient(nsol, shape, sigma2, spacing, dtype, zchunk):
+    """nsol_corr3_wrap_norms_* (out = A x with sum (A x)^2 and, from the tiles of x the
+    blur stages anyway, sum |grad x|^2 of the INPUT: the two sums of a Lanczos step on
+    A'A + rho grad'grad, nsol_amd/lsmr.py) against the blur, nsol_dot and
+    nsol_tk1_grad_norm_*: the gradient's zero boundary against the blur's periodic
+    tiles, tiles that stick out of the volume, z-chunk seams, weights."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, device="cuda", dtype=td, generator=gen) + 0.5
+    A, _ = _lo(3).get_gaussian_blurring_operators(np.diag([sigma2] * 3))
+    w = tuple(1.0 / v for v in (spacing or (1.0, 1.0, 1.0)))
+    want = A(x.view(shape)).view(-1)
+    tt_ref = ops.dot(want, want)
+    gg_ref = ops.tk1_grad_norm(x, shape, w)
+    out = torch.full_like(x, 777.0)
+    slots = torch.zeros(2, dtype=torch.float64, device="cuda")
+    nsol._lib.set_param("corr_blur3_zchunk", zchunk)
+    try:
+        got = A.apply_norms(x, out, shape, w, slots)
+    finally:
+        nsol._lib.set_param("corr_blur3_zchunk", 0)
+    assert got is slots, "the blur with the Lanczos sums did not run"
+    if zchunk == 0:
+        assert torch.equal(out, want)
+    else:
+        assert float((out - want).abs().max()) <= (1e-14 if dtype == np.float64 else 1e-6)
+    tt, gg = (float(v) for v in slots.cpu())
+    assert abs(tt - float((out.double() ** 2).sum())) <= 1e-12 * tt
+    assert abs(tt - tt_ref) <= 1e-12 * tt_ref
+    # (float32: a lane adds the squares of one plane's differences in float before it
+    # widens them, and takes x' - x where the stencil kernel takes w x' - w x)
+    assert abs(gg - gg_ref) <= (1e-12 if dtype == np.float64 else 3e-7) * gg_ref, (gg, gg_ref)
+
+
+def test_blur_norms_refuse_what_they_do_not_cover(nsol):
+    import torch
+    from nsol_amd import ops
+    A, _ = _lo(3).get_gaussian_blurring_operators(np.diag([4.0] * 3))
+    slots = torch.zeros(2, dtype=torch.float64, device="cuda")
+    w = (1.0, 1.0, 1.0)
+    # rows that are not whole 16-byte vectors, operands off the 16-byte grid: nothing
+    # is launched (the caller takes nsol_tk1_grad_norm_* beside the epilogue form)
+    for shape in ((24, 70, 131),):
+        x = torch.randn(int(np.prod(shape)), device="cuda")
+        out = torch.full_like(x, 777.0)
+        assert A.apply_norms(x, out, shape, w, slots) is None
+        assert bool((out == 777.0).all().item())
+    shape = (16, 32, 64)
+    n = int(np.prod(shape))
+    buf = torch.randn(n + 4, device="cuda")
+    out = torch.full((n,), 777.0, device="cuda")
+    assert A.apply_norms(buf[1:n + 1], out, shape, w, slots) is None
+    assert bool((out == 777.0).all().item())
+    x = buf[:n]
+    with pytest.raises(Exception):
+        A.apply_norms(x, x, shape, w, slots)                   # in place
+    with pytest.raises(Exception):
+        A.apply_norms(x, out, shape, w, slots[:1])             # one slot
+    with pytest.raises(Exception):
+        A.apply_norms(x, out[:n - 4], shape, w, slots)         # lengths differ
+
+
 @pytest.mark.parametrize("mode", ["wrap", "constant", "nearest", "reflect",
                                   "mirror"])
 def test_user_kernel_convolution(nsol, golden, mode):
