@@ -16,6 +16,7 @@ constexpr int kBlock = 256;          // 4 waves, one per SIMD
 constexpr int kMaxGridBlocks = 2048;
 constexpr int kMaxGridBlocksLimit = 4096;
 inline int g_max_grid_blocks = kMaxGridBlocks;   // (runtime knob "max_grid_blocks")
+inline int g_stencil_slabs = 1;                  // (runtime knob "stencil_slabs")
 constexpr int kReducePartials = 16384;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -41,6 +42,8 @@ struct Geom {
   int64_t n;    // = nz*ny*nx  (component stride of a gradient field)
   T wx, wy, wz; // 1/h
   int ndim;
+  int slabs;    // stencil kernels deal the rows of a plane to the XCDs in slabs
+                // (voxel_at in nsol_stencil.hpp; runtime knob "stencil_slabs")
 };
 
 template <typename T>
@@ -51,6 +54,7 @@ inline Geom<T> make_geom(int ndim, int64_t nz, int64_t ny, int64_t nx,
   g.sy = nx; g.sz = ny * nx; g.n = nz * ny * nx;
   g.wx = static_cast<T>(wx); g.wy = static_cast<T>(wy); g.wz = static_cast<T>(wz);
   g.ndim = ndim;
+  g.slabs = g_stencil_slabs;
   return g;
 }
 

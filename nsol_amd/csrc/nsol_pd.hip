@@ -622,6 +622,7 @@ int nsol_hip_set_param(const char *name, int value) {
   else if (!strcmp(name, "pd_two_pass")) g_tune.force_two_pass = value;
   else if (!strcmp(name, "pd_xcd_map")) g_tune.xcd_map = value;
   else if (!strcmp(name, "pd_rag")) g_tune.rag = value;
+  else if (!strcmp(name, "stencil_slabs")) g_stencil_slabs = value ? 1 : 0;
   else if (!strcmp(name, "max_grid_blocks"))
     g_max_grid_blocks = value < 1 ? 1 : (value > kMaxGridBlocksLimit ? kMaxGridBlocksLimit : value);
   else return NSOL_EINVAL;

@@ -148,8 +148,28 @@ __device__ __forceinline__ Voxel voxel_at(const Geom<T> &G, int64_t rg) {
     xo = urg % nxo;
     urg /= nxo;
   }
-  c.iz = urg / rgy;
-  c.iy = (int64_t)(urg - (unsigned)c.iz * rgy) * ROWS + (threadIdx.x / XT);
+  // Which XCD runs a workgroup is its linear id (blockIdx.x + gridDim.x * blockIdx.y)
+  // mod 8, so with row groups dealt in their natural order the groups above and below
+  // a workgroup's rows run on OTHER XCDs and every y halo row is a second trip to
+  // memory (k_tk1_reg's Lanczos form fetched 1.4x its 12 B per voxel).  Instead the
+  // P values of blockIdx.y one XCD cycle spans stand for P slabs of a plane's rows: a
+  // slab's groups are then neighbours in one L2, as the groups of the plane above and
+  // below already were (same blockIdx.y mod P, a plane of a slab apart).
+  unsigned iz = urg / rgy, yg = urg - iz * rgy;
+  if (G.slabs && nxo == 1) {
+    const unsigned low = gridDim.x & (0u - gridDim.x);       // gcd(gridDim.x, 8) if < 8
+    const unsigned sh = low >= 8 ? 0u : (low == 4 ? 1u : (low == 2 ? 2u : 3u));
+    const unsigned P = 1u << sh;
+    // (every trip of the grid-stride loop must keep blockIdx.y mod P)
+    if (sh && rgy % P == 0 &&
+        (gridDim.y % P == 0 || (int64_t)gridDim.y >= (int64_t)rgy * G.nz)) {
+      const unsigned per = rgy >> sh, r = urg >> sh;
+      iz = r / per;
+      yg = (urg & (P - 1)) * per + (r - iz * per);
+    }
+  }
+  c.iz = iz;
+  c.iy = (int64_t)yg * ROWS + (threadIdx.x / XT);
   c.ix = (((int64_t)xo * gridDim.x + blockIdx.x) * XT + (threadIdx.x % XT)) * VEC;
   c.ok = c.ix < G.nx && c.iy < G.ny;
   c.i = (c.iz * G.ny + c.iy) * G.nx + c.ix;

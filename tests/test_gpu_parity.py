@@ -1041,6 +1041,40 @@ def test_lanczos_stencil_kernels_match_their_parts(nsol, shape, spacing, dtype):
         ops.tk1_lanczos(x, g, None, shape, w, 0.1, 1.0, 0.0, 0.0, out=x)   # x may not alias out
 
 
+@pytest.mark.parametrize("shape", [(160, 256, 512), (40, 64, 256), (33, 36, 1024),
+                                   (12, 30, 64), (5, 128, 2048)])
+def test_stencil_rows_dealt_in_slabs_change_nothing(nsol, shape):
+    """The stand-alone stencil kernels deal the row groups of a plane to the XCDs in
+    slabs (voxel_at in nsol_stencil.hpp: a permutation of which workgroup takes which
+    rows): every voxel is still visited once, whatever the grid -- one or two workgroups
+    per row, two trips of the grid-stride loop (160 x 256 x 512), row counts the slabs
+    do not divide (the natural order is kept there)."""
+    import torch
+    from nsol_amd import ops
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x, g, z = (torch.randn(n, device="cuda", generator=gen) for _ in range(3))
+    p = torch.randn(3 * n, device="cuda", generator=gen)
+    w = (1.0, 0.5, 2.0)
+
+    def run():
+        out = torch.empty_like(x)
+        nb2 = ops.tk1_lanczos(x, g, z, shape, w, 0.37, 0.8, -1.3, -0.6, out=out)
+        return [ops.grad(x, shape, w), ops.grad_adj(p, shape, w), out], \
+            [nb2, ops.tk1_grad_norm(x, shape, w)]
+    try:
+        nsol._lib.set_param("stencil_slabs", 0)
+        want, sums0 = run()
+        nsol._lib.set_param("stencil_slabs", 1)
+        got, sums1 = run()
+    finally:
+        nsol._lib.set_param("stencil_slabs", 1)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    for a, b in zip(sums1, sums0):                 # (partial sums in another order)
+        assert abs(a - b) <= 1e-12 * abs(b)
+
+
 @pytest.mark.parametrize("weight,scale,takes", [(0.1, 1.0, True), (0.5, 1.0, True),
                                                 (10.0, 10.0, True), (0.05, 1.0, False),
                                                 (0.1, 10.0, False)])
