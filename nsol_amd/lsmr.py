@@ -306,9 +306,12 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     flat = (n,)
     one = (1.0, 1.0, 1.0)
     grad_mode = bmode == ops.B_GRAD
-    norms = None
-    if USE_BLUR_NORMS and grad_mode and len(shape) == 3 and \
-            tuple(getattr(A_axpby, "shape", ())) == tuple(shape):
+    # (B = identity or absent: the same kernel with zero weights -- unlike the
+    # epilogue form it does not read the tile it overwrites)
+    norms, w_norms = None, w if grad_mode else (0.0, 0.0, 0.0)
+    if USE_BLUR_NORMS and (not grad_mode or (
+            len(shape) == 3 and
+            tuple(getattr(A_axpby, "shape", ())) == tuple(shape))):
         norms = getattr(A_axpby, "norms", None)
     # g = A^T b_top + sa B^T b_bot
     atu = atb() if atb is not None else A_adj(b_top)
@@ -329,7 +332,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         yj = ys[-1]
         got, have_gg = None, False
         if norms is not None:
-            got = norms(yj, t, w, slots[0:2])
+            got = norms(yj, t, w_norms, slots[0:2])
             have_gg = got is not None
         if got is None and A_axpby is not None:
             got = A_axpby(yj, t, 1.0, 0.0, result=slots[0:1])

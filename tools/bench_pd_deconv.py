@@ -14,7 +14,14 @@ def main():
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--iter-max", type=int, default=10)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--set", action="append", default=[], dest="py_set",
+                    help="module.NAME=int under nsol_amd (e.g. lsmr.USE_BLUR_NORMS=0)")
     args = ap.parse_args()
+    import importlib
+    for item in args.py_set:
+        path, val = item.split("=")
+        mod, name = path.rsplit(".", 1)
+        setattr(importlib.import_module("nsol_amd." + mod), name, int(val))
     import torch
     import nsol_amd.linear_operators as LO
     import nsol_amd.primal_dual_solver as pd
