@@ -390,7 +390,7 @@ def main():
         normal = bool(lsmr_mod.USE_NORMAL_EQUATIONS) and deferred and \
             0.1 >= lsmr_mod.NE_MIN_WEIGHT[4] and args.iter_max <= lsmr_mod.NE_MAX_ITER
         # (k_wcomb: x assembled from the stored vectors; timed for 11)
-        blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS) and n % 4 == 0
+        blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS)
         if normal:
             per_it = {"k_blur3_dma": args.iter_max + 1,
                       "k_blur3_dma_epi": 0 if blur_norms else args.iter_max,

@@ -175,8 +175,8 @@ int nsol_corr3_wrap_axpby_f64(const double *x, double *io, int64_t nz, int64_t n
  * inverse spacings) and zero behind the last voxel of an axis, exactly
  * nsol_tk1_grad_norm_*'s sum, taken from the tiles of x the blur stages anyway
  * instead of a second pass over x.  ws: >= 2 doubles per tile.  Returns -2 (nothing
- * launched) where nsol_corr3_wrap_axpby_* does, and for rows that are not whole
- * 16-byte vectors or operands off the 16-byte grid. */
+ * launched) where nsol_corr3_wrap_axpby_* does, for 15 / 17 taps in double and
+ * for ragged rows or off-grid operands at 17 taps. */
 int nsol_corr3_wrap_norms_f32(const float *x, float *out, int64_t nz, int64_t ny,
                               int64_t nx, const double *taps_z, const double *taps_y,
                               const double *taps_x, int ntaps, double wx, double wy,

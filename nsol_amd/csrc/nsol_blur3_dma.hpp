@@ -588,11 +588,28 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     if constexpr (EPI == 2) {
       if (st + 1 < nsteps) {
         // plane j of the chunk's nsteps planes is one of its own for R <= j < nsteps - R
-        const V *o = raw + (size_t)r_next + (size_t)(row + R) * rl + lx + NBH;
-        const V own = o[0];
+        const V *rbase = raw + (size_t)r_next;
+        const V *o = rbase + (size_t)(row + R) * rl + lx + NBH;
+        // (RAG: the vector that straddles the row end comes from its row's patch slot,
+        // and the elements of the row's partial vector that lie behind the row read as
+        // zero -- every difference they enter is then the boundary's or zero)
+        auto rd = [&](int dslot, int drow) -> V {
+          if constexpr (RAG) {
+            const V *pslot = rbase + patch0 + (row + R + drow);
+            V v = *((cs >= 0 && lx + NBH + dslot == cs) ? pslot : o + drow * rl + dslot);
+            if (dslot == 0) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) v[k] = k < nvalid ? v[k] : T(0);
+            }
+            return v;
+          } else {
+            return o[drow * rl + dslot];
+          }
+        };
+        const V own = rd(0, 0);
         if (st + 1 >= R && st + 1 < nsteps - R) {          // d_x, d_y of plane st + 1
-          const V right = o[1];
-          const V down = o[rl];
+          const V right = rd(1, 0);
+          const V down = rd(0, 1);
           const V dy = __builtin_elementwise_fma(down, splat<V, T>(ym), -own);
           T sx = T(0), sy = T(0);
 #pragma unroll
@@ -668,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, 
 // LDS-DMA staged kernel: tiles of kDmaLxb lanes per row whatever the row length;
 // returns -2 when it does not apply.  EPI 1 (out = io, in place): io = ca * blur(x) +
 // cb * io and *result = sum of squares of the new io (part: >= tiles doubles).  EPI 2:
-// see the kernel (result[0 .. 1], part: >= 2 * tiles doubles; whole 16-byte rows only).
+// see the kernel (result[0 .. 1], part: >= 2 * tiles doubles).
 template <typename T, int VEC, int NT, int NWD, int EPI = 0>
 int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                      const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
@@ -723,10 +740,10 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int per_xcd = (int)((tiles + 7) / 8);
   bool iso = true;
   for (int t = 0; t < NT; ++t) iso = iso && tz.w[t] == tx.w[t] && ty.w[t] == tx.w[t];
-  // (the difference sums are not instantiated for ragged rows: the caller takes
+  // (the difference sums on ragged rows at 17 taps would spill: the caller takes
   // nsol_tk1_grad_norm_* beside the epilogue form there)
-  if (EPI == 2 && rag) return -2;
-  constexpr bool RG = EPI != 2;
+  constexpr bool RG = !(EPI == 2 && NT >= 17);
+  if (rag && !RG) return -2;
   auto kern = rag ? (iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI, RG>
                          : k_blur3_dma<T, VEC, NT, NWD, false, EPI, RG>)
                   : (iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI, false>

@@ -198,7 +198,12 @@ def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
     ((1, 64, 32), 1.0, None, np.float32, 0), ((5, 1, 48), 1.0, None, np.float64, 0),
     # z-chunk seams: a plane's d_z pairs it with the first plane of the next chunk
     ((23, 40, 64), 2.0, (1.0, 3.0, 0.5), np.float32, 4), ((17, 64, 20), 4.0, None, np.float64, 7),
-    ((12, 16, 16), 1.0, None, np.float32, 1)])
+    ((12, 16, 16), 1.0, None, np.float32, 1),
+    # rows that are not a multiple of 16 bytes: the row's partial vector comes from its
+    # patch slot and its elements behind the row end count for nothing
+    ((24, 70, 131), 4.0, None, np.float32, 0), ((20, 140, 81), 4.0, (1.0, 2.0, 0.5), np.float32, 0),
+    ((33, 20, 517), 4.0, None, np.float32, 5), ((11, 33, 101), 4.0, None, np.float64, 0),
+    ((10, 70, 130), 2.0, None, np.float32, 0), ((14, 65, 45), 2.0, (3.0, 1.0, 1.0), np.float64, 4)])
 def test_blur_norms_match_blur_and_gradient(nsol, shape, sigma2, spacing, dtype, zchunk):
     """nsol_corr3_wrap_norms_* (out = A x with sum (A x)^2 and, from the tiles of x the
     blur stages anyway, sum |grad x|^2 of the INPUT: the two sums of a Lanczos step on
@@ -242,20 +247,26 @@ def test_blur_norms_refuse_what_they_do_not_cover(nsol):
     A, _ = _lo(3).get_gaussian_blurring_operators(np.diag([4.0] * 3))
     slots = torch.zeros(2, dtype=torch.float64, device="cuda")
     w = (1.0, 1.0, 1.0)
-    # rows that are not whole 16-byte vectors, operands off the 16-byte grid: nothing
-    # is launched (the caller takes nsol_tk1_grad_norm_* beside the epilogue form)
-    for shape in ((24, 70, 131),):
+    # ragged rows shorter than a raw tile row (80 floats at 13 taps): nothing is
+    # launched (the caller takes nsol_tk1_grad_norm_* beside the epilogue form)
+    for shape in ((24, 70, 45),):
         x = torch.randn(int(np.prod(shape)), device="cuda")
         out = torch.full_like(x, 777.0)
         assert A.apply_norms(x, out, shape, w, slots) is None
         assert bool((out == 777.0).all().item())
-    shape = (16, 32, 64)
+    # operands off the 16-byte grid take the ragged form
+    shape = (16, 32, 128)
     n = int(np.prod(shape))
     buf = torch.randn(n + 4, device="cuda")
-    out = torch.full((n,), 777.0, device="cuda")
-    assert A.apply_norms(buf[1:n + 1], out, shape, w, slots) is None
-    assert bool((out == 777.0).all().item())
+    obuf = torch.full((n + 4,), 777.0, device="cuda")
+    want = A(buf[1:n + 1].clone().view(shape)).view(-1)
+    gg_ref = ops.tk1_grad_norm(buf[1:n + 1].clone(), shape, w)
+    assert A.apply_norms(buf[1:n + 1], obuf[3:n + 3], shape, w, slots) is slots
+    assert torch.equal(obuf[3:n + 3], want)
+    assert bool((obuf[:3] == 777.0).all().item()) and bool((obuf[n + 3:] == 777.0).all().item())
+    assert abs(float(slots[1]) - gg_ref) <= 3e-7 * gg_ref
     x = buf[:n]
+    out = torch.full((n,), 777.0, device="cuda")
     with pytest.raises(Exception):
         A.apply_norms(x, x, shape, w, slots)                   # in place
     with pytest.raises(Exception):
