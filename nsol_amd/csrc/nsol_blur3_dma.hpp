@@ -459,7 +459,12 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   double sumsq = 0.0;
   // (EPI == 2) weights of the squared differences, zero in lanes that own no voxel;
   // 0 / 1 factors that blank the neighbour behind the volume's last column and row
+  // (both sums of this form gather in T over the planes of one trip through the loop
+  // body -- 4 and 12 squares per plane and lane -- and are widened once per trip:
+  // per plane, six conversions and six double operations were a tenth of the
+  // kernel's issue slots)
   double gsum = 0.0;
+  T sacc = T(0), gacc = T(0);
   V prev_own = splat<V, T>(T(0));
   const T gx2 = owner ? ca : T(0), gy2 = owner ? cb : T(0), gz2 = owner ? cc : T(0);
   const T xm = (xv + 1 < nxv) ? T(1) : T(0);
@@ -487,7 +492,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       if (owner) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          if (!RAG || e < nvalid) sumsq += (double)val[e] * (double)val[e];
+          if (!RAG || e < nvalid) {
+            if constexpr (EPI == 2) sacc = fma1(val[e], val[e], sacc);
+            else sumsq += (double)val[e] * (double)val[e];
+          }
       }
     }
     // (non-temporal: the output is not read again by this launch; 0.2285 -> 0.2245 ms)
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
             sx = fma1(dx, dx, sx);
             sy = fma1(dy[k], dy[k], sy);
           }
-          gsum += (double)fma1(gx2, sx, gy2 * sy);
+          gacc = fma1(gx2, sx, fma1(gy2, sy, gacc));
         }
         if (st >= R && st < nsteps - R) {                  // d_z of plane st
           const T zm = (zbeg + (st - R) + 1 < nz) ? T(1) : T(0);
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
           T sz = T(0);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) sz = fma1(dz[k], dz[k], sz);
-          gsum += (double)(gz2 * sz);
+          gacc = fma1(gz2, sz, gacc);
         }
         prev_own = own;
       }
@@ -639,7 +647,14 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     phase_end((more ? my_stage_ops : 0) + (storing ? my_store_ops : 0));
   };
 #pragma unroll 1
-  for (int st0 = 0; st0 < nsteps; st0 += M) blur3_phases<0, M>(st0, nsteps, phase);
+  for (int st0 = 0; st0 < nsteps; st0 += M) {
+    blur3_phases<0, M>(st0, nsteps, phase);
+    if constexpr (EPI == 2) {
+      sumsq += (double)sacc;
+      gsum += (double)gacc;
+      sacc = gacc = T(0);
+    }
+  }
   if constexpr (EPI != 0) {
     // (the last phase ended with a barrier: the LDS is free)
     double *red = reinterpret_cast<double *>(smem_raw);

@@ -234,11 +234,13 @@ def test_blur_norms_match_blur_and_gradient(nsol, shape, sigma2, spacing, dtype,
     else:
         assert float((out - want).abs().max()) <= (1e-14 if dtype == np.float64 else 1e-6)
     tt, gg = (float(v) for v in slots.cpu())
-    assert abs(tt - float((out.double() ** 2).sum())) <= 1e-12 * tt
-    assert abs(tt - tt_ref) <= 1e-12 * tt_ref
-    # (float32: a lane adds the squares of one plane's differences in float before it
-    # widens them, and takes x' - x where the stencil kernel takes w x' - w x)
-    assert abs(gg - gg_ref) <= (1e-12 if dtype == np.float64 else 3e-7) * gg_ref, (gg, gg_ref)
+    # (float32: a lane adds the squares of up to ntaps - 1 planes in float before it
+    # widens them -- independent errors that average out over the lanes --, and takes
+    # x' - x where the stencil kernel takes w x' - w x)
+    tol = 1e-12 if dtype == np.float64 else 3e-7
+    assert abs(tt - float((out.double() ** 2).sum())) <= tol * tt
+    assert abs(tt - tt_ref) <= tol * tt_ref
+    assert abs(gg - gg_ref) <= tol * gg_ref, (gg, gg_ref)
 
 
 def test_blur_norms_refuse_what_they_do_not_cover(nsol):
