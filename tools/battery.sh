@@ -42,4 +42,7 @@ python tools/bench_f64.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_f64.jso
 # PMC traffic of config 4's kernels (LSMR branch)
 timeout -k 10 400 bash tools/profile_admm_pmc.sh ${TAG}
 python3 tools/summarize_pmc.py k_ $O/${TAG}_admm_pmc_fetch $O/${TAG}_admm_pmc_write > $O/${TAG}_admm_pmc.jsonl
+# ... and of the L-BFGS-B / Huber branch
+timeout -k 10 400 bash tools/profile_admm_pmc_huber.sh ${TAG}
+python3 tools/summarize_pmc.py k_ $O/${TAG}_huber_pmc_fetch $O/${TAG}_huber_pmc_write > $O/${TAG}_admm_lbfgsb_huber_pmc.jsonl
 echo BATTERY_DONE
