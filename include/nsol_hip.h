@@ -730,6 +730,14 @@ int nsol_lb_wcomb_f32(float *out, int64_t n, const int8_t *iwhere, double scale,
                       int nbase, const float *const *base_host,
                       const double *bcoef_host, int nw, const float *const *w_host,
                       const double *wcoef_host, void *stream);
+/* out = clip(sum_k wcoef[k] * w[k], lo, hi): LSMR's solution assembled from its
+ * stored vectors (nsol_amd/lsmr.py) and projected onto the solver's bounds
+ * (tikhonov_linear_solver.py:142-143 applied to the result of :146-158) in one
+ * pass -- nsol_lb_wcomb_*'s sum, term for term, then nsol_clip_*'s projection.
+ * w / wcoef: HOST arrays of nw <= 40 device pointers / doubles. */
+int nsol_lincomb_clip_f32(float *out, int64_t n, int nw, const float *const *w_host,
+                          const double *wcoef_host, double lo, double hi,
+                          void *stream);
 int nsol_lb_project_step_f32(const float *xcp, const float *d, int64_t n, double lo,
                              double hi, const int8_t *iwhere, float *xnew,
                              double *result, double *ws, void *stream);
@@ -762,6 +770,9 @@ int nsol_lb_wcomb_f64(double *out, int64_t n, const int8_t *iwhere, double scale
                       int nbase, const double *const *base_host,
                       const double *bcoef_host, int nw, const double *const *w_host,
                       const double *wcoef_host, void *stream);
+int nsol_lincomb_clip_f64(double *out, int64_t n, int nw, const double *const *w_host,
+                          const double *wcoef_host, double lo, double hi,
+                          void *stream);
 int nsol_lb_project_step_f64(const double *xcp, const double *d, int64_t n, double lo,
                              double hi, const int8_t *iwhere, double *xnew,
                              double *result, double *ws, void *stream);

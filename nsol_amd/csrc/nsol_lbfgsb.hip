@@ -1048,10 +1048,13 @@ struct WComb {
 // VEC elements = 16 bytes per lane and trip; the W vectors are fetched four at a
 // time so that several loads are in flight (with one 4-byte load after the other
 // the kernel ran at 3.6 TB/s for ten stored pairs); the sum keeps its order.
-template <typename T, int VEC>
+// CLIP: the sum is projected onto [lo, hi] as nsol_clip_* does (LSMR's solution
+// assembled from its stored vectors and clipped to the solver's bounds in one pass,
+// tikhonov_linear_solver.py:142-158)
+template <typename T, int VEC, bool CLIP = false>
 __global__ __launch_bounds__(kBlock) void k_wcomb(T *__restrict__ out, int64_t n,
                                                    const int8_t *iw, T scale,
-                                                   WComb<T> C) {
+                                                   WComb<T> C, T lo = T(0), T hi = T(0)) {
   typedef T V __attribute__((ext_vector_type(VEC)));
   typedef int8_t M __attribute__((ext_vector_type(VEC)));
   const int64_t nv = n / VEC;
@@ -1081,6 +1084,14 @@ __global__ __launch_bounds__(kBlock) void k_wcomb(T *__restrict__ out, int64_t n
       }
       for (; q < C.nw; ++q) acc += C.wcoef[q] * reinterpret_cast<const V *>(C.w[q])[j];
       acc *= scale;
+      if constexpr (CLIP) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          T v = acc[e];
+          v = v < lo ? lo : v;
+          acc[e] = v > hi ? hi : v;
+        }
+      }
       if (iw) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
@@ -1586,6 +1597,36 @@ int nsol_lb_masked_gram_rgrad_f64(const double *const *vecs, int nvec,
     else                                                                         \
       hipLaunchKernelGGL((k_wcomb<T, 1>), dim3(grid_for(n)), dim3(kBlock), 0,    \
                          as_stream(s), out, n, iwhere, (T)scale, C);             \
+    return launch_status();                                                      \
+  }                                                                              \
+  int nsol_lincomb_clip_##SUF(T *out, int64_t n, int nw, const T *const *w_host, \
+                              const double *wcoef_host, double lo, double hi,    \
+                              void *s) {                                         \
+    if (n < 1 || !out || nw < 1 || nw > kMaxW || !w_host || !wcoef_host ||       \
+        !(lo <= hi))                                                             \
+      return NSOL_EINVAL;                                                        \
+    WComb<T> C;                                                                  \
+    C.nbase = 0;                                                                 \
+    C.nw = nw;                                                                   \
+    for (int k = 0; k < 3; ++k) { C.base[k] = nullptr; C.bcoef[k] = T(0); }      \
+    for (int j = 0; j < kMaxW; ++j) {                                            \
+      C.w[j] = j < nw ? w_host[j] : nullptr;                                     \
+      C.wcoef[j] = j < nw ? (T)wcoef_host[j] : T(0);                             \
+      if (j < nw && !w_host[j]) return NSOL_EINVAL;                              \
+    }                                                                            \
+    constexpr int VW = 16 / sizeof(T);                                           \
+    bool vec = n % VW == 0 && !(reinterpret_cast<uintptr_t>(out) & 15);          \
+    for (int j = 0; j < nw; ++j)                                                 \
+      vec = vec && !(reinterpret_cast<uintptr_t>(w_host[j]) & 15);               \
+    if (vec)                                                                     \
+      hipLaunchKernelGGL((k_wcomb<T, VW, true>), dim3(grid_for(n / VW)),         \
+                         dim3(kBlock), 0, as_stream(s), out, n,                  \
+                         (const int8_t *)nullptr, T(1), C, cast_bound<T>(lo),    \
+                         cast_bound<T>(hi));                                     \
+    else                                                                         \
+      hipLaunchKernelGGL((k_wcomb<T, 1, true>), dim3(grid_for(n)), dim3(kBlock), \
+                         0, as_stream(s), out, n, (const int8_t *)nullptr, T(1), \
+                         C, cast_bound<T>(lo), cast_bound<T>(hi));               \
     return launch_status();                                                      \
   }                                                                              \
   int nsol_lb_project_step_##SUF(const T *xcp, const T *d, int64_t n, double lo, \

@@ -232,6 +232,10 @@ USE_BLUR_NORMS = True
 LAST_NE_COND = [None]        # (diagnostics: the estimate of the last run)
 
 
+def _clipped(x, bounds):
+    return x if bounds is None else ops.clip(x, bounds[0], bounds[1], out=x)
+
+
 def _aliases(t, *others):
     p = t.untyped_storage().data_ptr()
     return any(o is not None and o.untyped_storage().data_ptr() == p
@@ -284,10 +288,11 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-                A_axpby=None, atb=None):
+                A_axpby=None, atb=None, x_bounds=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
     b_top is only read, b_bot too.  atb: a callable that returns A^T b_top (a caller
-    that solves around the same b again and again keeps it).  Returns (x, istop, itn).
+    that solves around the same b again and again keeps it).  x_bounds: see lsmr_fused.
+    Returns (x, istop, itn).
 
     Per step, on the unnormalised Lanczos vector y_j (nothing here needs beta_j):
         t = A y_j with ||t||^2            (the blur's epilogue form)
@@ -320,7 +325,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                                         0.0, out=g))
     del atu
     if beta1 == 0:
-        return torch.zeros_like(x_like), 0, 0
+        return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
     ys, betas = [g], [beta1]
     co = MinresCoefficients(maxiter + 1, beta1)
     t = torch.zeros_like(x_like)
@@ -381,13 +386,14 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     LAST_NE_COND[0] = co.gmax / co.gmin if co.gmin > 0 else np.inf
     if LAST_NE_COND[0] > NE_MAX_COND[x_like.element_size()]:
         return None, -1, k             # too ill-conditioned for this form
-    x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)])
+    x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)],
+                         bounds=x_bounds)
     return x, istop, k
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None,
-               own_b=True, atb=None):
+               own_b=True, atb=None, x_bounds=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
@@ -396,12 +402,15 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     itself (its epilogue), when A is nsol_amd's one-pass blur.  normb2: the squared
     norm of the right-hand side when the caller has it already.  own_b: b_top may be
     consumed (False: it is the caller's and gets copied where the bidiagonalisation
-    overwrites it).  atb: see lsmr_normal."""
+    overwrites it).  atb: see lsmr_normal.  x_bounds = (lo, hi): the solution comes back
+    projected onto them (tikhonov_linear_solver.py:142-143 applied to the result), in
+    the pass that assembles it from the stored vectors where there is one."""
     import torch
     if atol == 0.0 and btol == 0.0 and \
             normal_equations_ok(bmode, sa, maxiter, x_like):
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
-                                    x_like, maxiter, A_axpby=A_axpby, atb=atb)
+                                    x_like, maxiter, A_axpby=A_axpby, atb=atb,
+                                    x_bounds=x_bounds)
         if x is not None:
             return x, istop, itn
         # (the condition estimate came out too high: nothing was consumed, go on)
@@ -467,7 +476,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     istop = 0
     ctol = 1.0 / conlim if conlim > 0 else 0.0
     if alpha * beta == 0 or normb == 0:
-        return (torch.zeros_like(x_like) if defer else x), istop, itn
+        return _clipped(torch.zeros_like(x_like) if defer else x, x_bounds), istop, itn
 
     while itn < maxiter:
         itn += 1
@@ -567,5 +576,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         if istop > 0:
             break
     if defer:
-        x = ops.lincomb_many(vts, [coef.x[j] / svs[j] for j in range(len(vts))])
+        x = ops.lincomb_many(vts, [coef.x[j] / svs[j] for j in range(len(vts))],
+                             bounds=x_bounds)
+    else:
+        x = _clipped(x, x_bounds)
     return x, istop, itn

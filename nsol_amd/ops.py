@@ -250,9 +250,10 @@ def lincomb3(a, x, b, y, c, z, out=None):
     return out
 
 
-def lincomb_many(vecs, coefs, out=None):
+def lincomb_many(vecs, coefs, out=None, bounds=None):
     """sum_k coefs[k] * vecs[k] in one pass (up to 40 vectors; the terms are added
-    in order): nsol_lb_wcomb_* without base vectors or mask."""
+    in order): nsol_lb_wcomb_* without base vectors or mask.  bounds = (lo, hi): the
+    sum clipped to them in the same pass (nsol_lincomb_clip_*)."""
     import ctypes
     x = _same(vecs[0], *vecs[1:])
     if len(vecs) != len(coefs) or len(vecs) > 40:
@@ -260,8 +261,18 @@ def lincomb_many(vecs, coefs, out=None):
                          % (len(vecs), len(coefs)))
     if out is None:
         out = empty_like(x)
+    else:
+        _same(x, out)
     ptrs = (ctypes.c_void_p * len(vecs))(*[v.data_ptr() for v in vecs])
     co = np.ascontiguousarray(coefs, dtype=np.float64)
+    if bounds is not None:
+        lo, hi = _clip_bounds(x, bounds[0], bounds[1])       # (as clip() has them)
+        if lo <= hi:
+            _lib.check(_fn("lincomb_clip", x)(
+                _p(out), x.numel(), len(vecs), ctypes.cast(ptrs, ctypes.c_void_p),
+                co.ctypes.data, lo, hi, stream_ptr()), "nsol_lincomb_clip")
+            return out
+        return clip(lincomb_many(vecs, coefs, out=out), bounds[0], bounds[1], out=out)
     fn = getattr(_lib.load(), "nsol_lb_wcomb_%s" % suffix(x))
     _lib.check(fn(_p(out), x.numel(), None, 1.0, 0, None, None, len(vecs),
                   ctypes.cast(ptrs, ctypes.c_void_p), co.ctypes.data,
@@ -278,15 +289,20 @@ def scale(x, a, divide=False, out=None):
     return out
 
 
-def clip(x, lo, hi, out=None):
-    _chk(x)
-    if out is None:
-        out = empty_like(x)
+def _clip_bounds(x, lo, hi):
     lo = -1.7976931348623157e308 if lo == -np.inf else float(lo)
     hi = 1.7976931348623157e308 if hi == np.inf else float(hi)
     if x.dtype == torch.float32:
         lo = max(lo, -3.4028234663852886e38)
         hi = min(hi, 3.4028234663852886e38)
+    return lo, hi
+
+
+def clip(x, lo, hi, out=None):
+    _chk(x)
+    if out is None:
+        out = empty_like(x)
+    lo, hi = _clip_bounds(x, lo, hi)
     _lib.check(_fn("clip", x)(_p(out), _p(x), lo, hi, x.numel(),
                               stream_ptr()), "nsol_clip")
     return out

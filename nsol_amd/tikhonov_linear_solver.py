@@ -130,10 +130,7 @@ class TikhonovLinearSolver(LinearSolver):
                 x0 = self._clip_x0()
 
         if lsmr_path:
-            x = self._run_lsmr(x0)
-            if self._bounds is not None:
-                x = ops.clip(x, self._bounds[0], self._bounds[1], out=x)
-            self._x = x
+            self._x = self._run_lsmr(x0)        # (projected onto the bounds)
         elif self._minimizer in ("lsq_linear", "least_squares"):
             self._x = self._run_scipy_least_squares(x0)
         else:
@@ -185,13 +182,16 @@ class TikhonovLinearSolver(LinearSolver):
                                  normb2=None if pre is None else pre[1] + pre[2],
                                  own_b=False,
                                  atb=lambda: _adjoint_of_data(self._A_adj, fused[1],
-                                                              b_top))
+                                                              b_top),
+                                 x_bounds=self._bounds)
             return x
         if pre is not None:            # (not expected: undo the pre-multiplication)
             self._b_reg = ops.scale(self._dev(self._b_reg), 1.0 / pre[0])
             self._prescaled_b_reg = None
         matvec, rmatvec, rhs = self._augmented(x0)
         x, _, _ = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
+        if self._bounds is not None:                       # tikhonov :142-143
+            x = ops.clip(x, self._bounds[0], self._bounds[1], out=x)
         return x
 
     def _blur_epilogue(self, n):

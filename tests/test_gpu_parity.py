@@ -1054,6 +1054,32 @@ def test_lanczos_stencil_kernels_match_their_parts(nsol, shape, spacing, dtype):
         ops.tk1_lanczos(x, g, None, shape, w, 0.1, 1.0, 0.0, 0.0, out=x)   # x may not alias out
 
 
+@pytest.mark.parametrize("n,dtype", [(4096, np.float32), (100003, np.float32),
+                                     (65536, np.float64), (777, np.float64)])
+def test_clipped_linear_combination_matches_combination_then_clip(nsol, n, dtype):
+    """nsol_lincomb_clip_* (LSMR's solution assembled from its stored vectors and
+    projected onto the solver's bounds in one pass) against nsol_lb_wcomb_* followed
+    by nsol_clip_*: the same sum term for term, the same projection."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    vecs = [torch.randn(n, device="cuda", dtype=td, generator=gen) for _ in range(11)]
+    coefs = [0.3 * (-1) ** k * (k + 1) for k in range(11)]
+    for lo, hi in ((0.0, np.inf), (-0.5, 0.25), (-np.inf, np.inf)):
+        want = ops.clip(ops.lincomb_many(vecs, coefs), lo, hi)
+        got = ops.lincomb_many(vecs, coefs, bounds=(lo, hi))
+        assert torch.equal(got, want)
+    # a view off the 16-byte grid takes the element-wise form
+    buf = torch.randn(n + 4, device="cuda", dtype=td, generator=gen)
+    vecs[3] = buf[1:n + 1]
+    out = torch.empty(n + 4, device="cuda", dtype=td)[3:n + 3]
+    want = ops.clip(ops.lincomb_many(vecs, coefs), 0.0, 1.0)
+    assert torch.equal(ops.lincomb_many(vecs, coefs, out=out, bounds=(0.0, 1.0)), want)
+    with pytest.raises(Exception):
+        ops.lincomb_many(vecs, coefs, out=out[:n - 1], bounds=(0.0, 1.0))
+
+
 @pytest.mark.parametrize("shape", [(160, 256, 512), (40, 64, 256), (33, 36, 1024),
                                    (12, 30, 64), (5, 128, 2048)])
 def test_stencil_rows_dealt_in_slabs_change_nothing(nsol, shape):
