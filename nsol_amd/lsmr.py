@@ -288,7 +288,7 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-                A_axpby=None, atb=None, x_bounds=None):
+                A_axpby=None, atb=None, x_bounds=None, b_bot_scale=1.0):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
     b_top is only read, b_bot too.  atb: a callable that returns A^T b_top (a caller
     that solves around the same b again and again keeps it).  x_bounds: see lsmr_fused.
@@ -321,7 +321,8 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     # g = A^T b_top + sa B^T b_bot
     atu = atb() if atb is not None else A_adj(b_top)
     g = torch.empty_like(x_like)
-    beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0, sa,
+    beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0,
+                                        sa * b_bot_scale,
                                         0.0, out=g))
     del atu
     if beta1 == 0:
@@ -393,7 +394,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None,
-               own_b=True, atb=None, x_bounds=None):
+               own_b=True, atb=None, x_bounds=None, b_bot_scale=1.0):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
@@ -404,18 +405,23 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     consumed (False: it is the caller's and gets copied where the bidiagonalisation
     overwrites it).  atb: see lsmr_normal.  x_bounds = (lo, hi): the solution comes back
     projected onto them (tikhonov_linear_solver.py:142-143 applied to the result), in
-    the pass that assembles it from the stored vectors where there is one."""
+    the pass that assembles it from the stored vectors where there is one.
+    b_bot_scale: the lower block of the right-hand side is b_bot_scale * b_bot (the
+    caller's array is then only read: the normal-equations form folds the factor into a
+    coefficient, the bidiagonalisation scales into a copy)."""
     import torch
     if atol == 0.0 and btol == 0.0 and \
             normal_equations_ok(bmode, sa, maxiter, x_like):
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
                                     x_like, maxiter, A_axpby=A_axpby, atb=atb,
-                                    x_bounds=x_bounds)
+                                    x_bounds=x_bounds, b_bot_scale=b_bot_scale)
         if x is not None:
             return x, istop, itn
         # (the condition estimate came out too high: nothing was consumed, go on)
     if not own_b:                 # (the caller's b: consumed below, so work in a copy)
         b_top = b_top.clone()
+    if b_bot is not None and b_bot_scale != 1.0:
+        b_bot = ops.scale(b_bot, b_bot_scale)
     ut, ub = b_top, b_bot
     if normb2 is not None:           # ||[b_top; b_bot]||^2 known to the caller
         normb = math.sqrt(normb2)

@@ -183,7 +183,8 @@ class TikhonovLinearSolver(LinearSolver):
                                  own_b=False,
                                  atb=lambda: _adjoint_of_data(self._A_adj, fused[1],
                                                               b_top),
-                                 x_bounds=self._bounds)
+                                 x_bounds=self._bounds,
+                                 b_bot_scale=self._lower_scale)
             return x
         if pre is not None:            # (not expected: undo the pre-multiplication)
             self._b_reg = ops.scale(self._dev(self._b_reg), 1.0 / pre[0])
@@ -222,6 +223,7 @@ class TikhonovLinearSolver(LinearSolver):
         if b.numel() != n:
             return None
         flat_ok = ops.flat_geometry(n) is not None
+        self._lower_scale = 1.0
         if not (self._alpha > EPS):
             if not flat_ok:
                 return None
@@ -250,6 +252,7 @@ class TikhonovLinearSolver(LinearSolver):
         else:
             return None
         sa = float(np.sqrt(self._alpha))
+        self._lower_scale = 1.0
         if self._prescaled_b_reg is not None and \
                 is_device_tensor(self._b_reg) and self._b_reg.numel() == rows:
             # already sqrt(alpha) * b_reg; consumed by LSMR (it becomes u's lower
@@ -258,7 +261,10 @@ class TikhonovLinearSolver(LinearSolver):
         elif is_device_tensor(self._b_reg) or np.ndim(self._b_reg) > 0:
             if self._prescaled_b_reg is not None:
                 return None
-            lower = ops.scale(self._dev(self._b_reg), sa)
+            # (handed over as it is with its factor: only the bidiagonalisation needs
+            # sqrt(alpha) * b_reg as an array of its own)
+            lower = self._dev(self._b_reg)
+            self._lower_scale = sa
             if lower.numel() != rows:
                 return None
         else:
