@@ -643,6 +643,53 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
         assert rel_l2(s.get_x(), g["admm_lsmr_" + k]) < tol
 
 
+def test_golden_lsmr_solves_run_through_the_blur_with_the_lanczos_sums(nsol, golden,
+                                                                      monkeypatch):
+    """The 3-D goldens above are not held by a fallback: in the default form their
+    LSMR solves take the blur that forms both sums of a Lanczos step
+    (nsol_corr3_wrap_norms_*), in either precision, and the solution is assembled and
+    projected onto the bounds by nsol_lincomb_clip_*; with the form switched off the
+    same goldens are met through nsol_tk1_grad_norm_*."""
+    import nsol_amd.admm_linear_solver as admm
+    import nsol_amd.lsmr as lsmr_mod
+    from nsol_amd import ops
+    g, shape, A, Aa, D, Da = _dec_ops(golden, "3d")
+    y = g["y_3d"]
+    calls = {"norms": 0, "grad_norm": 0, "clipped": 0}
+    real_norms, real_gn, real_lm = ops.corr3_wrap_norms, ops.tk1_grad_norm, ops.lincomb_many
+
+    def norms(*a, **k):
+        r = real_norms(*a, **k)
+        calls["norms"] += r is not None
+        return r
+
+    def grad_norm(*a, **k):
+        calls["grad_norm"] += 1
+        return real_gn(*a, **k)
+
+    def lincomb_many(*a, **k):
+        calls["clipped"] += k.get("bounds") is not None
+        return real_lm(*a, **k)
+    monkeypatch.setattr(ops, "corr3_wrap_norms", norms)
+    monkeypatch.setattr(ops, "tk1_grad_norm", grad_norm)
+    monkeypatch.setattr(ops, "lincomb_many", lincomb_many)
+    for use in (True, False):
+        monkeypatch.setattr(lsmr_mod, "USE_BLUR_NORMS", use)
+        for dtype, tol in ((np.float64, 1e-9), (np.float32, F32_TOL)):
+            for key in calls:
+                calls[key] = 0
+            s = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y,
+                                      dimension=3, alpha=0.05, rho=0.5, iterations=6,
+                                      iter_max=8, x_scale=float(y.max()), dtype=dtype)
+            s.run()
+            assert rel_l2(s.get_x(), g["admm_lsmr_3d"]) < tol
+            assert calls["clipped"] == 6
+            if use:
+                assert calls["norms"] == 6 * 8 and calls["grad_norm"] == 0, calls
+            else:
+                assert calls["norms"] == 0 and calls["grad_norm"] == 6 * 8, calls
+
+
 @pytest.fixture(params=["device-lbfgsb", "scipy-lbfgsb"])
 def lbfgsb_form(request):
     import nsol_amd.tikhonov_linear_solver as tk
