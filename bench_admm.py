@@ -46,6 +46,48 @@ BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
 SETUP_BYTES = 156
 
 
+# the kernels of the LSMR branch as rocprofv3 names them at 512^3 / float32 / 13 taps
+PMC_NAMES = {"k_tk1_lanczos": "k_tk1_reg<float, 4, 4, false, 2>",
+             "k_blur3_dma_norms": "k_blur3_dma<float, 4, 13, 16, true, 2, false>",
+             "k_blur3_dma": "k_blur3_dma<float, 4, 13, 16, true, 0, false>",
+             "k_blur3_dma_epi": "k_blur3_dma<float, 4, 13, 16, true, 1, false>",
+             "k_wcomb": "k_wcomb<float, 4, true>",
+             "k_admm_vw": "k_admm_vw<float, 4, 4, false, true>",
+             "k_lsmr_v": "k_lsmr_v<float, 4, 4, false>",
+             "k_lsmr_u": "k_lsmr_u<float, 4, 4, false>"}
+
+
+def profiled_traffic(kernel, size):
+    """HBM bytes per launch of one of the branch's kernels from the committed rocprofv3
+    PMC passes over this script (profiles/<tag>_admm_pmc.jsonl, tools/battery.sh:
+    separate FETCH_SIZE / WRITE_SIZE passes, 2 * FETCH + WRITE KiB per dispatch as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside
+    this process: the figure belongs to ANOTHER run of the same kernel on the same
+    problem size.  Returns (bytes or None, source or None)."""
+    import glob
+    name = PMC_NAMES.get(kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_admm_pmc.jsonl")))
+    if size != 512 or name is None or not files:
+        return None, None
+    fetch = write = None
+    try:
+        for line in open(files[-1]):
+            rec = json.loads(line)
+            if rec.get("kernel") == name:
+                if rec["counter"] == "FETCH_SIZE":
+                    fetch = float(rec["mean"])
+                elif rec["counter"] == "WRITE_SIZE":
+                    write = float(rec["mean"])
+    except Exception:
+        return None, None
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, \
+        "from_profile: profiles/%s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
+        "of another run, same kernel and size; mean over its dispatches)" % (
+            os.path.basename(files[-1]), name)
+
+
 def bytes_per_admm_iteration(iter_max):
     return iter_max * 108 + SETUP_BYTES
 
@@ -414,11 +456,14 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms_per_admm_iteration"])
         run_bytes = bytes_per_admm_iteration(args.iter_max) * nvox
         run_gbps = run_bytes * args.iterations / med / 1e9
+        traffic, traffic_source = profiled_traffic(dom, n)
         out["roofline"] = {
             "bound": "hbm", "kernel": dom,
             "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None,
-            "traffic_source": None,
+            "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
+            "traffic_source": traffic_source,
+            "frac_traffic": (traffic / (kern[dom]["avg_launch_ms"] * 1e-3) / 1e9 /
+                             HBM_PEAK_GBPS) if traffic else None,
             "avg_launch_ms": kern[dom]["avg_launch_ms"],
             "bytes_per_launch": BYTES[dom] * nvox,
             "kernels": kern,
