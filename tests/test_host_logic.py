@@ -449,3 +449,36 @@ def test_lsmr_solution_coefficients_follow_the_vector_recurrences():
         assert np.allclose(coef.hbar @ V, hbar, rtol=1e-12, atol=1e-12)
     Q, _ = np.linalg.qr(V.T)                  # orthonormal columns: ||x||^2 = sum a^2
     assert np.isclose(coef.normx2(), np.sum((Q @ coef.x) ** 2))
+
+
+def test_minres_coefficients_reproduce_lsmr_iterates():
+    """lsmr_normal runs LSMR as Lanczos on M = A'A + rho B'B with the Paige-Saunders
+    rotations on the host (MinresCoefficients) and x assembled from the Lanczos
+    vectors at the end: in exact arithmetic these are the iterates of SciPy's lsmr on
+    [A; sqrt(rho) B] (tikhonov_linear_solver.py:146-158 on :226-274), iteration by
+    iteration -- checked here in float64 NumPy, where the two agree to rounding."""
+    import scipy.sparse.linalg as sla
+    from nsol_amd.lsmr import MinresCoefficients
+    rng = np.random.default_rng(11)
+    m, n, K = 70, 30, 10
+    A = rng.standard_normal((m, n)) / np.sqrt(m)
+    B = np.eye(n) - np.eye(n, k=1)                      # a difference operator
+    for rho in (0.5, 0.1):
+        Ahat = np.vstack([A, np.sqrt(rho) * B])
+        bhat = np.concatenate([rng.standard_normal(m), np.sqrt(rho) * rng.standard_normal(n)])
+        M = Ahat.T @ Ahat
+        g = Ahat.T @ bhat
+        beta = float(np.linalg.norm(g))
+        V = [g / beta]
+        co = MinresCoefficients(K + 1, beta)
+        for j in range(K):
+            w = M @ V[j] - (beta * V[j - 1] if j > 0 else 0.0)
+            alfa = float(V[j] @ w)
+            w = w - alfa * V[j]
+            beta = float(np.linalg.norm(w))
+            co.step(alfa, beta)
+            V.append(w / beta)
+            x = co.x[:j + 1] @ np.array(V[:j + 1])
+            ref = sla.lsmr(Ahat, bhat, atol=0.0, btol=0.0, conlim=0.0, maxiter=j + 1)[0]
+            assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref), (rho, j)
+        assert co.itn == K and co.gmax / co.gmin < 1e3
