@@ -203,7 +203,9 @@ def test_blur_epilogue_matches_blur_then_combine(nsol, shape, sigma2, dtype):
     # patch slot and its elements behind the row end count for nothing
     ((24, 70, 131), 4.0, None, np.float32, 0), ((20, 140, 81), 4.0, (1.0, 2.0, 0.5), np.float32, 0),
     ((33, 20, 517), 4.0, None, np.float32, 5), ((11, 33, 101), 4.0, None, np.float64, 0),
-    ((10, 70, 130), 2.0, None, np.float32, 0), ((14, 65, 45), 2.0, (3.0, 1.0, 1.0), np.float64, 4)])
+    ((10, 70, 130), 2.0, None, np.float32, 0), ((14, 65, 45), 2.0, (3.0, 1.0, 1.0), np.float64, 4),
+    # BASELINE config 4's own size and blur (sigma = 2: 13 taps), and its ragged neighbour
+    ((512, 512, 512), 4.0, None, np.float32, 0), ((511, 511, 511), 4.0, None, np.float32, 0)])
 def test_blur_norms_match_blur_and_gradient(nsol, shape, sigma2, spacing, dtype, zchunk):
     """nsol_corr3_wrap_norms_* (out = A x with sum (A x)^2 and, from the tiles of x the
     blur stages anyway, sum |grad x|^2 of the INPUT: the two sums of a Lanczos step on
