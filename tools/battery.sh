@@ -26,6 +26,7 @@ timeout -k 10 300 bash tools/profile_blur3.sh ${TAG}
 python3 tools/summarize_pmc.py blur3 $O/${TAG}_blur3_stats $O/${TAG}_blur3_fetch $O/${TAG}_blur3_write $O/${TAG}_blur3_sq1 $O/${TAG}_blur3_sq2 > $O/${TAG}_blur3_pmc.jsonl
 python bench.py --gpus 2 --backend gloo --steps 300 > $O/${TAG}_bench_2ranks_gloo.json 2>> $O/${TAG}_bench.err
 python bench.py --gpus 2 --backend gloo --batch 4 --steps 150 > $O/${TAG}_bench_batch4_2ranks_gloo.json 2>> $O/${TAG}_bench.err
+python bench.py --batch 8 --steps 150 --no-cpu-baseline > $O/${TAG}_bench_batch8.json 2>> $O/${TAG}_bench.err
 python tools/bench_small.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_small.jsonl
 python tools/bench_persist.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_bench_persist.jsonl
 python tools/bench_lbfgsb_kernels.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_lbfgsb_kernels.jsonl
