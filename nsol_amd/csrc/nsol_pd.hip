@@ -623,6 +623,8 @@ int nsol_hip_set_param(const char *name, int value) {
   else if (!strcmp(name, "pd_xcd_map")) g_tune.xcd_map = value;
   else if (!strcmp(name, "pd_rag")) g_tune.rag = value;
   else if (!strcmp(name, "stencil_slabs")) g_stencil_slabs = value ? 1 : 0;
+  else if (!strcmp(name, "stencil_blocks"))
+    g_stencil_blocks = value < 256 ? 256 : (value > kReducePartials ? kReducePartials : value);
   else if (!strcmp(name, "max_grid_blocks"))
     g_max_grid_blocks = value < 1 ? 1 : (value > kMaxGridBlocksLimit ? kMaxGridBlocksLimit : value);
   else return NSOL_EINVAL;

@@ -190,7 +190,7 @@ inline dim3 stencil_grid(int64_t nz, int64_t ny, int64_t nx) {
   int64_t gx = (nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
   if (gx > kStencilMaxTilesX) gx = kStencilMaxTilesX;
   const int64_t nrg = ((ny + ROWS - 1) / ROWS) * nz;
-  int64_t gy = kStencilMaxBlocks / (gx > 0 ? gx : 1);
+  int64_t gy = g_stencil_blocks / (gx > 0 ? gx : 1);
   if (gy < 1) gy = 1;
   if (gy > nrg) gy = nrg;
   return dim3((unsigned)gx, (unsigned)gy, 1);
