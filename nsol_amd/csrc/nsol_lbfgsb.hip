@@ -1036,6 +1036,15 @@ __global__ __launch_bounds__(kBlock) void k_cauchy_finish(
 
 // ---- out = mask ? scale * (sum base + sum_j c_j W_j) : 0
 constexpr int kMaxW = 40;
+// A pass over ten to twenty-odd vectors runs faster with FEWER workgroups than the
+// element-wise kernels' cap (fewer DRAM streams open at a time): the assembly of LSMR's
+// solution from ten vectors at 512^3 takes 1.37 / 1.10 / 1.08 / 1.34 ms with 2 048 /
+// 1 024 / 512 / 256 workgroups, the 23-vector sums of L-BFGS-B 2.6 / 2.5 / 2.5 ms
+// (tools/_probe/wcomb_time.py, lb_grid.py).  Half the cap serves both.
+inline int wcomb_grid(int64_t n) {
+  const int g = grid_for(n), cap = g_max_grid_blocks / 2 > 0 ? g_max_grid_blocks / 2 : 1;
+  return g < cap ? g : cap;
+}
 template <typename T>
 struct WComb {
   const T *base[3];
@@ -1592,10 +1601,10 @@ int nsol_lb_masked_gram_rgrad_f64(const double *const *vecs, int nvec,
     for (int j = 0; j < nw; ++j)                                                 \
       vec = vec && !(reinterpret_cast<uintptr_t>(w_host[j]) & 15);               \
     if (vec)                                                                     \
-      hipLaunchKernelGGL((k_wcomb<T, VW>), dim3(grid_for(n / VW)), dim3(kBlock), \
+      hipLaunchKernelGGL((k_wcomb<T, VW>), dim3(wcomb_grid(n / VW)), dim3(kBlock), \
                          0, as_stream(s), out, n, iwhere, (T)scale, C);          \
     else                                                                         \
-      hipLaunchKernelGGL((k_wcomb<T, 1>), dim3(grid_for(n)), dim3(kBlock), 0,    \
+      hipLaunchKernelGGL((k_wcomb<T, 1>), dim3(wcomb_grid(n)), dim3(kBlock), 0,    \
                          as_stream(s), out, n, iwhere, (T)scale, C);             \
     return launch_status();                                                      \
   }                                                                              \
@@ -1619,12 +1628,12 @@ int nsol_lb_masked_gram_rgrad_f64(const double *const *vecs, int nvec,
     for (int j = 0; j < nw; ++j)                                                 \
       vec = vec && !(reinterpret_cast<uintptr_t>(w_host[j]) & 15);               \
     if (vec)                                                                     \
-      hipLaunchKernelGGL((k_wcomb<T, VW, true>), dim3(grid_for(n / VW)),         \
+      hipLaunchKernelGGL((k_wcomb<T, VW, true>), dim3(wcomb_grid(n / VW)),         \
                          dim3(kBlock), 0, as_stream(s), out, n,                  \
                          (const int8_t *)nullptr, T(1), C, cast_bound<T>(lo),    \
                          cast_bound<T>(hi));                                     \
     else                                                                         \
-      hipLaunchKernelGGL((k_wcomb<T, 1, true>), dim3(grid_for(n)), dim3(kBlock), \
+      hipLaunchKernelGGL((k_wcomb<T, 1, true>), dim3(wcomb_grid(n)), dim3(kBlock), \
                          0, as_stream(s), out, n, (const int8_t *)nullptr, T(1), \
                          C, cast_bound<T>(lo), cast_bound<T>(hi));               \
     return launch_status();                                                      \
