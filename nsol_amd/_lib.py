@@ -101,7 +101,7 @@ def check(rc, what):
 # (nsol_pd.hip PdTuning, nsol_pd2.hip / nsol_pdk.hip Tuning, nsol_conv.hip globals)
 PARAM_DEFAULTS = {
     "pd_zchunk": 0, "pd_ry": 0, "pd_two_pass": 0, "pd_xcd_map": 1, "pd_rag": 1,
-    "max_grid_blocks": 2048, "stencil_slabs": 1, "stencil_blocks": 16384,
+    "max_grid_blocks": 2048, "stencil_slabs": 1, "stencil_blocks": 65536,
     "pd2_zchunk": 0, "pd2_enable": 1, "pd2_variant": 0, "pd2_xcd_map": 1,
     "pdk_enable": 1, "pdk_kmax": 3, "pdk_nw": 0, "pdk_zchunk": 0, "pdk_ntx": 0,
     "pdk_xcd_map": 1, "pdk_verbose": 0, "pdk_autotune": 1, "pdk_pf2": -1,

@@ -17,9 +17,9 @@ constexpr int kMaxGridBlocks = 2048;
 constexpr int kMaxGridBlocksLimit = 4096;
 inline int g_max_grid_blocks = kMaxGridBlocks;   // (runtime knob "max_grid_blocks")
 inline int g_stencil_slabs = 1;                  // (runtime knob "stencil_slabs")
-inline int g_stencil_blocks = 16384;             // (runtime knob "stencil_blocks": workgroups
+inline int g_stencil_blocks = 65536;             // (runtime knob "stencil_blocks": workgroups
                                                  // of a stencil kernel's grid, <= kReducePartials)
-constexpr int kReducePartials = 16384;
+constexpr int kReducePartials = 65536;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

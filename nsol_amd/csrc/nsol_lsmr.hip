@@ -327,8 +327,8 @@ inline int rgrid(int64_t n) {
 // than that reduce through a private scratch area past it is NOT available:
 // instead rows are folded -- see ws_blocks().
 template <int VEC, int ROWS>
-inline int64_t grid_blocks(int64_t nz, int64_t ny, int64_t nx) {
-  const dim3 g = stencil_grid<VEC, ROWS>(nz, ny, nx);
+inline int64_t grid_blocks(int64_t nz, int64_t ny, int64_t nx, int cap = 0) {
+  const dim3 g = stencil_grid<VEC, ROWS>(nz, ny, nx, cap);
   return (int64_t)g.x * g.y * g.z;
 }
 
@@ -430,8 +430,9 @@ int tk1_norm_impl(const T *x, int ndim, int64_t nz, int64_t ny, int64_t nx, doub
   return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
     constexpr bool RG = decltype(rag)::value;
-    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
-    hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG, 1>), (stencil_grid<V, R>(nz, ny, nx)),
+    // (nothing is written but the partial sums: 16 384 workgroups, 0.16 against 0.19 ms)
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx, 16384);
+    hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG, 1>), (stencil_grid<V, R>(nz, ny, nx, 16384)),
                        dim3(kBlock), 0, as_stream(stream), x, (const T *)nullptr,
                        (T *)nullptr, G, T(0), ws);
     hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,

@@ -181,16 +181,22 @@ __device__ __forceinline__ Voxel voxel_at(const Geom<T> &G, int64_t rg) {
   return c;
 }
 
-constexpr int kStencilMaxBlocks = 16384;  // = reduction partials (kReducePartials)
+// Workgroups of a stencil kernel's grid: g_stencil_blocks (knob "stencil_blocks", at
+// most the kReducePartials partial sums the reduction workspace holds).  The more, the
+// better for the kernels that write as much as they read (512^3, 2 048 ... 65 536
+// workgroups: k_grad 0.48 / 0.47 / 0.46 / 0.46 / 0.43 / 0.41 ms, the Lanczos update
+// 0.60 / 0.51 / 0.46 / 0.45 / 0.45 / 0.45, k_admm_vw 1.18 / 1.08 / 1.07 / 1.03 / 1.00 /
+// 0.96; tools/_probe/stencil_time.py); a kernel that only reduces wants fewer (`cap`).
 constexpr int kStencilMaxTilesX = 4096;   // x tiles per grid row; longer rows loop
 
 template <int VEC, int ROWS>
-inline dim3 stencil_grid(int64_t nz, int64_t ny, int64_t nx) {
+inline dim3 stencil_grid(int64_t nz, int64_t ny, int64_t nx, int cap = 0) {
   constexpr int XT = kBlock / ROWS;
   int64_t gx = (nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
   if (gx > kStencilMaxTilesX) gx = kStencilMaxTilesX;
   const int64_t nrg = ((ny + ROWS - 1) / ROWS) * nz;
-  int64_t gy = g_stencil_blocks / (gx > 0 ? gx : 1);
+  const int blocks = cap > 0 && cap < g_stencil_blocks ? cap : g_stencil_blocks;
+  int64_t gy = blocks / (gx > 0 ? gx : 1);
   if (gy < 1) gy = 1;
   if (gy > nrg) gy = nrg;
   return dim3((unsigned)gx, (unsigned)gy, 1);

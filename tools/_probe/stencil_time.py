@@ -32,7 +32,7 @@ cases = [
     ("grad_adj", lambda: ops.grad_adj(p3, shape, w, out=out)),
 ]
 for rep in range(2):
-    for blocks in (16384, 8192, 4096, 2048):
+    for blocks in (65536, 16384, 4096):
         _lib.set_param("stencil_blocks", blocks)
         print("blocks=%d " % blocks + "  ".join("%s %.4f" % (k, t(f)) for k, f in cases), flush=True)
-_lib.set_param("stencil_blocks", 16384)
+_lib.set_param("stencil_blocks", 65536)
