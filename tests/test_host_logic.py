@@ -32,7 +32,7 @@ def test_library_builds_loads_and_exports_declared_symbols():
             assert "nsol_%s_%s" % (base, suf) in decl
     lib = _lib.load()            # binds every symbol or raises
     assert lib.nsol_hip_abi_version() == 1
-    assert lib.nsol_hip_reduce_ws_doubles() == 16384
+    assert lib.nsol_hip_reduce_ws_doubles() == 65536
     assert lib.nsol_lb_gram_ws_doubles() >= 256
     assert lib.nsol_pd_fusedk_launches(3) == 0 and lib.nsol_pd_fusedk_launches(4) == -1
     for name in ("nsol_pd_fusedk_tuned", "nsol_pd_fusedk_plan",
