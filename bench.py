@@ -122,12 +122,35 @@ def cpu_baseline_c(sample_n, iters):
 
 # ------------------------------------------------------------------ launcher
 def visible_gpus():
-    """Device count without creating a HIP context in this process."""
+    """GPUs of this node WITHOUT loading the HIP runtime: the launcher goes on
+    to start the ranks as child processes, and a parent that has initialised a
+    GPU must not do that.  Counted from the KFD topology in sysfs (a node with
+    SIMDs is a GPU), capped by a *_VISIBLE_DEVICES list.  None = unknown (no
+    sysfs here): every rank repeats the check with the runtime's own count and
+    refuses a world larger than it."""
+    root = os.environ.get("NSOL_KFD_TOPOLOGY",
+                          "/sys/class/kfd/kfd/topology/nodes")
     try:
-        import torch
-        return int(torch.cuda.device_count())
-    except Exception:
-        return 0
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            with open(os.path.join(root, d, "properties")) as f:
+                props = f.read()
+        except OSError:
+            continue
+        for line in props.splitlines():
+            key, _, val = line.partition(" ")
+            if key == "simd_count" and val.strip().isdigit() and int(val) > 0:
+                n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
+                "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var) is not None:
+            n = min(n, len([t for t in os.environ[var].split(",")
+                            if t.strip()]))
+    return n
 
 
 def launch_ranks(args, argv):
@@ -135,9 +158,12 @@ def launch_ranks(args, argv):
     child processes (this parent never initialises a GPU), pass rank 0's JSON
     line through, fail if any rank fails."""
     n = args.gpus
-    if args.backend == "nccl" and not args.dry_run:
+    # (--dry-run takes this branch only against a stated topology: the CPU test
+    # of the RCCL launcher path; a bare dry run rehearses on gloo with no GPU)
+    if args.backend == "nccl" and (not args.dry_run or
+                                   "NSOL_KFD_TOPOLOGY" in os.environ):
         have = visible_gpus()
-        if have < n:
+        if have is not None and have < n:
             sys.stderr.write(
                 "bench.py: --gpus %d but only %d GPU(s) visible; refusing to "
                 "report a %d-rank number from fewer devices (use --backend "
@@ -201,6 +227,10 @@ def parse_args(argv):
                          "volumes sharded over the ranks, one gather at the "
                          "end inside the clock (0 = one volume per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the replay of the timed schedule through the "
+                         "one-iteration kernel (profiling passes: keeps the "
+                         "kernel trace to the timed launches)")
     ap.add_argument("--pdk", default="",
                     help="waves:ntx:zchunk -- pin the depth-3 kernel's "
                          "configuration instead of tuning (profiling passes)")
@@ -246,6 +276,9 @@ def dry_run(args, world, rank):
         dist.gather(res, gather_list=bucket, dst=0)
         if rank == 0:
             assert [int(b[0]) for b in bucket] == list(range(world))
+        every = [torch.empty_like(t) for _ in range(world)]     # per-rank ms
+        dist.all_gather(every, torch.tensor([float(rank)], dtype=torch.float64))
+        assert [int(e.item()) for e in every] == list(range(world))
     if rank == 0:
         assert int(joined.item()) == world and float(t.item()) == world
         print(json.dumps({"dry_run": True, "n_gpus": world,
@@ -468,10 +501,72 @@ def main(argv=None):
 
     tmed = median(rep_s)
     kernel_ms = median(rep_kernel_ms)
+    # every rank's own figure travels to rank 0: a straggling GPU shows in the line
+    per_rank_ms = [kernel_ms]
+    if world > 1:
+        mine_ms = torch.tensor([kernel_ms], dtype=torch.float64,
+                               device="cpu" if on_host else dev)
+        every = [torch.empty_like(mine_ms) for _ in range(world)]
+        dist.all_gather(every, mine_ms)
+        per_rank_ms = [float(t.item()) for t in every]
     if triples:
         launches, iters_per_launch = triples, 3
     else:
         launches, iters_per_launch = 1, args.steps
+
+    # The timed state proves itself: replay the SAME schedule from the same
+    # initial state through the one-iteration-per-launch kernel (k_pd_fused,
+    # the form held to the reference goldens and the oracle) and require the
+    # final x, xbar and p to be bit-identical to what the timed launches left
+    # (primal_dual_solver.py:242-256 per iteration).  Every rank checks its own
+    # volume; in --batch mode the last volume of the rank's share.
+    verify = None
+    if not args.no_verify:
+        a = state["slot"]
+        timed = (x.clone(), xbar[a].clone(), p[a].clone())
+        launches_k = ops.pd_fusedk_launches(3)
+        _lib.set_param("pd2_enable", 0)
+        _lib.set_param("pdk_enable", 0)
+        try:
+            if not args.batch:
+                reset(bt)
+                if args.warmup > 0:
+                    run(bt, sig, ta, th, 0, args.warmup, True)
+                first = args.warmup
+                for r in range(reps):
+                    if triples:
+                        run(bt, sig, ta, th, first, 3 * triples, first == 0)
+                    if args.steps > 3 * triples:
+                        run(bt, sig, ta, th, first + 3 * triples,
+                            args.steps - 3 * triples,
+                            first == 0 and triples == 0)
+                    first += args.steps
+                replayed = total
+            else:
+                reset(inputs[-1])
+                run(inputs[-1], sig, ta, th, 0, args.steps, True)
+                replayed = args.steps
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_param("pd2_enable", 1)
+            _lib.set_param("pdk_enable", 1)
+        a = state["slot"]
+        same = [bool(torch.equal(u, v)) for u, v in
+                zip(timed, (x, xbar[a], p[a]))]
+        ok = torch.tensor([int(all(same))], dtype=torch.int64,
+                          device="cpu" if on_host else dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        verify = {"bit_identical": bool(ok.item()),
+                  "rank0_arrays": dict(zip(("x", "xbar", "p"), same)),
+                  "iterations_replayed": replayed,
+                  "depth3_launches_during_replay":
+                      ops.pd_fusedk_launches(3) - launches_k,
+                  "how": "same schedule from the same initial state, one "
+                         "launch of k_pd_fused per iteration (pdk_enable=0, "
+                         "pd2_enable=0); torch.equal on x, xbar and p; every "
+                         "rank, MIN over ranks"}
+        del timed
 
     # for reference: the one-iteration-per-pass kernel on the same state
     single = None
@@ -555,7 +650,10 @@ def main(argv=None):
                 "ranks_joined": int(joined.item()),
                 "gather_ms": gather_ms,
                 "gather_inside_clock": bool(args.batch),
-                "result_finite": finite},
+                "result_finite": finite,
+                "result_bit_identical_to_single_pass":
+                    None if verify is None else verify["bit_identical"],
+                "verification": verify},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -574,6 +672,7 @@ def main(argv=None):
                 "iterations_per_launch": iters_per_launch,
                 "launches": launches,
                 "avg_launch_ms": kernel_ms,
+                "avg_launch_ms_per_rank": per_rank_ms,
                 "avg_launch_ms_repetitions": rep_kernel_ms,
                 "single_pass_reference": single},
         }
@@ -602,6 +701,10 @@ def main(argv=None):
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if verify is not None and not verify["bit_identical"]:
+        sys.stderr.write("bench.py: the timed state is NOT bit-identical to "
+                         "the one-iteration-per-launch replay: %r\n" % (verify,))
+        return 4
     return 0
 
 

@@ -337,6 +337,10 @@ dist.destroy_process_group()
 
 def _bench(*argv, **env):
     e = dict(os.environ, **env)
+    if "NSOL_KFD_TOPOLOGY" in env:      # the stated topology is all there is
+        for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
+                  "CUDA_VISIBLE_DEVICES"):
+            e.pop(k, None)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         if k not in env:
             e.pop(k, None)
@@ -370,6 +374,53 @@ def test_bench_refuses_a_silent_single_gpu_run():
     # a batch that does not divide over the ranks
     r = _bench("--gpus", "2", "--batch", "3", WORLD_SIZE="2", RANK="0")
     assert r.returncode == 2 and b"multiple" in r.stderr
+
+
+def _fake_kfd(tmp_path, simd_counts):
+    for i, simd in enumerate(simd_counts):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(
+            "cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n"
+            % (0 if simd else 64, simd))
+    return str(tmp_path)
+
+
+def test_launcher_counts_gpus_without_the_hip_runtime(tmp_path, monkeypatch):
+    """The parent of `--gpus N` reads the KFD topology (a node with SIMDs is a
+    GPU) instead of asking torch / HIP, which would initialise the runtime in
+    a process that then starts the ranks."""
+    import bench
+    root = _fake_kfd(tmp_path, [0, 0, 1024, 1024, 1024])   # 2 CPU sockets + 3 GPUs
+    monkeypatch.setenv("NSOL_KFD_TOPOLOGY", root)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
+                "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
+    monkeypatch.setenv("NSOL_KFD_TOPOLOGY", str(tmp_path / "absent"))
+    assert bench.visible_gpus() is None                     # unknown: ranks check
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launcher = src[src.index("def visible_gpus"):src.index("def parse_args")]
+    assert "import torch" not in launcher and "device_count" not in launcher
+
+
+def test_rccl_launcher_branch_against_a_stated_topology(tmp_path):
+    """`--backend nccl` in the parent: refuses more ranks than the topology has
+    GPUs before starting anything, starts them otherwise (dry run: the ranks
+    themselves then rendezvous on gloo)."""
+    import json
+    root = _fake_kfd(tmp_path, [0, 1024, 1024])
+    r = _bench("--gpus", "3", "--dry-run", "--backend", "nccl",
+               NSOL_KFD_TOPOLOGY=root)
+    assert r.returncode == 2 and b"only 2 GPU(s) visible" in r.stderr
+    r = _bench("--gpus", "2", "--dry-run", "--backend", "nccl",
+               NSOL_KFD_TOPOLOGY=root)
+    assert r.returncode == 0, r.stderr.decode()
+    d = json.loads([ln for ln in r.stdout.decode().splitlines()
+                    if ln.startswith("{")][0])
+    assert d["ranks_joined"] == 2
 
 
 def test_bridge_tells_gpu_failures_from_numpy_only_callables():

@@ -15,6 +15,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -94,6 +95,7 @@ def main():
             rows.append((kern[:100], ctr, len(use), mean))
             if kern == dominant and ctr == name:
                 summary[name.lower() + "_kib"] = mean
+                summary.setdefault("dominant_instantiation", kern[:80])
     with open(os.path.join(out, "%s_pmc_summary.csv" % args.tag), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "counter", "dispatches", "mean_KiB_per_dispatch"])
@@ -111,7 +113,13 @@ def main():
             table = json.load(open(table_path))
         except Exception:
             table = {}
-        key = "%s:%d:%s" % (args.kernel, args.size,
+        # keyed by the template name of the dominant instantiation
+        # ("k_pd_fusedk"), not by the --kernel substring it was found with:
+        # bench.py looks the entry up by the kernel it timed
+        base = re.search(r"(k_[A-Za-z0-9_]+)",
+                         summary.get("dominant_instantiation", "") or
+                         (dominant or ""))
+        key = "%s:%d:%s" % (base.group(1) if base else args.kernel, args.size,
                             ":".join(str(v) for v in
                                      summary.get("kernel_config", [])))
         table[key] = {"traffic_bytes_per_launch":
