@@ -255,11 +255,15 @@ class MinresCoefficients(object):
         self.x = np.zeros(capacity)
         self.itn = 0
         self.gmax, self.gmin = 0.0, np.inf
+        self.beta1 = float(beta1)
+        self.alfas, self.betas = [], []     # T_k: diagonal, off-diagonal (beta_2 ..)
 
     def step(self, alfa, beta_new):
         """v_{itn} has been multiplied: alfa = v'Mv, beta_new = the next beta."""
         j = self.itn
         self.itn += 1
+        self.alfas.append(float(alfa))
+        self.betas.append(float(beta_new))
         self.oldb, self.beta = self.beta, float(beta_new)
         oldeps = self.epsln
         delta = self.cs * self.dbar + self.sn * alfa
@@ -278,6 +282,35 @@ class MinresCoefficients(object):
         self.w = (e - oldeps * w1 - delta * self.w2) / gamma
         self.x = self.x + phi * self.w
 
+    def lsmr_tests(self, normb2):
+        """The quantities SciPy's LSMR tests after iteration k = itn
+        (scipy lsmr.py:416-449), from the Lanczos / MINRES scalars.  With
+        x_k = V_k z (orthonormal v_j), Abar = [A; sa B], M = Abar'Abar,
+        Abar'b = beta_1 v_1 and V_k' M V_k = T_k = B_k' B_k (the Golub-Kahan
+        bidiagonal of the same Krylov space):
+            ||Abar' r_k|| = phibar_k                  (LSMR's normar = |zetabar|)
+            ||B_k||_F^2   = trace T_k = sum alfa_j    (LSMR's normA^2)
+            ||r_k||^2     = ||b||^2 - 2 beta_1 z_1 + z' T_k z     (normr^2)
+            ||x_k||       = ||z||
+        Returns (test1, test2, t1) = (normr / normb, normar / (normA normr),
+        test1 / (1 + normA normx / normb))."""
+        k = self.itn
+        z = self.x[:k]
+        a = np.asarray(self.alfas[:k])
+        quad = float(np.dot(a, z * z))
+        if k > 1:
+            quad += 2.0 * float(np.dot(np.asarray(self.betas[:k - 1]),
+                                       z[:-1] * z[1:]))
+        normr2 = normb2 - 2.0 * self.beta1 * float(z[0]) + quad
+        normr = math.sqrt(normr2) if normr2 > 0 else 0.0
+        normb = math.sqrt(normb2)
+        normA = math.sqrt(float(np.sum(a)))
+        normx = float(np.linalg.norm(z))
+        test1 = normr / normb
+        test2 = self.phibar / (normA * normr) if normA * normr != 0 else np.inf
+        t1 = test1 / (1 + normA * normx / normb)
+        return test1, test2, t1
+
 
 def normal_equations_ok(bmode, sa, maxiter, x_like):
     return (USE_NORMAL_EQUATIONS and bmode != ops.B_NONE and sa > 0 and
@@ -288,7 +321,8 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-                A_axpby=None, atb=None, x_bounds=None, b_bot_scale=1.0):
+                A_axpby=None, atb=None, x_bounds=None, b_bot_scale=1.0,
+                normb2=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
     b_top is only read, b_bot too.  atb: a callable that returns A^T b_top (a caller
     that solves around the same b again and again keeps it).  x_bounds: see lsmr_fused.
@@ -297,6 +331,15 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     Per step, on the unnormalised Lanczos vector y_j (nothing here needs beta_j):
         t = A y_j with ||t||^2            (the blur's epilogue form)
         sum |grad y_j|^2                   (nsol_tk1_grad_norm_*; B = gradient)
+    SciPy's stopping rules (lsmr.py:416-449, atol = btol = 0, conlim = 1e8) after
+    every iteration: istop 1 / 2 / 4 / 5 (a residual or a normal-equations residual
+    at zero or below machine precision -- a Krylov space exhausted before maxiter)
+    are restated on the MINRES scalars (MinresCoefficients.lsmr_tests; normb2 = the
+    squared norm of the right-hand side, taken here when the caller does not have
+    it); istop 3 / 6 (cond(Abar) estimate >= 1e8 / 1/eps) cannot be reached in this
+    form: it hands a run back to the bidiagonalisation -- which carries SciPy's own
+    tests -- as soon as its estimate of cond(M) = cond(Abar)^2 exceeds NE_MAX_COND
+    (1e3 / 1e7: cond(Abar) <= 32 / 3.2e3).
     -- both sums from the blur itself where A is nsol_amd's one-pass blur on the
     regulariser's grid (nsol_corr3_wrap_norms_*: it holds y_j with a halo anyway) --
         y' = A^T t                         (the blur)
@@ -327,6 +370,25 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     del atu
     if beta1 == 0:
         return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
+    if normb2 is None:
+        # (right-hand side [b_top; b_bot_scale * b_bot])
+        normb2 = ops.dot(b_top, b_top)
+        if b_bot is not None and bmode != ops.B_NONE:
+            normb2 += b_bot_scale ** 2 * ops.dot(b_bot, b_bot)
+
+    def scipy_stop(co):
+        """istop of scipy lsmr.py:432-449 after iteration co.itn (0: go on)."""
+        test1, test2, t1 = co.lsmr_tests(normb2)
+        stop = 0
+        if 1 + test2 <= 1:
+            stop = 5
+        if 1 + t1 <= 1:
+            stop = 4
+        if test2 <= 0.0:
+            stop = 2
+        if test1 <= 0.0:
+            stop = 1
+        return stop
     ys, betas = [g], [beta1]
     co = MinresCoefficients(maxiter + 1, beta1)
     t = torch.zeros_like(x_like)
@@ -355,10 +417,13 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         if alfa_prev is not None:
             beta_j = math.sqrt(nb2) if nb2 > 0 else 0.0
             co.step(alfa_prev, beta_j)
-            if beta_j == 0 or not math.isfinite(beta_j):  # Krylov space exhausted
-                ys.pop()
+            stop = scipy_stop(co)
+            if stop == 0 and (beta_j == 0 or not math.isfinite(beta_j)):
+                stop = 2                                  # Krylov space exhausted
+            if stop:
+                ys.pop()              # (the vector this step was working on)
                 alfa_prev = None
-                istop = 1
+                istop = stop
                 break
             betas.append(beta_j)
         beta = betas[-1]
@@ -383,6 +448,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     if alfa_prev is not None:                            # the last step's beta
         nb2 = float(slots[2].item())
         co.step(alfa_prev, math.sqrt(nb2) if nb2 > 0 else 0.0)
+        istop = scipy_stop(co) or istop      # (SciPy: 7, overridden by 5 / 4 / 2 / 1)
     k = co.itn
     LAST_NE_COND[0] = co.gmax / co.gmin if co.gmin > 0 else np.inf
     if LAST_NE_COND[0] > NE_MAX_COND[x_like.element_size()]:
@@ -414,7 +480,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
             normal_equations_ok(bmode, sa, maxiter, x_like):
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
                                     x_like, maxiter, A_axpby=A_axpby, atb=atb,
-                                    x_bounds=x_bounds, b_bot_scale=b_bot_scale)
+                                    x_bounds=x_bounds, b_bot_scale=b_bot_scale,
+                                    normb2=normb2)
         if x is not None:
             return x, istop, itn
         # (the condition estimate came out too high: nothing was consumed, go on)

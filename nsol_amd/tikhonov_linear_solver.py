@@ -177,7 +177,7 @@ class TikhonovLinearSolver(LinearSolver):
             # in, the normal-equations form only reads it -- and A^T b, the same in
             # every solve of an outer loop around one b, is kept)
             b_top = fused[2]
-            x, _, _ = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
+            x, istop, itn = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
                                  A_axpby=self._blur_epilogue(x0.numel()),
                                  normb2=None if pre is None else pre[1] + pre[2],
                                  own_b=False,
@@ -185,12 +185,14 @@ class TikhonovLinearSolver(LinearSolver):
                                                               b_top),
                                  x_bounds=self._bounds,
                                  b_bot_scale=self._lower_scale)
+            self._lsmr_stop = (istop, itn)     # (SciPy's istop, iterations taken)
             return x
         if pre is not None:            # (not expected: undo the pre-multiplication)
             self._b_reg = ops.scale(self._dev(self._b_reg), 1.0 / pre[0])
             self._prescaled_b_reg = None
         matvec, rmatvec, rhs = self._augmented(x0)
-        x, _, _ = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
+        x, istop, itn = lsmr(matvec, rmatvec, rhs, x0, self._iter_max)
+        self._lsmr_stop = (istop, itn)
         if self._bounds is not None:                       # tikhonov :142-143
             x = ops.clip(x, self._bounds[0], self._bounds[1], out=x)
         return x

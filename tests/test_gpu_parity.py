@@ -1208,6 +1208,118 @@ def test_normal_equations_form_is_taken_by_relative_weight(nsol, weight, scale, 
         assert np.array_equal(outs[0], outs[1])
 
 
+def _cfg4_ops(n):
+    lo = _lo(3)
+    A, A_adj = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
+    grad, grad_adj = lo.get_gradient_operators()
+    X, Z = (n, n, n), (3 * n, n, n)
+    return (lambda x: A(x.reshape(*X)).flatten(),
+            lambda x: A_adj(x.reshape(*X)).flatten(),
+            lambda x: grad(x.reshape(*X)).flatten(),
+            lambda x: grad_adj(x.reshape(*Z)).flatten())
+
+
+@pytest.mark.parametrize("bname,wname,iters",
+                         [(b, "edge", it) for b in ("grad", "ident")
+                          for it in (10, 20, 32)] +
+                         [("grad", "cfg4", 32), ("ident", "cfg4", 32)])
+def test_normal_equations_lsmr_at_the_edge_of_its_guard(nsol, golden, bname, wname,
+                                                        iters):
+    """LSMR runs as Lanczos / MINRES on A'A + weight B'B (nsol_amd/lsmr.py) in place
+    of SciPy's Golub-Kahan LSMR (tikhonov_linear_solver.py:146-158) when the weight
+    is >= 0.1 x ||A v_1||^2 and iter_max <= NE_MAX_ITER.  Here the weight sits
+    exactly on that bound (and at config 4's rho = 0.1), sigma = 2 blur at 32^3,
+    B = gradient and B = identity, 10 / 20 / 32 iterations; against what the
+    REFERENCE produced (tests/golden/cfg4.npz), float32 at north_star's 1e-5."""
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.lsmr as L
+    g = golden("cfg4")
+    A, Aa, D, Da = _cfg4_ops(32)
+    I = lambda x: x.flatten()
+    B, Ba = (D, Da) if bname == "grad" else (I, I)
+    y = g["y_32"]
+    ratio = float(g["ratio_32"])
+    # (on the bound up to rounding: the guard's own (1 - 1e-9) slack lets it pass)
+    weight = 0.1 * ratio if wname == "edge" else 0.1
+    ref = g["tk_%s_%s_%d" % (bname, wname, iters)]
+    for dtype, tol in ((np.float64, 1e-9), (np.float32, F32_TOL)):
+        L.LAST_NE_COND[0] = None
+        s = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=B, B_adj=Ba, b=y, x0=y,
+                                    alpha=weight, x_scale=float(y.max()),
+                                    iter_max=iters, dtype=dtype)
+        s.run()
+        assert L.LAST_NE_COND[0] is not None, "the normal-equations form did not run"
+        assert rel_l2(s.get_x(), ref,
+                      "%s %s %d %s cond %.3g" % (bname, wname, iters,
+                                                 np.dtype(dtype).name,
+                                                 L.LAST_NE_COND[0])) < tol
+
+
+@pytest.mark.parametrize("branch", ["lsmr", "lbfgsb_huber"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_config4_at_contract_depth_matches_the_reference(nsol, golden, branch, dtype):
+    """BASELINE config 4 as the contract states it -- rho = 0.1, alpha = 0.01,
+    10 ADMM x 10 inner iterations (admm_linear_solver.py:165-218), sigma = 2 blur,
+    TK1 inner problem -- at 40^3, both branches, against the reference's own output
+    (tests/golden/cfg4.npz); float32 is what bench_admm.py times."""
+    import nsol_amd.admm_linear_solver as admm
+    g = golden("cfg4")
+    A, Aa, D, Da = _cfg4_ops(40)
+    y = g["y_40"]
+    kw = {} if branch == "lsmr" else dict(minimizer="L-BFGS-B", data_loss="huber",
+                                          data_loss_scale=1)
+    s = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y, dimension=3,
+                              alpha=0.01, rho=0.1, iterations=10, iter_max=10,
+                              x_scale=float(y.max()), dtype=dtype, **kw)
+    s.run()
+    tol = F32_TOL if dtype == np.float32 else 1e-8
+    assert rel_l2(s.get_x(), g["admm_%s_40" % branch],
+                  "%s %s" % (branch, np.dtype(dtype).name)) < tol
+
+
+@pytest.mark.parametrize("bname", ["grad", "ident"])
+def test_lsmr_stops_where_scipys_does_when_the_krylov_space_runs_out(nsol, bname):
+    """A 9-sample signal and iter_max = 15: SciPy's LSMR (atol = btol = 0) ends on
+    its machine-precision tests (istop 4 / 5, lsmr.py:432-449) after about nine
+    iterations, not on maxiter.  The normal-equations form restates those tests on
+    the MINRES scalars; both forms stop with SciPy's code at SciPy's iteration (one
+    step of slack: the tests compare against rounding) and return its solution."""
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.lsmr as L
+    from oracle import nsol_oracle as orc
+    n = 9
+    rng = np.random.default_rng(5)
+    lo = _lo(1)
+    A, A_adj = lo.get_gaussian_blurring_operators(0.5)
+    grad, grad_adj = lo.get_gradient_operators()
+    I = lambda x: x.flatten()
+    B, Ba = (grad, grad_adj) if bname == "grad" else (I, I)
+    y = 50.0 + 10.0 * rng.standard_normal(n)
+    xs = float(y.max())
+    Do, Dao, Ao, _ = orc.flat_operators((n,), None, 0.5)
+    Bo, Bao = (Do, Dao) if bname == "grad" else (I, I)
+    sa = np.sqrt(0.3)
+    mv = lambda x: np.concatenate((Ao(x), sa * Bo(x)))
+    rmv = lambda u: Ao(u[:n]) + sa * Bao(u[n:])
+    rhs = np.concatenate((y / xs, np.zeros(mv(y).size - n)))
+    xo, istop_o, itn_o = orc.lsmr(mv, rmv, rhs, n, 15)
+    assert istop_o in (4, 5) and itn_o < 15
+    for ne in (True, False):
+        L.USE_NORMAL_EQUATIONS = ne
+        L.LAST_NE_COND[0] = None
+        try:
+            s = tk.TikhonovLinearSolver(A=A, A_adj=A_adj, B=B, B_adj=Ba, b=y, x0=y,
+                                        alpha=0.3, x_scale=xs, iter_max=15,
+                                        bounds=None, dtype=np.float64)
+            s.run()
+        finally:
+            L.USE_NORMAL_EQUATIONS = True
+        assert (L.LAST_NE_COND[0] is not None) == ne
+        istop, itn = s._lsmr_stop
+        assert istop in (2, 4, 5) and abs(itn - itn_o) <= 1, (ne, istop, itn, itn_o)
+        assert rel_l2(s.get_x(), xo * xs) < 1e-9
+
+
 def test_foreign_numpy_callables_take_the_host_bridge(nsol, golden):
     """A caller may still pass plain NumPy lambdas (the reference contract)."""
     import nsol_amd.primal_dual_solver as pd
@@ -1972,6 +2084,27 @@ def test_full_size_512_properties(nsol):
     c = _run_pd_raw(shape, np.float32, 5, flags, enable2=0, two_pass=1)
     for u, v in zip(b[:3], c[:3]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("plan", [(12, 2, 103), (8, 3, 64), (12, 2, 64)])
+def test_timed_plans_at_512_are_bit_identical(nsol, plan):
+    """The configuration bench.py times (the tuner settles on 12 waves x 2 tiles
+    x z-chunk 103 at 512^3: five z-chunk seams) and an 8-wave plan, pinned, over
+    12 iterations (four depth-3 launches): x, xbar and p bit-identical to twelve
+    launches of the one-iteration kernel (primal_dual_solver.py:242-256)."""
+    import torch
+    from nsol_amd import ops
+    shape = (512, 512, 512)
+    flags = ops.PD_REG_TV | ops.PD_DATA_L2
+    w = (1.0, 1.0, 1.0)
+    ref = _run_pd_raw(shape, np.float32, 12, flags, enable2=0, w=w)
+    before = ops.pd_fusedk_launches(3)
+    got = _run_pd_raw(shape, np.float32, 12, flags, enable2=1, w=w,
+                      pdk=dict(pdk_enable=1, pdk_nw=plan[0], pdk_ntx=plan[1],
+                               pdk_zchunk=plan[2], pdk_min_kvox=1024))
+    assert ops.pd_fusedk_launches(3) == before + 4, "the pinned plan did not run"
+    for name, a, b in zip(("x", "xbar", "p"), ref[:3], got[:3]):
+        assert torch.equal(a, b), (plan, name)
 
 
 @pytest.mark.parametrize("shape", [(1000,), (7,), (33, 20), (64, 256),

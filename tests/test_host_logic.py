@@ -423,6 +423,54 @@ def test_rccl_launcher_branch_against_a_stated_topology(tmp_path):
     assert d["ranks_joined"] == 2
 
 
+def test_minres_scalars_restate_scipys_lsmr_stopping_tests():
+    """nsol_amd/lsmr.py runs LSMR as Lanczos / MINRES on the normal equations;
+    SciPy's stopping quantities (lsmr.py:416-449 behind
+    tikhonov_linear_solver.py:146-158) are rebuilt from the MINRES scalars
+    (MinresCoefficients.lsmr_tests).  Host arithmetic only: Lanczos in NumPy on
+    small dense systems, every iterate against the oracle's LSMR, the tests
+    against their definitions, and the iteration at which a 7-dimensional Krylov
+    space is exhausted (SciPy: istop 5 at itn 7) found at the same step."""
+    import math
+    from nsol_amd.lsmr import MinresCoefficients
+    from oracle import nsol_oracle as orc
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        m, n = 30, 7
+        Ab, b = rng.standard_normal((m, n)), rng.standard_normal(m)
+        M, g = Ab.T @ Ab, Ab.T @ b
+        beta1 = np.linalg.norm(g)
+        V, betas, vprev = [g / beta1], [beta1], np.zeros(n)
+        co = MinresCoefficients(12, beta1)
+        fired = None
+        for k in range(1, 10):
+            v = V[-1]
+            y = M @ v
+            alfa = v @ y
+            y = y - alfa * v - betas[-1] * vprev * (k > 1)
+            beta = np.linalg.norm(y)
+            co.step(alfa, beta)
+            x = np.stack(V, 1) @ co.x[:k]
+            xo, istop_o, itn_o = orc.lsmr(lambda u: Ab @ u, lambda u: Ab.T @ u,
+                                          b, n, k)
+            test1, test2, t1 = co.lsmr_tests(float(b @ b))
+            r = b - Ab @ x
+            if itn_o == k:
+                assert np.linalg.norm(x - xo) <= 1e-13 * np.linalg.norm(xo)
+            assert abs(test1 - np.linalg.norm(r) / np.linalg.norm(b)) < 1e-13
+            if k < n:
+                true2 = np.linalg.norm(Ab.T @ r) / np.linalg.norm(r)
+                assert abs(test2 * math.sqrt(sum(co.alfas)) - true2) < 1e-10 * true2
+                assert istop_o == 7 and not (1 + test2 <= 1) and not (1 + t1 <= 1)
+            elif fired is None and 1 + test2 <= 1:
+                fired = k
+                assert (istop_o, itn_o) == (5, k)
+            vprev = v
+            V.append(y / beta)
+            betas.append(beta)
+        assert fired == n
+
+
 def test_bridge_tells_gpu_failures_from_numpy_only_callables():
     """BridgedCallable falls back to the host round trip only for callables
     that cannot take a tensor; a failing launch or an out-of-memory error is

@@ -417,3 +417,26 @@ def test_admm_refstyle_equals_restatement(golden):
     out = orc.admm_lsmr_refstyle(y, DEC["3d"], g["cov_3d"], 0.05, 0.5, 6, 8,
                                  float(y.max()))
     assert rel_l2(out, g["admm_lsmr_3d"]) < 1e-10
+
+
+CFG4_TK = [(b, "edge", it) for b in ("grad", "ident") for it in (10, 20, 32)] + \
+    [("grad", "cfg4", 32), ("ident", "cfg4", 32)]
+
+
+@pytest.mark.parametrize("bname,wname,iters", CFG4_TK)
+def test_lsmr_at_the_normal_equations_guard_matches_reference(golden, bname,
+                                                              wname, iters):
+    """tests/golden/cfg4.npz: the reference's LSMR (tikhonov_linear_solver.py:
+    146-158) on config 4's blur at 32^3 with the regulariser's weight where the
+    build's normal-equations form starts (0.1 relative) -- the restated
+    Golub-Kahan LSMR must reproduce what SciPy's produced, up to 32 iterations."""
+    g = golden("cfg4")
+    n = 32
+    D, Da, A, _ = orc.flat_operators((n, n, n), None, np.diag([4.0, 4.0, 4.0]))
+    ident = lambda v: v.reshape(-1)
+    B, Ba = (D, Da) if bname == "grad" else (ident, ident)
+    y = g["y_32"]
+    weight = 0.1 * float(g["ratio_32"]) if wname == "edge" else 0.1
+    out = orc.tikhonov(A, A, B, Ba, y, y, alpha=weight, iter_max=iters,
+                       x_scale=float(y.max()))
+    assert rel_l2(out, g["tk_%s_%s_%d" % (bname, wname, iters)]) < 1e-10
