@@ -55,9 +55,15 @@
 using namespace nsol;
 
 // Timing experiments only (wrong results): -DPDK_ABLATE=1 no global loads,
-// 2 no global stores, 4 no barrier; bits combine.
+// 2 no global stores, 4 no barrier, 8 no arithmetic (memory pattern + LDS exchange
+// + barrier only), 16 with 8: no LDS exchange and no barrier either; bits combine
+// (DESIGN.md section 5).
 #ifndef PDK_ABLATE
 #define PDK_ABLATE 0
+#endif
+// cache policy of the 16-byte plane loads (experiments: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef PDK_LOAD_AUX
+#define PDK_LOAD_AUX 0
 #endif
 
 namespace nsol_pdk {
@@ -101,7 +107,7 @@ __device__ __forceinline__ void bld(rsrc_t r, uint32_t vo, uint32_t so, T (&v)[V
   for (int k = 0; k < V; ++k) v[k] = T(1e-3) * (T)((vo + so + k) & 255u);
   return;
 #endif
-  const P t = __builtin_bit_cast(P, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+  const P t = __builtin_bit_cast(P, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, PDK_LOAD_AUX));
 #pragma unroll
   for (int k = 0; k < V; ++k) v[k] = t[k];
 }
@@ -469,6 +475,59 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   auto step = [&](auto have1_tag, int s, Loads &L, Loads &LN, const Carry &P,
                   Carry &N) {
     constexpr bool HAVE1 = decltype(have1_tag)::value;
+#if PDK_ABLATE & 8
+    {
+      // Timing experiment (wrong results): the step's memory traffic without its
+      // arithmetic -- the prefetched plane is summed up (every load stays alive),
+      // the sum goes through the LDS exchange and the barrier of a step (bit 16:
+      // neither) and out through the five stores.
+      const bool more = s + 1 <= s_hi;
+      T acc[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        acc[j] = L.xn[j] + L.xv[j] + L.btn[j] + L.pxo[j] + L.pyo[j] + L.pzo[j] + L.xdown[j] +
+                 L.xup[j] + L.pyup[j] + L.xright + L.xleft + L.pxleft + P.xc[j];
+      if constexpr (HAVE1) issue_loads(L, more ? s + 1 : s, more ? adv + szb : adv);
+      const int buf = (int)(s & 1);
+#if !(PDK_ABLATE & 16)
+#pragma unroll
+      for (int k = 2; k <= K; ++k) {
+        stv<T, VEC>(&s_xb[buf][k - 2][li], acc);
+        stv<T, VEC>(&s_py[buf][k - 2][li], acc);
+        s_px[buf][k - 2][slot] = acc[0];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 2; k <= K; ++k) {
+        T below[VEC], above[VEC], above_py[VEC];
+        ldv<T, VEC>(&s_xb[buf][k - 2][li + lxb * VEC], below);
+        ldv<T, VEC>(&s_xb[buf][k - 2][li - lxb * VEC], above);
+        ldv<T, VEC>(&s_py[buf][k - 2][li - lxb * VEC], above_py);
+        const T e = s_xb[buf][k - 2][li + VEC] + s_xb[buf][k - 2][li - 1] +
+                    s_px[buf][k - 2][slot - 1];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += below[j] + above[j] + above_py[j] + e;
+      }
+#endif
+      const int f = s - (K - 1);
+      if (f >= zbeg && f < zend) {
+        const uint32_t vo = v_st + (adv - (uint32_t)(K - 1) * szb);
+        store_vec(w_pz, vo, acc);
+        store_vec(w_x, vo, acc);
+        store_vec(w_xb, vo, acc);
+      }
+      const int a = s - (K - 2);
+      if (a >= zbeg && a < zend) {
+        const uint32_t vo = v_st + (adv - (uint32_t)(K - 2) * szb);
+        store_vec(w_px, vo, acc);
+        store_vec(w_py, vo, acc);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) N.xc[j] = acc[j];
+      adv += szb;
+      return;
+    }
+#endif
     // fr_*[k-1]: results of stage k produced in this step
     T fr_xb[K][VEC], fr_x[K][VEC], fr_bt[K][VEC], pzn[K][VEC];
     T f_px[VEC], f_py[VEC];
