@@ -361,8 +361,12 @@ int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx
  * tile's x, xbar, b~, p in registers for all iterations and hands the one-voxel
  * faces to its face neighbours through tagged 8-byte granules in `ws`
  * (nsol_pdp.hip).  Bit-identical to `iterations` calls of nsol_pd_fused_iter_*.
- * xbar, x, p are updated in place (p is read only when p_is_zero == 0); the step
- * sizes are host arrays as for nsol_pd_run_*.  ws: caller-owned DEVICE scratch
+ * nsol_pd_persist_run_*: xbar, x, p are updated in place (p is read only when
+ * p_is_zero == 0).  nsol_pd_persist_run_to_*: the state is read from (xbar, x, p)
+ * and the result written to (xbar_out, x_out, p_out) -- with distinct output
+ * arrays the inputs survive a run that raised the error word, and the caller
+ * repeats it through nsol_pd_run_* (one launch per iteration, the same bits).
+ * The step sizes are host arrays as for nsol_pd_run_*.  ws: caller-owned DEVICE scratch
  * of nsol_pd_persist_ws_bytes() bytes, 16-byte aligned; a small set-up kernel
  * on `stream` fills it (the step sizes travel as its arguments).  err_word:
  * a 32-bit word the kernel can write, zeroed by the caller -- device memory or
@@ -371,7 +375,8 @@ int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx
  * run if a workgroup gave up waiting for a neighbour (every wait is bounded;
  * the results are then invalid).
  * Returns -2 (nothing launched) when the kernel does not apply: rows not a
- * multiple of 16 bytes, unaligned arrays, more tiles than CUs.
+ * multiple of 16 bytes, unaligned arrays, more tiles than the device can hold
+ * resident at once (occupancy of the kernel x CU count).
  * nsol_pd_persist_ws_bytes returns -1 in that case. */
 int64_t nsol_pd_persist_ws_bytes(int elem_size, int ndim, int64_t nz, int64_t ny,
                                  int64_t nx, int iterations);
@@ -389,6 +394,22 @@ int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p
                             int iterations, int p_is_zero, double gamma_huber, int flags,
                             void *ws, int64_t ws_bytes, unsigned int *err_word,
                             void *stream);
+int nsol_pd_persist_run_to_f32(const float *xbar, const float *x, const float *bt,
+                               const float *p, float *xbar_out, float *x_out,
+                               float *p_out, int ndim, int64_t nz, int64_t ny, int64_t nx,
+                               double wx, double wy, double wz, double lambda,
+                               const double *sigma_host, const double *tau_host,
+                               const double *theta_host, int iterations, int p_is_zero,
+                               double gamma_huber, int flags, void *ws, int64_t ws_bytes,
+                               unsigned int *err_word, void *stream);
+int nsol_pd_persist_run_to_f64(const double *xbar, const double *x, const double *bt,
+                               const double *p, double *xbar_out, double *x_out,
+                               double *p_out, int ndim, int64_t nz, int64_t ny, int64_t nx,
+                               double wx, double wy, double wz, double lambda,
+                               const double *sigma_host, const double *tau_host,
+                               const double *theta_host, int iterations, int p_is_zero,
+                               double gamma_huber, int flags, void *ws, int64_t ws_bytes,
+                               unsigned int *err_word, void *stream);
 /* `iterations` iterations enqueued back to back with the host-side step
  * schedule (primal_dual_solver.py:278-403): sigma/tau/theta_host[n] are the
  * values used in iteration n.  xbar0/xbar1 and p0/p1 are ping-pong buffers;

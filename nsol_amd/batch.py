@@ -15,6 +15,15 @@ def shard_indices(n_items, rank, world_size):
     return list(range(rank, n_items, world_size))
 
 
+def _settle():
+    """Results built from ops.pd_run directly (not through Solver.run(), which
+    settles itself): the verdict of the persistent runs before anything is sent."""
+    import sys
+    ops = sys.modules.get("nsol_amd.ops")
+    if ops is not None:
+        ops.settle_persist_runs()
+
+
 def solve_batch(solve_one, n_items, group=None, dst=0):
     """Run solve_one(i) -> 1-D tensor for the items this rank owns, then gather
     all results on rank `dst` in item order.
@@ -23,11 +32,14 @@ def solve_batch(solve_one, n_items, group=None, dst=0):
     Every result must have the same length and dtype (one reconstruction per
     volume)."""
     if not dist.is_initialized():
-        return [solve_one(i) for i in range(n_items)]
+        out = [solve_one(i) for i in range(n_items)]
+        _settle()
+        return out
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     mine = shard_indices(n_items, rank, world)
     local = [solve_one(i) for i in mine]
+    _settle()
     if n_items == 0:
         return [] if rank == dst else None
     # Length, dtype and device of a result are agreed before the first gather,

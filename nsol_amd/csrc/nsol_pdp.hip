@@ -27,11 +27,15 @@
 // old p and xbar, exactly as k_pd_fused recomputes it across its patches), so the
 // result is bit-identical to one launch of k_pd_fused per iteration.
 //
-// Co-residency: the grid is at most one workgroup per CU (checked on the host), so
-// every workgroup is running when its neighbours wait for it.  Every wait is still
-// bounded: a workgroup that does not see a flag within ~2^21 polls gives up
-// polling for the rest of the run and raises the error word of the workspace,
-// which the host reads after the run -- no wave can spin forever.
+// Co-residency: the grid is at most one workgroup per CU (checked on the host, against
+// the occupancy the runtime reports for this kernel and launch shape), so every
+// workgroup is running when its neighbours wait for it.  On a shared or CU-masked
+// device that can still fail, so every wait is bounded: a workgroup that does not see
+// a flag within ~2^21 polls gives up polling for the rest of the run and raises the
+// error word, which the host reads after the run -- no wave can spin forever.  The
+// kernel READS the state from (xbar, x, p) and WRITES the result to (xbar_out,
+// x_out, p_out): with distinct output arrays the inputs survive a failed run and the
+// caller repeats it with one launch per iteration (nsol_amd/ops.py does).
 #include <string.h>
 
 #include "nsol_common.hpp"
@@ -44,6 +48,11 @@ namespace {
 constexpr int kMaxTiles = 256;
 constexpr int kMaxSpin = 1 << 21;   // polling rounds of ~1-2 us before a workgroup gives up
 constexpr int kKinds = 3;          // XF: xbar first layer, XL: xbar last, PL: p last
+// debug knobs (nsol_hip_set_param_pdp): "pdp_max_spin" bounds the polls of a wait,
+// "pdp_mute_tile" names a tile that never raises its flag -- together they force the
+// time-out path in a test without oversubscribing the device
+int g_max_spin = kMaxSpin;
+int g_mute_tile = -1;
 
 template <typename T>
 struct IterScalars {               // one Chambolle-Pock iteration's step sizes
@@ -100,10 +109,10 @@ __device__ __forceinline__ void getv(const double *g, double (&v)[2]) {
 // boundary lane's 27-30 granules in flight; the 1024-lane form spills a few of them)
 template <typename T, int VEC, int NDIM, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_pd_persist(
-    T *__restrict__ xbar, T *__restrict__ x, const T *__restrict__ bt, T *__restrict__ p,
-    Geom<T> G, const IterScalars<T> *__restrict__ sc, int iterations, int huber, int l1,
-    int has_p, Tiling Q, T *__restrict__ halo, unsigned int *__restrict__ flags,
-    unsigned int *__restrict__ err) {
+    const T *xbar, const T *x, const T *__restrict__ bt, const T *p, T *xbar_out, T *x_out,
+    T *p_out, Geom<T> G, const IterScalars<T> *__restrict__ sc, int iterations, int huber,
+    int l1, int has_p, Tiling Q, T *__restrict__ halo, unsigned int *__restrict__ flags,
+    unsigned int *__restrict__ err, int max_spin, int mute_tile) {
   typedef typename Pack<T, VEC>::type V;
   extern __shared__ __attribute__((aligned(16))) unsigned char pdp_smem[];
   const int nthr = Q.lx * Q.ly * Q.lz;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(MAXT) void k_pd_persist(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0)
+    if (tid == 0 && me != (int64_t)mute_tile)
       __hip_atomic_store(flags + me, (unsigned int)k + 1u, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(MAXT) void k_pd_persist(
       int spin = 0;
       while (__hip_atomic_load(flags + nb_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
              (unsigned int)k + 1u) {
-        if (++spin >= kMaxSpin) { failed = true; break; }
+        if (++spin >= max_spin) { failed = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -367,11 +376,11 @@ __global__ __launch_bounds__(MAXT) void k_pd_persist(
     // by lanes that have passed this iteration's second one: no third barrier)
   }
   if (in) {
-    stv<T, VEC>(xbar + off, xb);
-    stv<T, VEC>(x + off, xv);
-    stv<T, VEC>(p + off, px);
-    if constexpr (NDIM >= 2) stv<T, VEC>(p + G.n + off, py);
-    if constexpr (NDIM >= 3) stv<T, VEC>(p + 2 * G.n + off, pz);
+    stv<T, VEC>(xbar_out + off, xb);
+    stv<T, VEC>(x_out + off, xv);
+    stv<T, VEC>(p_out + off, px);
+    if constexpr (NDIM >= 2) stv<T, VEC>(p_out + G.n + off, py);
+    if constexpr (NDIM >= 3) stv<T, VEC>(p_out + 2 * G.n + off, pz);
   }
   if (failed) atomicOr(err, 1u);
 }
@@ -466,19 +475,23 @@ int64_t persist_ws_bytes(int ndim, int64_t nz, int64_t ny, int64_t nx, int itera
 }
 
 template <typename T>
-int persist_run(T *xbar, T *x, const T *bt, T *p, int ndim, int64_t nz, int64_t ny,
+int persist_run(const T *xbar, const T *x, const T *bt, const T *p, T *xbar_out, T *x_out,
+                T *p_out, int ndim, int64_t nz, int64_t ny,
                 int64_t nx, double wx, double wy, double wz, double lambda,
                 const double *sig, const double *tau, const double *theta, int iterations,
                 int p_is_zero, double gamma_huber, int flags, void *ws, int64_t ws_bytes,
                 unsigned int *err_word, void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   constexpr int VEC = 16 / (int)sizeof(T);
-  if (!xbar || !x || !bt || !p || !sig || !tau || !theta || iterations < 1 || !ws)
+  if (!xbar || !x || !bt || !p || !xbar_out || !x_out || !p_out || !sig || !tau ||
+      !theta || iterations < 1 || !ws)
     return NSOL_EINVAL;
   const int64_t need = persist_ws_bytes<T>(ndim, nz, ny, nx, iterations);
   if (need < 0) return -2;                          // the kernel does not apply
   if (ws_bytes < need || ((uintptr_t)ws & 15u)) return NSOL_EINVAL;
-  if (((uintptr_t)xbar | (uintptr_t)x | (uintptr_t)bt | (uintptr_t)p) & 15u) return -2;
+  if (((uintptr_t)xbar | (uintptr_t)x | (uintptr_t)bt | (uintptr_t)p | (uintptr_t)xbar_out |
+       (uintptr_t)x_out | (uintptr_t)p_out) & 15u)
+    return -2;
   if ((nz * ny * nx) % VEC != 0) return -2;
   Tiling Q;
   pick_tiling<VEC>(ndim, nz, ny, nx, &Q);
@@ -513,10 +526,19 @@ int persist_run(T *xbar, T *x, const T *bt, T *p, int ndim, int64_t nz, int64_t 
   const size_t lds = (size_t)nthr * (3 * 16 + sizeof(T));
   const dim3 grid((unsigned)(Q.ntx * Q.nty * Q.ntz));
 #define NSOL_PDP_GO(ND, MT)                                                          \
-  hipLaunchKernelGGL((k_pd_persist<T, VEC, ND, MT>), grid, dim3(nthr), lds, st, xbar, x, \
-                     bt, p, G, scd, iterations, huber ? 1 : 0,                        \
-                     (flags & NSOL_PD_DATA_L1) ? 1 : 0, p_is_zero ? 0 : 1, Q, halo, flags_d, \
-                     err)
+  do {                                                                               \
+    /* one workgroup per tile must be resident at once: ask the runtime what this   \
+       kernel's registers and LDS admit per CU (advisory -- hence the bounded waits) */ \
+    int per_cu = 0;                                                                  \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(                               \
+            &per_cu, k_pd_persist<T, VEC, ND, MT>, nthr, lds) != hipSuccess ||       \
+        (int64_t)per_cu * cu_count_pdp() < (int64_t)grid.x)                          \
+      return -2;                                                                     \
+    hipLaunchKernelGGL((k_pd_persist<T, VEC, ND, MT>), grid, dim3(nthr), lds, st, xbar, x, \
+                       bt, p, xbar_out, x_out, p_out, G, scd, iterations, huber ? 1 : 0, \
+                       (flags & NSOL_PD_DATA_L1) ? 1 : 0, p_is_zero ? 0 : 1, Q, halo,    \
+                       flags_d, err, g_max_spin, g_mute_tile);                       \
+  } while (0)
   if (nthr <= 256) {
     switch (ndim) {
       case 1: NSOL_PDP_GO(1, 256); break;
@@ -545,27 +567,41 @@ int64_t nsol_pd_persist_ws_bytes(int elem_size, int ndim, int64_t nz, int64_t ny
   return -1;
 }
 
-int nsol_pd_persist_run_f32(float *xbar, float *x, const float *bt, float *p, int ndim,
-                            int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
-                            double wz, double lambda, const double *sigma_host,
-                            const double *tau_host, const double *theta_host,
-                            int iterations, int p_is_zero, double gamma_huber, int flags,
-                            void *ws, int64_t ws_bytes, unsigned int *err_word,
-                            void *stream) {
-  return persist_run<float>(xbar, x, bt, p, ndim, nz, ny, nx, wx, wy, wz, lambda,
-                            sigma_host, tau_host, theta_host, iterations, p_is_zero,
-                            gamma_huber, flags, ws, ws_bytes, err_word, stream);
-}
-int nsol_pd_persist_run_f64(double *xbar, double *x, const double *bt, double *p, int ndim,
-                            int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
-                            double wz, double lambda, const double *sigma_host,
-                            const double *tau_host, const double *theta_host,
-                            int iterations, int p_is_zero, double gamma_huber, int flags,
-                            void *ws, int64_t ws_bytes, unsigned int *err_word,
-                            void *stream) {
-  return persist_run<double>(xbar, x, bt, p, ndim, nz, ny, nx, wx, wy, wz, lambda,
-                             sigma_host, tau_host, theta_host, iterations, p_is_zero,
-                             gamma_huber, flags, ws, ws_bytes, err_word, stream);
+#define NSOL_PDP_DEF(T, SUF)                                                        \
+  int nsol_pd_persist_run_to_##SUF(                                                 \
+      const T *xbar, const T *x, const T *bt, const T *p, T *xbar_out, T *x_out,   \
+      T *p_out, int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, double wy, \
+      double wz, double lambda, const double *sigma_host, const double *tau_host,  \
+      const double *theta_host, int iterations, int p_is_zero, double gamma_huber, \
+      int flags, void *ws, int64_t ws_bytes, unsigned int *err_word, void *stream) { \
+    return persist_run<T>(xbar, x, bt, p, xbar_out, x_out, p_out, ndim, nz, ny, nx, \
+                          wx, wy, wz, lambda, sigma_host, tau_host, theta_host,     \
+                          iterations, p_is_zero, gamma_huber, flags, ws, ws_bytes,  \
+                          err_word, stream);                                        \
+  }                                                                                 \
+  int nsol_pd_persist_run_##SUF(                                                    \
+      T *xbar, T *x, const T *bt, T *p, int ndim, int64_t nz, int64_t ny,           \
+      int64_t nx, double wx, double wy, double wz, double lambda,                   \
+      const double *sigma_host, const double *tau_host, const double *theta_host,  \
+      int iterations, int p_is_zero, double gamma_huber, int flags, void *ws,       \
+      int64_t ws_bytes, unsigned int *err_word, void *stream) {                     \
+    return persist_run<T>(xbar, x, bt, p, xbar, x, p, ndim, nz, ny, nx, wx, wy, wz, \
+                          lambda, sigma_host, tau_host, theta_host, iterations,     \
+                          p_is_zero, gamma_huber, flags, ws, ws_bytes, err_word,    \
+                          stream);                                                  \
+  }
+NSOL_PDP_DEF(float, f32)
+NSOL_PDP_DEF(double, f64)
+#undef NSOL_PDP_DEF
+
+/* debug knobs: "pdp_max_spin" (polls before a wait gives up), "pdp_mute_tile" (a
+ * tile that never raises its flag; -1 = none) */
+int nsol_hip_set_param_pdp(const char *name, int value) {
+  if (!name) return NSOL_EINVAL;
+  if (!strcmp(name, "pdp_max_spin")) g_max_spin = value < 1 ? 1 : value;
+  else if (!strcmp(name, "pdp_mute_tile")) g_mute_tile = value;
+  else return NSOL_EINVAL;
+  return 0;
 }
 
 }  // extern "C"

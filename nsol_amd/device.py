@@ -119,8 +119,9 @@ def to_numpy(t, dtype=np.float64):
     # persistent runs that produced what was just downloaded)
     import sys
     ops = sys.modules.get("nsol_amd.ops")
-    if ops is not None and ops._err_pending:
-        ops.drain_persist_checks()
+    if ops is not None and ops._pending_runs:
+        if ops.settle_persist_runs(synchronize=False):
+            out = _download(t, dtype)       # a run was repeated: fetch its result
     return out
 
 

@@ -598,14 +598,35 @@ def pd_persist_launches():
 
 
 # Error words of the persistent runs: a ring of 32-bit words in pinned host
-# memory the kernels write to directly.  A word is looked at when the result is
-# downloaded (device.to_numpy -> drain_persist_checks: the stream has been
-# synchronised by then) or when its slot is needed again -- never with a
-# synchronisation of its own.
+# memory the kernels write to directly.  A persistent run reads its state from
+# one set of arrays and writes the result to another, so a run whose word came
+# back raised (a workgroup gave up waiting for a neighbour: the device is shared
+# or CU-masked and not every workgroup was resident) is REPEATED from the
+# untouched inputs with one launch per iteration -- the same bits -- by
+# settle_persist_runs().  That is called wherever a result is consumed after a
+# synchronisation the caller performs anyway: Solver.run() (after its own
+# torch.cuda.synchronize), device.to_numpy, solve_batch before its gather, the
+# next pd_run on the device; never with a synchronisation in the middle of
+# enqueued work.
 _ERR_SLOTS = 256
 _err_ring = None
 _err_next = 0
-_err_pending = []          # (slot, stream the run was enqueued on)
+_pending_runs = []         # PersistRun records, oldest first
+_fallback_warned = False
+persist_fallbacks = 0      # runs repeated so far (tests, tools)
+
+
+class PersistRun(object):
+    """What it takes to repeat a persistent run through nsol_pd_run_*."""
+
+    def __init__(self, slot, stream, src, dst, bt, shape, w, lmbda, sigma, tau,
+                 theta, p_is_zero, gamma_huber, flags, keep):
+        self.slot, self.stream = slot, stream
+        self.src, self.dst = src, dst         # (xbar, x, p) tensors read / written
+        self.bt, self.shape, self.w, self.lmbda = bt, shape, w, lmbda
+        self.sigma, self.tau, self.theta = sigma, tau, theta
+        self.p_is_zero, self.gamma_huber, self.flags = p_is_zero, gamma_huber, flags
+        self.keep = keep                      # tensors that must outlive the run
 
 
 def _err_slot():
@@ -614,35 +635,90 @@ def _err_slot():
         _err_ring = torch.zeros(_ERR_SLOTS, dtype=torch.int32).pin_memory()
     slot = _err_next
     _err_next = (_err_next + 1) % _ERR_SLOTS
-    for k, (s, _) in enumerate(_err_pending):
-        if s == slot:                     # the ring has wrapped: settle that run first
-            torch.cuda.synchronize()
-            drain_persist_checks()
-            break
+    if any(r.slot == slot for r in _pending_runs):
+        settle_persist_runs()             # the ring has wrapped: settle first
     _err_ring[slot] = 0
     return slot
 
 
+def _repeat_with_a_launch_per_iteration(r):
+    """The inputs of run r are intact (it wrote elsewhere): the same iterations
+    through nsol_pd_run_*, the result put where the persistent run left it."""
+    import ctypes
+    xb_in, x_in, p_in = r.src
+    xb_out, x_out, p_out = r.dst
+    ndim, nz, ny, nx = dims3(r.shape)
+    n_it = int(r.sigma.size)
+    slot = ctypes.c_int(0)
+    # scratch state so that neither the inputs' nor the outputs' roles matter:
+    # start from copies of the inputs, ping-pong against the output arrays
+    xb0, x0, p0 = xb_in.clone(), x_in.clone(), p_in.clone()
+    _lib.check(_fn("pd_run", x0)(
+        _p(xb0), _p(xb_out), _p(x0), _p(x_out), _p(r.bt), _p(p0), _p(p_out), ndim,
+        nz, ny, nx, r.w[0], r.w[1], r.w[2], float(r.lmbda), r.sigma.ctypes.data,
+        r.tau.ctypes.data, r.theta.ctypes.data, n_it, int(bool(r.p_is_zero)),
+        float(r.gamma_huber), int(r.flags) | PD_RUN_X_MAY_SWAP,
+        ctypes.addressof(slot), stream_ptr()), "nsol_pd_run")
+    if not (slot.value & 1):              # final xbar / p in the scratch pair
+        xb_out.copy_(xb0)
+        p_out.copy_(p0)
+    if not (slot.value & 2):              # final x in x0, not in x_out
+        x_out.copy_(x0)
+    torch.cuda.synchronize()
+
+
+def settle_persist_runs(synchronize=True):
+    """Look at the error word of every persistent run enqueued so far; repeat
+    the runs that timed out (see above); returns how many were repeated.
+    synchronize=False: the caller has just synchronised the device."""
+    global _fallback_warned, persist_fallbacks
+    if not _pending_runs:
+        return 0
+    if synchronize:
+        torch.cuda.synchronize()
+    saved = (globals()["PD_PERSIST"],)
+    repeated = 0
+    while _pending_runs:
+        r = _pending_runs.pop(0)
+        if int(_err_ring[r.slot]) == 0:
+            continue
+        if r.dst[0] is r.src[0]:          # in place: the inputs are gone
+            del _pending_runs[:]
+            raise _lib.NsolHipError(
+                "nsol_pd_persist_run: a workgroup gave up waiting for a neighbour "
+                "(device shared or CU-masked?) in a run that updated its state in "
+                "place; the result is invalid")
+        if not _fallback_warned:
+            import warnings
+            warnings.warn(
+                "nsol_pd_persist_run: a workgroup gave up waiting for a "
+                "neighbour (device shared or CU-masked?); the run is repeated "
+                "with one launch per iteration -- set nsol_amd.ops.PD_PERSIST "
+                "= False to skip the attempt", RuntimeWarning)
+            _fallback_warned = True
+        persist_fallbacks += 1
+        repeated += 1
+        globals()["PD_PERSIST"] = False
+        try:
+            _repeat_with_a_launch_per_iteration(r)
+        finally:
+            globals()["PD_PERSIST"] = saved[0]
+    return repeated
+
+
 def drain_persist_checks():
-    """Raise if a persistent run that has completed reported a time-out.  Call
-    after the stream(s) have been synchronised."""
-    bad = False
-    while _err_pending:
-        slot, _ = _err_pending.pop(0)
-        bad = bad or int(_err_ring[slot]) != 0
-    if bad:
-        raise _lib.NsolHipError(
-            "nsol_pd_persist_run: a workgroup gave up waiting for a neighbour "
-            "(device oversubscribed?); the result is invalid -- set "
-            "nsol_amd.ops.PD_PERSIST = False to run one launch per iteration")
+    """(former name) settle after the caller's own synchronisation."""
+    settle_persist_runs(synchronize=False)
 
 
 def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero,
-                   gamma_huber, flags):
-    """All len(sigma) iterations in one launch, state updated in place (xbar, x,
-    p).  Returns False when the kernel does not apply (nothing launched).  Does
-    not synchronise: a time-out of a bounded wait inside the kernel surfaces as
-    an exception when the result is downloaded (drain_persist_checks)."""
+                   gamma_huber, flags, out=None):
+    """All len(sigma) iterations in one launch.  out = (xbar_out, x_out, p_out):
+    where the result goes -- arrays other than the inputs, which then survive a
+    timed-out run (settle_persist_runs repeats it); out=None: in place, and a
+    time-out surfaces as an exception from settle_persist_runs instead.  Returns
+    False when the kernel does not apply (nothing launched).  Does not
+    synchronise."""
     global _persist_launches
     ndim, nz, ny, nx = dims3(shape)
     iters = int(np.size(sigma))
@@ -655,8 +731,10 @@ def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     slot = _err_slot()
-    rc = _fn("pd_persist_run", x)(
-        _p(xbar), _p(x), _p(bt), _p(p), ndim, nz, ny, nx, w[0], w[1], w[2],
+    dst = (xbar, x, p) if out is None else tuple(out)
+    rc = _fn("pd_persist_run_to", x)(
+        _p(xbar), _p(x), _p(bt), _p(p), _p(dst[0]), _p(dst[1]), _p(dst[2]), ndim,
+        nz, ny, nx, w[0], w[1], w[2],
         float(lmbda), sigma.ctypes.data, tau.ctypes.data, theta.ctypes.data, iters,
         int(bool(p_is_zero)), float(gamma_huber), int(flags), _p(ws), need,
         _err_ring.data_ptr() + 4 * slot, stream_ptr())
@@ -664,7 +742,9 @@ def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero
         return False
     _lib.check(rc, "nsol_pd_persist_run")
     ws.record_stream(torch.cuda.current_stream())      # freed once the run is done
-    _err_pending.append((slot, stream_ptr()))
+    _pending_runs.append(PersistRun(
+        slot, stream_ptr(), (xbar, x, p), dst, bt, tuple(shape), tuple(w), lmbda,
+        sigma, tau, theta, p_is_zero, gamma_huber, flags, keep=(ws,)))
     _persist_launches += 1
     return True
 
@@ -694,10 +774,32 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
     volume."""
     import ctypes
     ndim, nz, ny, nx = dims3(shape)
-    if PD_PERSIST and persist_pays(shape, np.size(sigma)) and \
-            pd_persist_run(xbar0, x, bt, p0, shape, w, lmbda, sigma, tau, theta,
-                           p_is_zero, gamma_huber, flags):
-        return 0
+    if _pending_runs:
+        # an earlier persistent run may feed this one: its verdict first (the
+        # device is drained here; runs of cache-resident volumes are ~1 ms)
+        settle_persist_runs()
+    if PD_PERSIST and persist_pays(shape, np.size(sigma)):
+        # the result goes to the other half of the ping-pong arrays (and to the
+        # x scratch volume): the inputs stay as they are until the run's error
+        # word has been looked at
+        xo = x_alt if x_alt is not None else empty_like(x)
+        if pd_persist_run(xbar0, x, bt, p0, shape, w, lmbda, sigma, tau, theta,
+                          p_is_zero, gamma_huber, flags, out=(xbar1, xo, p1)):
+            if swap_ok and x_alt is not None:
+                x.data, x_alt.data = x_alt.data, x.data
+                # (the record holds tensors, not storages: keep it pointing at
+                # the input / output storages after the swap of names)
+                r = _pending_runs[-1]
+                r.src = (r.src[0], x_alt, r.src[2])
+                r.dst = (r.dst[0], x, r.dst[2])
+            else:
+                # x must hold the result: the input x survives in a copy
+                r = _pending_runs[-1]
+                keep = x.clone()
+                x.copy_(xo)
+                r.src = (r.src[0], keep, r.src[2])
+                r.dst = (r.dst[0], x, r.dst[2])
+            return 1
     sigma = np.ascontiguousarray(sigma, dtype=np.float64)
     tau = np.ascontiguousarray(tau, dtype=np.float64)
     theta = np.ascontiguousarray(theta, dtype=np.float64)

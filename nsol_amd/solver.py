@@ -99,6 +99,9 @@ class Solver(object):
         t0 = time.time()
         self._run()
         torch.cuda.synchronize()
+        # (a persistent-kernel run that timed out is repeated here, before anyone
+        # can consume its result on the device or on the host)
+        ops.settle_persist_runs(synchronize=False)
         self._computational_time = datetime.timedelta(
             seconds=time.time() - t0)
         if self._verbose:

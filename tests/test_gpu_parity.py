@@ -1634,6 +1634,75 @@ def test_persistent_kernel_is_bit_identical(nsol, shape, dtype):
             assert torch.equal(a, b), (shape, flags, w)
 
 
+def test_persistent_kernel_falls_back_when_a_neighbour_never_answers(nsol):
+    """A shared or CU-masked device can leave a workgroup of the persistent kernel
+    unscheduled; its neighbours then give up after a bounded number of polls and the
+    run's error word is raised.  Forced here with the debug knobs (tile 0 never
+    raises its flag, 64 polls): the run must be REPEATED with one launch per
+    iteration from the inputs the persistent kernel left untouched -- same bits --
+    for a consumer of Solver.run() and for one of ops.pd_run (device tensors, no
+    download in between)."""
+    import warnings
+    import torch
+    from nsol_amd import ops, _lib
+    from nsol_amd.primal_dual_solver import step_schedule
+    shape = (64, 64, 64)
+    obs = 60.0 + 25.0 * np.random.default_rng(2).standard_normal(shape)
+    ops.PD_PERSIST = False
+    ref = _pd_solver(obs, "TV", "L2", 0.05, 20, 16.0, "ALG2", np.float32)
+    ref.run()
+    ops.PD_PERSIST = True
+    before, launches = ops.persist_fallbacks, ops.pd_persist_launches()
+    _lib.set_param("pdp_mute_tile", 0)
+    _lib.set_param("pdp_max_spin", 64)
+    ops._fallback_warned = False
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        s = _pd_solver(obs, "TV", "L2", 0.05, 20, 16.0, "ALG2", np.float32)
+        s.run()
+        got_dev = s.get_x_device()          # a device-side consumer
+        assert ops.pd_persist_launches() == launches + 1, "persistent kernel not tried"
+        assert ops.persist_fallbacks == before + 1, "the run was not repeated"
+        assert any(issubclass(w.category, RuntimeWarning) for w in seen)
+        assert torch.equal(got_dev, ref.get_x_device())
+        assert np.array_equal(s.get_x(), ref.get_x())
+        # ops.pd_run directly: all three state arrays, odd and even hand-over of x
+        n = int(np.prod(shape))
+        flags = ops.PD_REG_HUBER | ops.PD_DATA_L1
+        sig, ta, th = step_schedule("ALG2", 12.0, 1 / 0.05, 17)
+        for swap in (True, False):
+            outs = []
+            for persist in (False, True):
+                ops.PD_PERSIST = persist
+                gen = torch.Generator(device="cuda").manual_seed(7)
+                bt = torch.rand(n, device="cuda", generator=gen)
+                x, xa = bt.clone(), torch.empty_like(bt)
+                xb = [bt.clone(), torch.empty_like(bt)]
+                p = [torch.rand(3 * n, device="cuda", generator=gen) - 0.5,
+                     torch.empty(3 * n, device="cuda")]
+                slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, (1., 0.5, 2.),
+                                  20.0, sig, ta, th, False, 0.05, flags, x_alt=xa,
+                                  swap_ok=swap)
+                ops.settle_persist_runs()
+                outs.append((x, xb[slot], p[slot]))
+            assert ops.persist_fallbacks == before + (2 if swap else 3)
+            for a, b in zip(*outs):
+                assert torch.equal(a, b), swap
+    _lib.set_param("pdp_mute_tile", -1)
+    _lib.set_param("pdp_max_spin", 1 << 21)
+    # and an in-place run (the C entry's historical form) still fails loudly
+    _lib.set_param("pdp_mute_tile", 0)
+    _lib.set_param("pdp_max_spin", 64)
+    n = int(np.prod(shape))
+    bt = torch.rand(n, device="cuda")
+    x, xb, p = bt.clone(), bt.clone(), torch.zeros(3 * n, device="cuda")
+    sig, ta, th = step_schedule("ALG2", 12.0, 1 / 0.05, 17)
+    assert ops.pd_persist_run(xb, x, bt, p, shape, (1., 1., 1.), 20.0, sig, ta, th, True,
+                              0.05, 0)
+    with pytest.raises(_lib.NsolHipError):
+        ops.settle_persist_runs()
+
+
 def test_persistent_kernel_applies_only_where_it_fits(nsol):
     import torch
     from nsol_amd import ops, _lib
