@@ -42,12 +42,17 @@ BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
          # Lanczos update with the regulariser's stencil and its norm
          "k_blur3_dma_epi": 12, "k_tk1_norm": 4, "k_tk1_lanczos": 16,
          # ... or the blur that takes both sums itself (no io tile, no second read of y)
-         "k_blur3_dma_norms": 8}
+         "k_blur3_dma_norms": 8,
+         # ... or both halves of the Lanczos step inside the blur: (y, y_prev) -> (t, q0)
+         # and (t, q0, y) -> y_new
+         "k_blur3_lanczos_a": 16, "k_blur3_lanczos_b": 16}
 SETUP_BYTES = 156
 
 
 # the kernels of the LSMR branch as rocprofv3 names them at 512^3 / float32 / 13 taps
 PMC_NAMES = {"k_tk1_lanczos": "k_tk1_reg<float, 4, 4, false, 2>",
+             "k_blur3_lanczos_a": "k_blur3_dma<float, 4, 13, 16, true, 3, false>",
+             "k_blur3_lanczos_b": "k_blur3_dma<float, 4, 13, 16, true, 4, false>",
              "k_blur3_dma_norms": "k_blur3_dma<float, 4, 13, 16, true, 2, false>",
              "k_blur3_dma": "k_blur3_dma<float, 4, 13, 16, true, 0, false>",
              "k_blur3_dma_epi": "k_blur3_dma<float, 4, 13, 16, true, 1, false>",
@@ -156,13 +161,22 @@ def time_kernels(shape, reps=20):
                                              slot2)
     lib_lz = lambda: ops.tk1_lanczos(h, Av, hbar, shape, w, 0.1, 0.5, -0.3, -0.2,
                                      out=x_out, result=slot)
+    lb = ops.LanczosBoard(v, 4, 0.1, 0.0)
+    lb.board[0:1] = 1.0
+    lb.board[3:4] = 1.0
+    lb.init()
+    q0 = torch.empty_like(v)
+    lib_la = lambda: ops.corr3_lanczos_a(v, h, blur_out, q0, shape, taps, taps, taps, lb, 1)
+    lib_lb = lambda: ops.corr3_lanczos_b(blur_out, q0, v, x_out, shape, taps, taps, taps,
+                                         lb, 1)
     for _ in range(30):        # (clocks up before the first timed kernel)
         lib_blur()
     for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
                      ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
                      ("k_admm_vw", lib_vw), ("k_wcomb", lib_x),
                      ("k_blur3_dma_epi", lib_epi), ("k_tk1_norm", lib_reg),
-                     ("k_tk1_lanczos", lib_lz), ("k_blur3_dma_norms", lib_norms)):
+                     ("k_tk1_lanczos", lib_lz), ("k_blur3_dma_norms", lib_norms),
+                     ("k_blur3_lanczos_a", lib_la), ("k_blur3_lanczos_b", lib_lb)):
         for _ in range(3):
             fn()
         e0, e1 = ev.create(), ev.create()
@@ -425,6 +439,7 @@ def main():
                    "lsmr_x": "carried" if args.carried_x else "assembled at the end",
                    "lsmr_form": "bidiagonalisation" if (args.bidiag or args.carried_x)
                    else "Lanczos on the normal equations",
+                   "lanczos_step": __import__("nsol_amd.lsmr", fromlist=["x"]).LAST_FORM[0],
                    "execution": execution},
         "rel_change_vs_input": rel_change, "finite": finite}
     if args.minimizer == "lsmr":
@@ -435,12 +450,22 @@ def main():
             0.1 >= lsmr_mod.NE_MIN_WEIGHT[4] and args.iter_max <= lsmr_mod.NE_MAX_ITER
         # (k_wcomb: x assembled from the stored vectors; timed for 11)
         blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS)
-        if normal:
+        in_blur = normal and bool(lsmr_mod.USE_BLUR_LANCZOS) and \
+            lsmr_mod.LAST_FORM[0] == "lanczos-in-blur"
+        if in_blur:
+            per_it = {"k_blur3_lanczos_a": args.iter_max,
+                      "k_blur3_lanczos_b": args.iter_max, "k_blur3_dma": 0,
+                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_blur3_dma_norms": 0,
+                      "k_tk1_lanczos": 0, "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0,
+                      "k_admm_vw": 1, "k_wcomb": 1}
+            blur_norms = True
+        elif normal:
             per_it = {"k_blur3_dma": args.iter_max + 1,
                       "k_blur3_dma_epi": 0 if blur_norms else args.iter_max,
                       "k_tk1_norm": 0 if blur_norms else args.iter_max,
                       "k_blur3_dma_norms": args.iter_max if blur_norms else 0,
                       "k_tk1_lanczos": args.iter_max,
+                      "k_blur3_lanczos_a": 0, "k_blur3_lanczos_b": 0,
                       "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0, "k_admm_vw": 1,
                       "k_wcomb": 1}
         else:
@@ -449,7 +474,8 @@ def main():
                       "k_lsmr_hx": 0 if deferred else args.iter_max,
                       "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0,
                       "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_tk1_lanczos": 0,
-                      "k_blur3_dma_norms": 0}
+                      "k_blur3_dma_norms": 0, "k_blur3_lanczos_a": 0,
+                      "k_blur3_lanczos_b": 0}
         for k, c in per_it.items():
             kern[k]["launches_per_admm_iteration"] = c
             kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]

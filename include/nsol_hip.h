@@ -187,6 +187,49 @@ int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t 
                               const double *taps_x, int ntaps, double wx, double wy,
                               double wz, double *result, double *ws, int64_t ws_doubles,
                               void *stream);
+/* LSMR as Lanczos on the normal equations A'A + rho B'B (replaces SciPy's lsmr.py:320-413
+ * behind tikhonov_linear_solver.py:146-158) with BOTH halves of a step taken by the
+ * one-pass blur A = A' (linear_operators.py:60-86), unit spacing, B = gradient (rho_grad)
+ * or identity (rho_ident):
+ *   _a:  t = A y with sum t^2 and sum |grad y|^2, and
+ *        q0 = c1 K'K y + c0 y + c2 y_prev           (y_prev NULL in the first step)
+ *   _b:  y_new = ca A t + q0 + cy y with sum y_new^2
+ * board (device, 3 * (steps + 1) doubles; the caller stores |y_0|^2 in board[0]):
+ * board[3 j] = |y_j|^2, [3 j + 1] = |A y_j|^2, [3 j + 2] = |grad y_j|^2.  coef (device,
+ * 8 elements of the array type): c1, c0, c2 at [0..2], ca, cy at [4..5]; _init writes
+ * [0..2] for step 0 from board[0], every _a writes [4..5], every _b [0..2] for the next
+ * step -- steps follow each other on the stream without the host reading a scalar.
+ * q0 equals nsol_tk1_lanczos_* (c_g = 0) and y_new nsol_lincomb3_* of the plain blur bit
+ * for bit.  ws: >= 2 doubles per tile of scratch (nsol_hip_reduce_ws_doubles()).
+ * Return -2 (nothing launched) where the form does not apply: rows not a multiple of 16
+ * bytes, unaligned arrays, fewer than 5 or more than 13 taps, taps not symmetric. */
+int nsol_corr3_wrap_lanczos_init_f32(double *board, float *coef, double rho_grad,
+                                     double rho_ident, void *stream);
+int nsol_corr3_wrap_lanczos_init_f64(double *board, double *coef, double rho_grad,
+                                     double rho_ident, void *stream);
+int nsol_corr3_wrap_lanczos_a_f32(const float *y, const float *y_prev, float *t, float *q0,
+                                  int64_t nz, int64_t ny, int64_t nx, const double *taps_z,
+                                  const double *taps_y, const double *taps_x, int ntaps,
+                                  double rho_grad, double rho_ident, double *board, int step,
+                                  float *coef, double *ws, int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_lanczos_a_f64(const double *y, const double *y_prev, double *t,
+                                  double *q0, int64_t nz, int64_t ny, int64_t nx,
+                                  const double *taps_z, const double *taps_y,
+                                  const double *taps_x, int ntaps, double rho_grad,
+                                  double rho_ident, double *board, int step, double *coef,
+                                  double *ws, int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_lanczos_b_f32(const float *t, const float *q0, const float *y,
+                                  float *y_new, int64_t nz, int64_t ny, int64_t nx,
+                                  const double *taps_z, const double *taps_y,
+                                  const double *taps_x, int ntaps, double rho_grad,
+                                  double rho_ident, double *board, int step, float *coef,
+                                  double *ws, int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_lanczos_b_f64(const double *t, const double *q0, const double *y,
+                                  double *y_new, int64_t nz, int64_t ny, int64_t nx,
+                                  const double *taps_z, const double *taps_y,
+                                  const double *taps_x, int ntaps, double rho_grad,
+                                  double rho_ident, double *board, int step, double *coef,
+                                  double *ws, int64_t ws_doubles, void *stream);
 /* dense N-D correlation with DEVICE taps [kz][ky][kx] and centre (cz,cy,cx):
  *   out[i] = sum_t taps[t] * x[i + t - c].  Replaces linear_operators.py:60-68
  * (scipy.ndimage.convolve with an arbitrary kernel; the host flips the kernel

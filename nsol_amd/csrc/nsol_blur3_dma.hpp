@@ -67,6 +67,45 @@ int blur3_dma_run(const double *x, double *out, int64_t nz, int64_t ny, int64_t 
                   int ntaps, int epi, double ca, double cb, double cc, double *result,
                   double *part, int64_t part_doubles, hipStream_t st);
 
+// The two halves of a Lanczos step on A'A + rho B'B (nsol_amd/lsmr.py, lsmr_normal) taken
+// by the blur itself, unit spacing, B = gradient (rho_g) or identity (rho_i):
+//   half A (epi 3):  t = A y with sum t^2 and sum |grad y|^2 (as epi 2) and
+//                    q0 = c1 K'K y + c0 y + c2 y_prev            (y_prev may be null)
+//   half B (epi 4):  y_new = ca A t + q0 + cy y with sum y_new^2
+// The coefficients live in device memory (coef, element type T: [0..2] = c1, c0, c2 read
+// by half A, [4..5] = ca, cy read by half B) and are written by the reduction kernels that
+// close each half from the sums on the scalar board (doubles: board[3 j] = |y_j|^2,
+// [3 j + 1] = |A y_j|^2, [3 j + 2] = |grad y_j|^2), so consecutive steps are enqueued
+// without the host seeing a scalar.  -2: does not apply (nothing launched).
+__attribute__((visibility("hidden")))
+int blur3_lanczos_a(const float *y, const float *y_prev, float *t, float *q0, int64_t nz,
+                    int64_t ny, int64_t nx, const Taps<float> &tz, const Taps<float> &ty,
+                    const Taps<float> &tx, int ntaps, double rho_g, double rho_i,
+                    double *board, int step, float *coef, double *part,
+                    int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_a(const double *y, const double *y_prev, double *t, double *q0, int64_t nz,
+                    int64_t ny, int64_t nx, const Taps<double> &tz, const Taps<double> &ty,
+                    const Taps<double> &tx, int ntaps, double rho_g, double rho_i,
+                    double *board, int step, double *coef, double *part,
+                    int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_b(const float *t, const float *q0, const float *y, float *y_new,
+                    int64_t nz, int64_t ny, int64_t nx, const Taps<float> &tz,
+                    const Taps<float> &ty, const Taps<float> &tx, int ntaps, double rho_g,
+                    double rho_i, double *board, int step, float *coef, double *part,
+                    int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_b(const double *t, const double *q0, const double *y, double *y_new,
+                    int64_t nz, int64_t ny, int64_t nx, const Taps<double> &tz,
+                    const Taps<double> &ty, const Taps<double> &tx, int ntaps, double rho_g,
+                    double rho_i, double *board, int step, double *coef, double *part,
+                    int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_init(double *board, float *coef, double rho_g, double rho_i, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_init(double *board, double *coef, double rho_g, double rho_i, hipStream_t st);
+
 }  // namespace nsol_blur3
 
 #ifdef NSOL_BLUR3_DMA_IMPL
@@ -149,6 +188,21 @@ __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
 // vector of plane st + 1, the vector to its right and the one below from the raw tile
 // and keeps its own vector of the plane before in registers for d_z.
 //
+// EPI == 3 / 4: the two halves of a Lanczos step (see blur3_lanczos_a / _b above; unit
+// spacing, no RAG form).  EPI 3 is EPI 2 plus q0 = c1 K'K x + c0 x + c2 aux1 stored to
+// aux_out: the in-plane part of K'K x of plane st + 1 comes from the raw tile the
+// difference sums read anyway (plus the vector to the left and the one above), the z part
+// of plane st from the lane's own vectors of planes st - 1, st, st + 1 kept in registers;
+// every difference and sum is formed in the order of k_tk1_reg<.., 2> (nsol_lsmr.hip), so
+// q0 equals that kernel's result bit for bit.  EPI 4 stores ca A x + aux1 + cy aux2 (the
+// order of nsol_lincomb3_*) with its sum of squares.  The own-position tiles of aux1 /
+// aux2 travel global -> LDS by LDS-DMA, requested at the start of a phase ahead of its
+// raw-tile pieces and stores, so the counted wait at the end of the phase has them landed
+// while those stay in flight.  EPI 3 alternates two tiles like EPI 1; EPI 4 has LDS for
+// ONE tile per array: a lane moves its values of this plane to registers first and the
+// next plane's piece is requested into the same tile (a wave only ever reads what its own
+// piece brought).
+//
 // RAG: rows that are not a multiple of 16 bytes (or operands that are not 16-byte
 // aligned).  LDS-DMA takes 16-byte pieces from any 4-byte aligned source and honours
 // EXEC (tools/_probe/dma_probe.hip), so the raw tile is staged as before from
@@ -164,7 +218,11 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     const T *__restrict__ x, T *__restrict__ out, int64_t nz, int64_t ny, int64_t nx,
     Taps<T> tz_, Taps<T> ty_, Taps<T> tx, int ntx, int nty, int nzc, int zchunk,
     int per_xcd, T ca = T(1), T cb = T(0), T cc = T(0),
-    double *__restrict__ part = nullptr) {
+    double *__restrict__ part = nullptr, const T *__restrict__ aux1 = nullptr,
+    const T *__restrict__ aux2 = nullptr, T *__restrict__ aux_out = nullptr,
+    const T *__restrict__ coef = nullptr) {
+  static_assert(!(RAG && EPI >= 3), "the Lanczos halves have no ragged form");
+  static_assert(EPI < 3 || NT >= 5, "the Lanczos halves keep two planes of history");
   const Taps<T> &tz = ISO ? tx : tz_;
   const Taps<T> &ty = ISO ? tx : ty_;
   typedef typename VecOf<T, VEC>::type V;
@@ -469,6 +527,16 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   const T gx2 = owner ? ca : T(0), gy2 = owner ? cb : T(0), gz2 = owner ? cc : T(0);
   const T xm = (xv + 1 < nxv) ? T(1) : T(0);
   const T ym = (y0 + row + 1 < ny) ? T(1) : T(0);
+  // (EPI 3) the lane's own vectors of the two planes before, the in-plane part of K'K x
+  // of the plane before, 0 / 1 factors for the backward differences at the first column
+  // and row; (EPI 3 / 4) the coefficients, read once
+  V prev2_own = splat<V, T>(T(0)), lapxy_prev = splat<V, T>(T(0));
+  const T lm = xv > 0 ? T(1) : T(0);
+  const T um = (y0 + row > 0) ? T(1) : T(0);
+  T k0 = T(0), k1 = T(0), k2 = T(0);
+  if constexpr (EPI == 3) { k0 = coef[0]; k1 = coef[1]; k2 = coef[2]; }   // c1, c0, c2
+  if constexpr (EPI == 4) { k0 = coef[4]; k1 = coef[5]; }                   // ca, cy
+  const bool has_prev = EPI == 3 && aux1 != nullptr;
   auto put = [&](int64_t z, V val, int ob) {
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + z * plane, 0, plane_bytes,
                                                         0x00020000);
@@ -493,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
           if (!RAG || e < nvalid) {
-            if constexpr (EPI == 2) sacc = fma1(val[e], val[e], sacc);
+            if constexpr (EPI >= 2) sacc = fma1(val[e], val[e], sacc);
             else sumsq += (double)val[e] * (double)val[e];
           }
       }
@@ -528,7 +596,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   // (EPI) the io tile of one output plane -> obuf[ob]: one 1-KiB piece per wave; lanes
   // whose tile position lies outside the volume re-read a valid neighbour
   uint32_t old_off = 0;
-  if constexpr (EPI == 1) {
+  if constexpr (EPI == 1 || EPI >= 3) {
     const int i = wave * 64 + lane;
     int64_t yy = y0 + i / lxb;
     if (yy >= ny) yy = ny - 1;
@@ -547,6 +615,23 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
           (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
                                                      (size_t)wave * 64),
           16, 0, 0);
+  };
+  // (EPI 3 / 4) the own-position tile of plane z of `src` -> obuf[ob]
+  auto stage_tile = [&](const T *src, int64_t z, int ob) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(src + z * plane + old_off),
+        (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
+                                                   (size_t)wave * 64),
+        16, 0, 0);
+  };
+  // a 16-byte store every wave issues (offset kNoLane: dropped by the hardware)
+  auto store_at = [&](T *dst, int64_t z, uint32_t off, V val) {
+    if (z < 0) z = 0;
+    if (z >= nz) z = nz - 1;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst + z * plane, 0, plane_bytes,
+                                                        0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, off, 0, 2);
+    asm volatile("s_nop 1");
   };
 
   // prologue: planes 0, 1, 2 staged, plane 0 filtered along x  (nsteps >= 2R + 1 >= 3)
@@ -568,30 +653,130 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     constexpr int u = decltype(U)::value;           // = st mod M
     constexpr int q = u & 1;                        // = st & 1 (M is even)
     const bool more = st + 3 < nsteps;
+    const bool storing = st >= 2 * R;
+    // y pass of plane st from the x-filtered tile, z pass over the ring: the value of
+    // output plane st - 2R (meaningful from st = 2R on); the ring takes plane st
+    auto yz_value = [&]() -> V {
+      const V *col = xf + (size_t)q * xf_stride + (size_t)row * lxb + lx;
+      V v = splat<V, T>(ty.w[0]) * col[0];
+#pragma unroll
+      for (int t = 1; t < NT; ++t)
+        v = __builtin_elementwise_fma(splat<V, T>(ty.w[sym(t)]), col[(size_t)t * lxb], v);
+      V acc = splat<V, T>(T(0));
+      if (st >= 2 * R) {
+        // window of plane st: the ring from its oldest slot (u), then v
+        acc = splat<V, T>(tz.w[0]) * ring[u];
+#pragma unroll
+        for (int t = 1; t < M; ++t)
+          acc = __builtin_elementwise_fma(splat<V, T>(tz.w[sym(t)]), ring[(u + t) % M], acc);
+        acc = __builtin_elementwise_fma(splat<V, T>(tz.w[0]), v, acc);
+      }
+      ring[u] = v;                                  // replaces plane st - M
+      return acc;
+    };
+    if constexpr (EPI == 4) {
+      // ---- second half of a Lanczos step: y_new = ca A x + q0 + cy y.  The lane's
+      //      q0 and y of this output plane leave their (single) LDS tiles for registers
+      //      at the START of the phase, and the tiles of the next output plane are
+      //      requested right behind: a whole phase for them to land, like the raw tiles.
+      V q0v = splat<V, T>(T(0)), yv = splat<V, T>(T(0));
+      if (storing) {                                // (uniform)
+        q0v = obuf[(size_t)row * lxb + lx];
+        yv = obuf[(size_t)tile_vecs + (size_t)row * lxb + lx];
+      }
+      if (st + 1 >= 2 * R && st + 1 < nsteps) {
+        // (a wave only reads what its own piece brought: its reads above are done
+        // before its next piece can land, and the wait makes that explicit)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_tile(aux1, zbeg + (st + 1 - 2 * R), 0);
+        stage_tile(aux2, zbeg + (st + 1 - 2 * R), 1);
+      }
+      if (more) stage(next_plane(), r_cur);         // plane st + 3
+      if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+      V val = yz_value();
+      uint32_t soff = kNoLane;
+      if (storing) {
+        val = (splat<V, T>(k0) * val + q0v) + splat<V, T>(k1) * yv;
+        if (owner) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sacc = fma1(val[e], val[e], sacc);
+        }
+        soff = own_off;
+      }
+      store_at(out, zbeg + (st - 2 * R), soff, val);
+      const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
+      phase_end((more ? my_stage_ops : 0) + 1);
+      return;
+    }
+    if constexpr (EPI == 3) {
+      // ---- first half: K'K x of plane st (z part now, in-plane part from the phase
+      //      before) -> q0; the difference sums of EPI 2 from the same values.  The
+      //      y_prev tile of plane st + 1 is requested first (two tiles alternate).
+      if (has_prev && st + 1 >= R && st + 1 < nsteps - R)
+        stage_tile(aux1, zbeg + (st + 1 - R), q ^ 1);
+      if (more) stage(next_plane(), r_cur);         // plane st + 3
+      V q0v = splat<V, T>(T(0));
+      uint32_t qoff = kNoLane;
+      if (st + 1 < nsteps) {
+        const V *o = raw + (size_t)r_next + (size_t)(row + R) * rl + lx + NBH;
+        const V own = o[0];
+        V lapxy = splat<V, T>(T(0));
+        if (st + 1 >= R && st + 1 < nsteps - R) {          // in-plane part, plane st + 1
+          const V right = o[1], left = o[-1], down = o[rl], up = o[-rl];
+          const V dy = __builtin_elementwise_fma(down, splat<V, T>(ym), -own);
+          const V dpy = (own - up) * splat<V, T>(um);
+          T dx[VEC];
+          T sx = T(0), sy = T(0);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            dx[k] = (k + 1 < VEC) ? own[(k + 1) % VEC] - own[k]
+                                  : fma1(right[0], xm, -own[k]);
+            sx = fma1(dx[k], dx[k], sx);
+            sy = fma1(dy[k], dy[k], sy);
+          }
+          gacc = fma1(gx2, sx, fma1(gy2, sy, gacc));
+          const T dl = (own[0] - left[VEC - 1]) * lm;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const T l = (k > 0) ? dx[(k + VEC - 1) % VEC] : dl;
+            lapxy[k] = (l - dx[k]) + (dpy[k] - dy[k]);
+          }
+        }
+        if (st >= R && st < nsteps - R) {                  // z part, plane st
+          const int64_t zc = zbeg + (st - R);
+          const T zm = (zc + 1 < nz) ? T(1) : T(0);
+          const T zlm = zc > 0 ? T(1) : T(0);
+          const V dz = __builtin_elementwise_fma(own, splat<V, T>(zm), -prev_own);
+          const V dpz = (prev_own - prev2_own) * splat<V, T>(zlm);
+          T sz = T(0);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) sz = fma1(dz[k], dz[k], sz);
+          gacc = fma1(gz2, sz, gacc);
+          const V lap = lapxy_prev + (dpz - dz);
+          q0v = splat<V, T>(k0) * lap + splat<V, T>(k1) * prev_own;
+          if (has_prev)                                      // (uniform)
+            q0v = q0v + splat<V, T>(k2) *
+                            obuf[(size_t)q * tile_vecs + (size_t)row * lxb + lx];
+          qoff = own_off;
+        }
+        prev2_own = prev_own;
+        prev_own = own;
+        lapxy_prev = lapxy;
+      }
+      store_at(aux_out, zbeg + (st - R), qoff, q0v);
+      if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+      const V acc = yz_value();
+      if (storing) put(zbeg + (st - 2 * R), acc, q);
+      const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
+      phase_end((more ? my_stage_ops : 0) + 1 + (storing ? my_store_ops : 0));
+      return;
+    }
     if (EPI == 1 && st + 1 >= 2 * R && st + 1 < nsteps)
       stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io of the next output plane
     if (more) stage(next_plane(), r_cur);           // plane st + 3, two phases ahead
     // (The x pass of plane st + 1 and the y / z passes of plane st are independent,
     // but letting half of the waves of a SIMD run them in the opposite order, so that
     // not everybody waits for the LDS at the same time, measured no faster.)
-    const bool storing = st >= 2 * R;
-    auto yz = [&]() {
-      const V *col = xf + (size_t)q * xf_stride + (size_t)row * lxb + lx;
-      V v = splat<V, T>(ty.w[0]) * col[0];
-#pragma unroll
-      for (int t = 1; t < NT; ++t)
-        v = __builtin_elementwise_fma(splat<V, T>(ty.w[sym(t)]), col[(size_t)t * lxb], v);
-      if (st >= 2 * R) {
-        // window of plane st: the ring from its oldest slot (u), then v
-        V acc = splat<V, T>(tz.w[0]) * ring[u];
-#pragma unroll
-        for (int t = 1; t < M; ++t)
-          acc = __builtin_elementwise_fma(splat<V, T>(tz.w[sym(t)]), ring[(u + t) % M], acc);
-        acc = __builtin_elementwise_fma(splat<V, T>(tz.w[0]), v, acc);
-        if (storing) put(zbeg + (st - 2 * R), acc, q);
-      }
-      ring[u] = v;                                  // replaces plane st - M
-    };
     if (st + 1 < nsteps) xpass(r_next, q ^ 1);
     if constexpr (EPI == 2) {
       if (st + 1 < nsteps) {
@@ -640,7 +825,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         prev_own = own;
       }
     }
-    yz();
+    {
+      const V acc = yz_value();
+      if (storing) put(zbeg + (st - 2 * R), acc, q);
+    }
     const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
     // plane st + 2 (staged in the previous phase) must have landed; younger than
     // its pieces are this phase's pieces and this phase's store
@@ -649,7 +837,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
 #pragma unroll 1
   for (int st0 = 0; st0 < nsteps; st0 += M) {
     blur3_phases<0, M>(st0, nsteps, phase);
-    if constexpr (EPI == 2) {
+    if constexpr (EPI >= 2) {
       sumsq += (double)sacc;
       gsum += (double)gacc;
       sacc = gacc = T(0);
@@ -661,7 +849,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sumsq += __shfl_down(sumsq, o, 64);
     if (lane == 0) red[wave] = sumsq;
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 2 || EPI == 3) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) gsum += __shfl_down(gsum, o, 64);
       if (lane == 0) red[NW + wave] = gsum;
@@ -672,7 +860,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       for (int w2 = 0; w2 < NW; ++w2) t += red[w2];
       part[logical] = t;
     }
-    if (EPI == 2 && tid == 64) {
+    if ((EPI == 2 || EPI == 3) && tid == 64) {
       double t = 0.0;
       for (int w2 = 0; w2 < NW; ++w2) t += red[NW + w2];
       part[total + logical] = t;
@@ -697,6 +885,62 @@ __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, 
 }
 
 
+// What closes a Lanczos half: the per-tile partials summed in a fixed order onto the
+// scalar board, and the coefficients of the NEXT kernel formed from the board in double
+// (IEEE division and square root: the values the host forms from the same sums).
+//   which 0 (init):    coef[0..2] = rho_g / beta_0, rho_i / beta_0, 0
+//   which 1 (after A): board[3 j + 1] = sum t^2, board[3 j + 2] = sum |grad y|^2;
+//                      alpha = (tt + rho_g gg) / |y_j|^2 + rho_i;
+//                      coef[4] = 1 / beta_j, coef[5] = -alpha / beta_j
+//   which 2 (after B): board[3 j + 3] = sum y_new^2 = beta_{j+1}^2;
+//                      coef[0..2] = rho_g / beta_{j+1}, rho_i / beta_{j+1}, -beta_{j+1} / beta_j
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_blur3_lanczos_final(
+    const double *part, int n, int which, double *board, int j, double rho_g, double rho_i,
+    T *coef) {
+  __shared__ double s[2][kBlock];
+  const int nsum = which == 1 ? 2 : (which == 2 ? 1 : 0);
+  for (int a = 0; a < nsum; ++a) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) t += part[(size_t)a * n + i];
+    s[a][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double r[2] = {0.0, 0.0};
+  for (int a = 0; a < nsum; ++a)
+    for (int i = 0; i < kBlock; ++i) r[a] += s[a][i];
+  if (which == 0) {
+    const double b0 = sqrt(board[0]);
+    coef[0] = (T)(rho_g / b0);
+    coef[1] = (T)(rho_i / b0);
+    coef[2] = T(0);
+  } else if (which == 1) {
+    board[3 * j + 1] = r[0];
+    board[3 * j + 2] = r[1];
+    const double nb2 = board[3 * j];
+    const double alpha = (r[0] + rho_g * r[1]) / nb2 + rho_i;
+    const double beta = sqrt(nb2);
+    coef[4] = (T)(1.0 / beta);
+    coef[5] = (T)(-alpha / beta);
+  } else {
+    board[3 * j + 3] = r[0];
+    const double bn = sqrt(r[0]), beta = sqrt(board[3 * j]);
+    coef[0] = (T)(rho_g / bn);
+    coef[1] = (T)(rho_i / bn);
+    coef[2] = (T)(-bn / beta);
+  }
+}
+
+template <typename T>
+struct LanczosArgs {
+  const T *aux1, *aux2;
+  T *aux_out, *coef;
+  double *board;
+  int step;
+  double rho_g, rho_i;
+};
+
 // LDS-DMA staged kernel: tiles of kDmaLxb lanes per row whatever the row length;
 // returns -2 when it does not apply.  EPI 1 (out = io, in place): io = ca * blur(x) +
 // cb * io and *result = sum of squares of the new io (part: >= tiles doubles).  EPI 2:
@@ -706,20 +950,25 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                      const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,
                      hipStream_t st, double ca = 1.0, double cb = 0.0, double cc = 0.0,
                      double *result = nullptr, double *part = nullptr,
-                     int64_t part_doubles = 0) {
+                     int64_t part_doubles = 0, const LanczosArgs<T> *lz = nullptr) {
   constexpr int R = NT / 2;
   constexpr int NBH = (R + VEC - 1) / VEC;
   constexpr int dl = kDmaLxb;
   constexpr int dtyr = (NWD * 64) / dl;
   constexpr int frows = dtyr + 2 * R;
   constexpr int npieces = (frows * (dl + 2 * NBH) + 63) / 64;
+  // own-position tiles staged beside the raw tiles: EPI 1 two (old io, double buffered),
+  // EPI 3 two (y_prev, double buffered), EPI 4 two (q0 and y, one buffer each)
+  constexpr int otiles = EPI == 1 ? 2 : (EPI == 3 ? 2 : (EPI == 4 ? 2 : 0));
   constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl +
-                           (EPI == 1 ? 2 * (size_t)dtyr * dl : 0)) * 16;
+                           (size_t)otiles * dtyr * dl) * 16;
   constexpr size_t lds_patch = 3 * (size_t)((frows * 4 + 63) / 64) * 16 * 16;   // (RAG)
-  if constexpr (lds0 > 160 * 1024 || (EPI == 2 && sizeof(T) == 8 && NT >= 15)) {
+  if constexpr (lds0 > 160 * 1024 || ((EPI == 2 || EPI == 3) && sizeof(T) == 8 && NT >= 15) ||
+                (EPI >= 3 && (NT < 5 || NT >= 15))) {
     static_assert(EPI != 0, "LDS-DMA blur tile does not fit");
-    // (no room for the io tiles; the difference sums of 15 / 17 taps in double would
-    // need more than the 128 registers of a 16-wave workgroup)
+    // (no room for the io tiles; the difference sums of 15 / 17 taps in double -- and the
+    // first Lanczos half at 15 / 17 taps in either type -- would need more than the 128
+    // registers of a 16-wave workgroup)
     return -2;
   } else {
   if (dtyr < 2 * R) return -2;
@@ -728,6 +977,12 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const bool rag = nx % VEC != 0 || ((reinterpret_cast<uintptr_t>(x) |
                                       reinterpret_cast<uintptr_t>(out)) & 15u);
   if (rag && (!nsol_blur3_dma_rag || nx < (int64_t)(dl + 2 * NBH) * VEC)) return -2;
+  if constexpr (EPI >= 3) {
+    if (rag || !lz) return -2;                     // (no ragged form of the Lanczos halves)
+    if ((reinterpret_cast<uintptr_t>(lz->aux1) | reinterpret_cast<uintptr_t>(lz->aux2) |
+         reinterpret_cast<uintptr_t>(lz->aux_out)) & 15u)
+      return -2;
+  }
   const size_t lds = lds0 + (rag ? lds_patch : 0);
   if (lds > 160 * 1024) return -2;
   const int64_t nxv = (nx + VEC - 1) / VEC;
@@ -751,13 +1006,13 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int64_t nzc = (nz + zchunk - 1) / zchunk;
   const int64_t tiles = dntx * dnty * nzc;
   if (tiles >= ((int64_t)1 << 28)) return -2;
-  if (EPI != 0 && tiles * (EPI == 2 ? 2 : 1) > part_doubles) return -2;
+  if (EPI != 0 && tiles * ((EPI == 2 || EPI == 3) ? 2 : 1) > part_doubles) return -2;
   const int per_xcd = (int)((tiles + 7) / 8);
   bool iso = true;
   for (int t = 0; t < NT; ++t) iso = iso && tz.w[t] == tx.w[t] && ty.w[t] == tx.w[t];
   // (the difference sums on ragged rows at 17 taps would spill: the caller takes
   // nsol_tk1_grad_norm_* beside the epilogue form there)
-  constexpr bool RG = !(EPI == 2 && NT >= 17);
+  constexpr bool RG = !(EPI == 2 && NT >= 17) && EPI < 3;
   if (rag && !RG) return -2;
   auto kern = rag ? (iso ? k_blur3_dma<T, VEC, NT, NWD, true, EPI, RG>
                          : k_blur3_dma<T, VEC, NT, NWD, false, EPI, RG>)
@@ -769,9 +1024,20 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                                        (int)lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
   }
+  if constexpr (EPI >= 3) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
+                       nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
+                       per_xcd, (T)ca, (T)cb, (T)cc, part, lz->aux1, lz->aux2, lz->aux_out,
+                       (const T *)lz->coef);
+    hipLaunchKernelGGL(k_blur3_lanczos_final<T>, dim3(1), dim3(kBlock), 0, st, part,
+                       (int)tiles, EPI == 3 ? 1 : 2, lz->board, lz->step, lz->rho_g,
+                       lz->rho_i, lz->coef);
+    return launch_status();
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
                      nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
-                     per_xcd, (T)ca, (T)cb, (T)cc, part);
+                     per_xcd, (T)ca, (T)cb, (T)cc, part, (const T *)nullptr,
+                     (const T *)nullptr, (T *)nullptr, (const T *)nullptr);
   if (EPI != 0)
     hipLaunchKernelGGL(k_blur3_epi_final, dim3(EPI == 2 ? 2 : 1), dim3(kBlock), 0, st, part,
                        (int)tiles, result);
@@ -802,6 +1068,50 @@ int blur3_dma_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
 #undef NSOL_B3D_CASE
 }
 
+template <typename T, int EPI>
+int blur3_lanczos_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
+                           const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, int ntaps,
+                           const LanczosArgs<T> &lz, double *part, int64_t part_doubles,
+                           hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  // (the squared weights of the difference sums: unit spacing)
+#define NSOL_B3L_CASE(N)                                                                    \
+  case N:                                                                                   \
+    return launch_blur3_dma<T, VEC, N, 16, EPI>(x, out, nz, ny, nx, tz, ty, tx, st, 1.0, 1.0, \
+                                                1.0, nullptr, part, part_doubles, &lz);
+  switch (ntaps) {
+    NSOL_B3L_CASE(5) NSOL_B3L_CASE(7) NSOL_B3L_CASE(9) NSOL_B3L_CASE(11) NSOL_B3L_CASE(13)
+    NSOL_B3L_CASE(15) NSOL_B3L_CASE(17)
+    default: return -2;
+  }
+#undef NSOL_B3L_CASE
+}
+
 }  // namespace
+
+#define NSOL_B3L_DEF(T)                                                                      \
+  int blur3_lanczos_a(const T *y, const T *y_prev, T *t, T *q0, int64_t nz, int64_t ny,      \
+                      int64_t nx, const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,   \
+                      int ntaps, double rho_g, double rho_i, double *board, int step, T *coef, \
+                      double *part, int64_t part_doubles, hipStream_t st) {                  \
+    const LanczosArgs<T> lz{y_prev, nullptr, q0, coef, board, step, rho_g, rho_i};           \
+    return blur3_lanczos_dispatch<T, 3>(y, t, nz, ny, nx, tz, ty, tx, ntaps, lz, part,       \
+                                        part_doubles, st);                                   \
+  }                                                                                          \
+  int blur3_lanczos_b(const T *t, const T *q0, const T *y, T *y_new, int64_t nz, int64_t ny, \
+                      int64_t nx, const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx,   \
+                      int ntaps, double rho_g, double rho_i, double *board, int step, T *coef, \
+                      double *part, int64_t part_doubles, hipStream_t st) {                  \
+    const LanczosArgs<T> lz{q0, y, nullptr, coef, board, step, rho_g, rho_i};                \
+    return blur3_lanczos_dispatch<T, 4>(t, y_new, nz, ny, nx, tz, ty, tx, ntaps, lz, part,   \
+                                        part_doubles, st);                                   \
+  }                                                                                          \
+  int blur3_lanczos_init(double *board, T *coef, double rho_g, double rho_i,                 \
+                         hipStream_t st) {                                                   \
+    hipLaunchKernelGGL(k_blur3_lanczos_final<T>, dim3(1), dim3(kBlock), 0, st, nullptr, 0, 0, \
+                       board, 0, rho_g, rho_i, coef);                                        \
+    return launch_status();                                                                  \
+  }
+
 }  // namespace nsol_blur3
 #endif  // NSOL_BLUR3_DMA_IMPL

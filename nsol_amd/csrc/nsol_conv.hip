@@ -705,6 +705,57 @@ int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
                        ws_doubles, st);
 }
 
+// nsol_corr3_wrap_lanczos_{init,a,b}_*: the two halves of a Lanczos step on
+// A'A + rho B'B taken by the one-pass blur (nsol_blur3_dma.hpp, EPI 3 / 4); -2 when
+// that form does not apply (the caller then runs blur, blur and nsol_tk1_lanczos_*)
+template <typename T>
+bool lanczos_taps(const double *tz_host, const double *ty_host, const double *tx_host,
+                  int ntaps, Taps<T> *tz, Taps<T> *ty, Taps<T> *tx) {
+  if ((ntaps & 1) == 0 || ntaps < 5 || ntaps > 13 || !g_blur3_dma || g_blur3_lxb != kDmaLxb)
+    return false;
+  for (int t = 0; t < kMaxTaps; ++t) {
+    tz->w[t] = t < ntaps ? (T)tz_host[t] : T(0);
+    ty->w[t] = t < ntaps ? (T)ty_host[t] : T(0);
+    tx->w[t] = t < ntaps ? (T)tx_host[t] : T(0);
+  }
+  for (int t = 0; t < ntaps / 2; ++t)
+    if (tz->w[t] != tz->w[ntaps - 1 - t] || ty->w[t] != ty->w[ntaps - 1 - t] ||
+        tx->w[t] != tx->w[ntaps - 1 - t])
+      return false;
+  return true;
+}
+
+template <typename T>
+int lanczos_a_impl(const T *y, const T *y_prev, T *t, T *q0, int64_t nz, int64_t ny,
+                   int64_t nx, const double *tz_host, const double *ty_host,
+                   const double *tx_host, int ntaps, double rho_grad, double rho_ident,
+                   double *board, int step, T *coef, double *ws, int64_t ws_doubles,
+                   void *stream) {
+  if (!y || !t || !q0 || y == t || y == q0 || t == q0 || !tz_host || !ty_host || !tx_host ||
+      !board || !coef || !ws || step < 0 || nz < 1 || ny < 1 || nx < 1)
+    return NSOL_EINVAL;
+  Taps<T> tz, ty, tx;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  return blur3_lanczos_a(y, y_prev, t, q0, nz, ny, nx, tz, ty, tx, ntaps, rho_grad, rho_ident,
+                         board, step, coef, ws, ws_doubles, as_stream(stream));
+}
+
+template <typename T>
+int lanczos_b_impl(const T *t, const T *q0, const T *y, T *y_new, int64_t nz, int64_t ny,
+                   int64_t nx, const double *tz_host, const double *ty_host,
+                   const double *tx_host, int ntaps, double rho_grad, double rho_ident,
+                   double *board, int step, T *coef, double *ws, int64_t ws_doubles,
+                   void *stream) {
+  if (!t || !q0 || !y || !y_new || y_new == t || y_new == q0 || y_new == y || !tz_host ||
+      !ty_host || !tx_host || !board || !coef || !ws || step < 0 || nz < 1 || ny < 1 ||
+      nx < 1)
+    return NSOL_EINVAL;
+  Taps<T> tz, ty, tx;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  return blur3_lanczos_b(t, q0, y, y_new, nz, ny, nx, tz, ty, tx, ntaps, rho_grad, rho_ident,
+                         board, step, coef, ws, ws_doubles, as_stream(stream));
+}
+
 template <typename T, int VEC, int NT>
 int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                  const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, bool symmetric,
@@ -916,6 +967,33 @@ int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t 
   return corr3_axpby_impl<double>(x, out, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, wx * wx,
                                   wy * wy, result, ws, ws_doubles, stream, 2, wz * wz);
 }
+#define NSOL_LANCZOS_DEF(T, SUF)                                                          \
+  int nsol_corr3_wrap_lanczos_init_##SUF(double *board, T *coef, double rho_grad,         \
+                                         double rho_ident, void *stream) {                \
+    if (!board || !coef) return NSOL_EINVAL;                                              \
+    return blur3_lanczos_init(board, coef, rho_grad, rho_ident, as_stream(stream));       \
+  }                                                                                       \
+  int nsol_corr3_wrap_lanczos_a_##SUF(                                                    \
+      const T *y, const T *y_prev, T *t, T *q0, int64_t nz, int64_t ny, int64_t nx,       \
+      const double *taps_z, const double *taps_y, const double *taps_x, int ntaps,        \
+      double rho_grad, double rho_ident, double *board, int step, T *coef, double *ws,    \
+      int64_t ws_doubles, void *stream) {                                                 \
+    return lanczos_a_impl<T>(y, y_prev, t, q0, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, \
+                             rho_grad, rho_ident, board, step, coef, ws, ws_doubles,      \
+                             stream);                                                     \
+  }                                                                                       \
+  int nsol_corr3_wrap_lanczos_b_##SUF(                                                    \
+      const T *t, const T *q0, const T *y, T *y_new, int64_t nz, int64_t ny, int64_t nx,  \
+      const double *taps_z, const double *taps_y, const double *taps_x, int ntaps,        \
+      double rho_grad, double rho_ident, double *board, int step, T *coef, double *ws,    \
+      int64_t ws_doubles, void *stream) {                                                 \
+    return lanczos_b_impl<T>(t, q0, y, y_new, nz, ny, nx, taps_z, taps_y, taps_x, ntaps,  \
+                             rho_grad, rho_ident, board, step, coef, ws, ws_doubles,      \
+                             stream);                                                     \
+  }
+NSOL_LANCZOS_DEF(float, f32)
+NSOL_LANCZOS_DEF(double, f64)
+#undef NSOL_LANCZOS_DEF
 int nsol_corr_dense_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const float *taps, int kz, int ky, int kx,
                         int cz, int cy, int cx, int mode, void *stream) {

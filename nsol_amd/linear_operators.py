@@ -220,6 +220,22 @@ class ConvolutionOperator(DeviceOperator):
         return ops.corr3_wrap_norms(x, out, in_shape, self._passes[0][1],
                                     self._passes[1][1], self._passes[2][1], w, result)
 
+    def lanczos_halves(self, in_shape):
+        """(half_a, half_b) -- ops.corr3_lanczos_a / _b bound to this blur's taps -- when
+        the one-pass blur can take both halves of a Lanczos step on A'A + rho B'B itself
+        (symmetric separable taps on a 3-D grid), else None."""
+        if not (USE_FUSED_BLUR3 and USE_BLUR_EPILOGUE and self._passes and
+                len(in_shape) == 3 and self._fusable3()):
+            return None
+        tz, ty, tx = (self._passes[0][1], self._passes[1][1], self._passes[2][1])
+
+        def half_a(y, y_prev, t, q0, lb, step):
+            return ops.corr3_lanczos_a(y, y_prev, t, q0, in_shape, tz, ty, tx, lb, step)
+
+        def half_b(t, q0, y, y_new, lb, step):
+            return ops.corr3_lanczos_b(t, q0, y, y_new, in_shape, tz, ty, tx, lb, step)
+        return half_a, half_b
+
     def _apply(self, x, in_shape):
         if len(in_shape) != self.dimension:
             raise RuntimeError("%dD convolution applied to %d axes" %

@@ -229,6 +229,10 @@ NE_MAX_COND = {4: 1.0e3, 8: 1.0e7}
 NE_MAX_ITER = 32
 # the blur takes sum |grad y_j|^2 of its input itself (nsol_corr3_wrap_norms_*)
 USE_BLUR_NORMS = True
+# ... and the whole Lanczos update: two kernels per step (nsol_corr3_wrap_lanczos_a / _b)
+# instead of blur, blur and nsol_tk1_lanczos_*; the step's scalars stay on the device
+USE_BLUR_LANCZOS = True
+LAST_FORM = [None]           # (diagnostics: "lanczos-in-blur" / "lanczos" / None)
 LAST_NE_COND = [None]        # (diagnostics: the estimate of the last run)
 
 
@@ -364,31 +368,41 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     # g = A^T b_top + sa B^T b_bot
     atu = atb() if atb is not None else A_adj(b_top)
     g = torch.empty_like(x_like)
-    beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0,
-                                        sa * b_bot_scale,
-                                        0.0, out=g))
-    del atu
+
+    def rhs_norm2():
+        # (right-hand side [b_top; b_bot_scale * b_bot]; the caller's figure if it has one)
+        if normb2 is not None:
+            return normb2
+        r = ops.dot(b_top, b_top)
+        if b_bot is not None and bmode != ops.B_NONE:
+            r += b_bot_scale ** 2 * ops.dot(b_bot, b_bot)
+        return r
+    halves = getattr(A_axpby, "lanczos", None) if USE_BLUR_LANCZOS else None
+    if halves is not None and bmode in (ops.B_GRAD, ops.B_IDENTITY) and \
+            (not grad_mode or (tuple(w) == (1.0, 1.0, 1.0) and
+                               tuple(getattr(A_axpby, "shape", ())) == tuple(shape))):
+        # both halves of every step inside the blur: |g|^2 goes straight onto the
+        # device's scalar board and the steps are enqueued behind it, unseen by the host
+        lb = ops.LanczosBoard(x_like, maxiter, rho if grad_mode else 0.0,
+                              0.0 if grad_mode else rho)
+        ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0, sa * b_bot_scale, 0.0,
+                          out=g, result=lb.slot_norm2(0))
+        del atu
+        got = _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds)
+        if got is not None:
+            return got
+        beta1 = math.sqrt(float(lb.board[0].item()))     # (the kernels do not apply)
+    else:
+        beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0,
+                                            sa * b_bot_scale, 0.0, out=g))
+        del atu
     if beta1 == 0:
         return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
-    if normb2 is None:
-        # (right-hand side [b_top; b_bot_scale * b_bot])
-        normb2 = ops.dot(b_top, b_top)
-        if b_bot is not None and bmode != ops.B_NONE:
-            normb2 += b_bot_scale ** 2 * ops.dot(b_bot, b_bot)
+    normb2 = rhs_norm2()
 
     def scipy_stop(co):
-        """istop of scipy lsmr.py:432-449 after iteration co.itn (0: go on)."""
-        test1, test2, t1 = co.lsmr_tests(normb2)
-        stop = 0
-        if 1 + test2 <= 1:
-            stop = 5
-        if 1 + t1 <= 1:
-            stop = 4
-        if test2 <= 0.0:
-            stop = 2
-        if test1 <= 0.0:
-            stop = 1
-        return stop
+        return _scipy_stop(co, normb2)
+    LAST_FORM[0] = "lanczos"
     ys, betas = [g], [beta1]
     co = MinresCoefficients(maxiter + 1, beta1)
     t = torch.zeros_like(x_like)
@@ -453,6 +467,89 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     LAST_NE_COND[0] = co.gmax / co.gmin if co.gmin > 0 else np.inf
     if LAST_NE_COND[0] > NE_MAX_COND[x_like.element_size()]:
         return None, -1, k             # too ill-conditioned for this form
+    x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)],
+                         bounds=x_bounds)
+    return x, istop, k
+
+
+def _scipy_stop(co, normb2):
+    """istop of scipy lsmr.py:432-449 after iteration co.itn (0: go on), atol = btol =
+    0: the tests on machine precision (4, 5) and on exact zeros (1, 2)."""
+    test1, test2, t1 = co.lsmr_tests(normb2)
+    stop = 0
+    if 1 + test2 <= 1:
+        stop = 5
+    if 1 + t1 <= 1:
+        stop = 4
+    if test2 <= 0.0:
+        stop = 2
+    if test1 <= 0.0:
+        stop = 1
+    return stop
+
+
+def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
+    """lsmr_normal's loop with both halves of every step inside the blur
+    (nsol_corr3_wrap_lanczos_a / _b, nsol_blur3_dma.hpp): per step
+        t = A y_j, |t|^2, |grad y_j|^2, q0 = (rho / beta_j) K'K y_j - (beta_j / beta_{j-1}) y_{j-1}
+        y_{j+1} = (1 / beta_j) A t + q0 - (alfa_j / beta_j) y_j, |y_{j+1}|^2
+    with the coefficients formed ON THE DEVICE from the sums (lb: ops.LanczosBoard,
+    |g|^2 already on its way to board[0]): the steps are enqueued back to back and the
+    host reads the scalars once, afterwards, for the MINRES recurrences and SciPy's
+    stopping tests (a run that would have stopped early has then computed vectors it
+    does not use).  The guard on the regulariser's weight looks at step 0's sums once
+    two more steps are enqueued -- nobody waits.  Returns (x, istop, itn), (None, -1, 0)
+    when the guard fails, None when the kernels do not apply (nothing but the board's
+    initialisation was enqueued)."""
+    import torch
+    half_a, half_b = halves
+    lb.init()
+    ys = [g]
+    t, q0 = torch.empty_like(x_like), torch.empty_like(x_like)
+    fetch = ops.ScalarFetch(x_like.device, 3)
+    look = min(2, maxiter - 1)
+    for j in range(maxiter):
+        ynew = torch.empty_like(x_like)
+        if not half_a(ys[-1], ys[-2] if j > 0 else None, t, q0, lb, j):
+            if j == 0:
+                return None
+            raise RuntimeError("nsol_corr3_wrap_lanczos_a stopped applying mid-solve")
+        if j == 0:
+            fetch.start(lb.board[0:3])
+        if not half_b(t, q0, ys[-1], ynew, lb, j):
+            raise RuntimeError("nsol_corr3_wrap_lanczos_b does not apply")
+        ys.append(ynew)
+        if j == look:
+            v0 = fetch.wait()
+            if not float(v0[0]) > 0:                       # g = 0: x = 0
+                return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
+            if rho < NE_MIN_WEIGHT[x_like.element_size()] * float(v0[1]) / float(v0[0]):
+                return None, -1, 0       # regulariser too weak against ||A||^2
+    normb2 = rhs_norm2()
+    board = lb.board.cpu().numpy()
+    nb2, tt, gg = board[0::3], board[1::3], board[2::3]
+    betas = [math.sqrt(nb2[0])]
+    co = MinresCoefficients(maxiter + 1, betas[0])
+    istop = 7
+    for j in range(maxiter):
+        alfa = (tt[j] + lb.rho_grad * gg[j]) / nb2[j] + lb.rho_ident
+        beta_next = math.sqrt(nb2[j + 1]) if nb2[j + 1] > 0 else 0.0
+        co.step(alfa, beta_next)
+        stop = _scipy_stop(co, normb2)
+        if j + 1 < maxiter:
+            if stop == 0 and (beta_next == 0 or not math.isfinite(beta_next)):
+                stop = 2                                  # Krylov space exhausted
+            if stop:
+                istop = stop
+                break
+            betas.append(beta_next)
+        else:
+            istop = stop or istop
+    k = co.itn
+    LAST_NE_COND[0] = co.gmax / co.gmin if co.gmin > 0 else np.inf
+    LAST_FORM[0] = "lanczos-in-blur"
+    if LAST_NE_COND[0] > NE_MAX_COND[x_like.element_size()]:
+        return None, -1, k
     x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)],
                          bounds=x_bounds)
     return x, istop, k

@@ -214,6 +214,72 @@ def corr3_wrap_norms(x, out, shape, taps_z, taps_y, taps_x, w, result):
     return result
 
 
+class LanczosBoard(object):
+    """Device scalars of an LSMR solve run as Lanczos on the normal equations with both
+    halves of a step taken by the blur (nsol_corr3_wrap_lanczos_*): the sums of every
+    step (board: |y_j|^2, |A y_j|^2, |grad y_j|^2 at 3 j ..) and the coefficients the
+    next kernel reads (coef).  The host reads the board when it needs the scalars --
+    the kernels never wait for it."""
+
+    def __init__(self, like, steps, rho_grad, rho_ident):
+        self.steps = int(steps)
+        self.rho_grad, self.rho_ident = float(rho_grad), float(rho_ident)
+        self.board = torch.zeros(3 * (self.steps + 2), dtype=torch.float64,
+                                 device=like.device)
+        self.coef = torch.zeros(8, dtype=like.dtype, device=like.device)
+
+    def slot_norm2(self, j):
+        """The one-element view |y_j|^2 lands in (a reduction kernel's `result`)."""
+        return self.board[3 * j:3 * j + 1]
+
+    def init(self):
+        _lib.check(_fn("corr3_wrap_lanczos_init", self.coef)(
+            _p(self.board), _p(self.coef), self.rho_grad, self.rho_ident, stream_ptr()),
+            "nsol_corr3_wrap_lanczos_init")
+
+
+def corr3_lanczos_a(y, y_prev, t, q0, shape, taps_z, taps_y, taps_x, lb, step):
+    """First half of Lanczos step `step` (see LanczosBoard): t = blur(y), q0 = c1 K'K y +
+    c0 y + c2 y_prev, sums onto the board.  False when the kernel does not apply
+    (nothing launched)."""
+    _same(y, t, q0)
+    if y_prev is not None:
+        _same(y, y_prev)
+    ndim, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(v, dtype=np.float64)
+                  for v in (taps_z, taps_y, taps_x))
+    if ndim != 3 or nz * ny * nx != y.numel() or not (tz.size == ty.size == tx.size):
+        return False
+    ws, _ = _workspace(y.device)
+    rc = _fn("corr3_wrap_lanczos_a", y)(
+        _p(y), _p(y_prev), _p(t), _p(q0), nz, ny, nx, tz.ctypes.data, ty.ctypes.data,
+        tx.ctypes.data, int(tz.size), lb.rho_grad, lb.rho_ident, _p(lb.board), int(step),
+        _p(lb.coef), _p(ws), int(ws.numel()), stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_corr3_wrap_lanczos_a")
+    return True
+
+
+def corr3_lanczos_b(t, q0, y, y_new, shape, taps_z, taps_y, taps_x, lb, step):
+    """Second half: y_new = ca blur(t) + q0 + cy y with |y_new|^2 onto the board."""
+    _same(t, q0, y, y_new)
+    ndim, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(v, dtype=np.float64)
+                  for v in (taps_z, taps_y, taps_x))
+    if ndim != 3 or nz * ny * nx != y.numel() or not (tz.size == ty.size == tx.size):
+        return False
+    ws, _ = _workspace(y.device)
+    rc = _fn("corr3_wrap_lanczos_b", y)(
+        _p(t), _p(q0), _p(y), _p(y_new), nz, ny, nx, tz.ctypes.data, ty.ctypes.data,
+        tx.ctypes.data, int(tz.size), lb.rho_grad, lb.rho_ident, _p(lb.board), int(step),
+        _p(lb.coef), _p(ws), int(ws.numel()), stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_corr3_wrap_lanczos_b")
+    return True
+
+
 def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
     _chk(x)
     _chk(taps_dev)

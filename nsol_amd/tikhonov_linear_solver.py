@@ -214,6 +214,14 @@ class TikhonovLinearSolver(LinearSolver):
         epilogue.shape = shape
         epilogue.norms = lambda v, out, w, result: op.apply_norms(v, out, shape, w,
                                                                   result)
+        # (for lsmr_normal: both halves of a Lanczos step inside the blur -- needs
+        # A_adj to be this very blur, which it is for symmetric taps)
+        epilogue.lanczos = None
+        da = trace_operator(self._A_adj, n)
+        if da is not None and da[0] == "conv" and tuple(da[2]) == shape and \
+                hasattr(op, "lanczos_halves") and \
+                (da[1] is op or getattr(da[1], "same_blur_as", lambda o: False)(op)):
+            epilogue.lanczos = op.lanczos_halves(shape)
         return epilogue
 
     def _fused_lsmr_setup(self, x0):

@@ -645,6 +645,76 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
         assert rel_l2(s.get_x(), g["admm_lsmr_" + k]) < tol
 
 
+@pytest.mark.parametrize("shape,sigma2,dtype", [
+    ((40, 48, 64), 4.0, np.float32), ((33, 70, 128), 4.0, np.float32),
+    ((64, 64, 64), 1.0, np.float32), ((24, 40, 96), 2.0, np.float32),
+    ((30, 36, 64), 4.0, np.float64), ((20, 20, 32), 1.0, np.float64)])
+@pytest.mark.parametrize("ident", [False, True])
+def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype, ident):
+    """nsol_corr3_wrap_lanczos_a / _b: both halves of a Lanczos step on A'A + rho B'B
+    inside the one-pass blur.  Against their parts, bit for bit: t and the two sums as
+    nsol_corr3_wrap_norms_* leaves them; q0 as nsol_tk1_lanczos_* (c_g = 0) forms it;
+    y_new as nsol_lincomb3_* of the plain blur; the coefficients the device derives from
+    the sums against the same formulas on the host."""
+    import torch
+    from nsol_amd import ops
+    lo = _lo(3)
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([sigma2] * 3))
+    halves = A.lanczos_halves(shape)
+    assert halves is not None
+    half_a, half_b = halves
+    n = int(np.prod(shape))
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    y = torch.rand(n, device="cuda", dtype=td, generator=gen) - 0.3
+    yp = torch.rand(n, device="cuda", dtype=td, generator=gen) - 0.5
+    rho = 0.37
+    rg, ri = (0.0, rho) if ident else (rho, 0.0)
+    w = (1.0, 1.0, 1.0)
+    for step, prev in ((0, None), (3, yp)):
+        lb = ops.LanczosBoard(y, 8, rg, ri)
+        nb2 = ops.dot(y, y)
+        nb2_prev = 1.7 * nb2
+        lb.board[3 * step:3 * step + 1] = nb2
+        if step == 0:
+            lb.init()
+            c = lb.coef.cpu().double().numpy()
+            beta = np.sqrt(nb2)
+            assert np.allclose(c[:3], [rg / beta, ri / beta, 0.0], rtol=1e-6 if td == torch.float32 else 1e-14)
+        else:
+            beta, bprev = np.sqrt(nb2), np.sqrt(nb2_prev)
+            lb.coef[0:3] = torch.tensor([rg / beta, ri / beta, -beta / bprev],
+                                        dtype=td, device="cuda")
+        c1, c0, c2 = (float(v) for v in lb.coef[0:3].cpu())
+        t, q0 = torch.empty_like(y), torch.empty_like(y)
+        assert half_a(y, prev, t, q0, lb, step)
+        t_ref = torch.empty_like(y)
+        sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        assert A.apply_norms(y, t_ref, shape, w, sums) is not None
+        assert torch.equal(t, t_ref)
+        board = lb.board.cpu().numpy()
+        assert board[3 * step + 1] == float(sums[0]) and board[3 * step + 2] == float(sums[1])
+        q0_ref = torch.empty_like(y)
+        ops.tk1_lanczos(y, torch.zeros_like(y), prev, shape, w, c1, 0.0, c0, c2, out=q0_ref)
+        assert torch.equal(q0, q0_ref), (shape, step, ident)
+        # the coefficients of the second half
+        alfa = (board[3 * step + 1] + rg * board[3 * step + 2]) / nb2 + ri
+        ca, cy = (float(v) for v in lb.coef[4:6].cpu())
+        tol = 1e-6 if td == torch.float32 else 1e-14
+        assert abs(ca - 1 / np.sqrt(nb2)) <= tol / np.sqrt(nb2)
+        assert abs(cy + alfa / np.sqrt(nb2)) <= tol * alfa / np.sqrt(nb2)
+        ynew = torch.empty_like(y)
+        assert half_b(t, q0, y, ynew, lb, step)
+        ref = ops.lincomb3(ca, A(t.view(shape)).view(-1), 1.0, q0, cy, y)
+        assert torch.equal(ynew, ref), (shape, step, ident)
+        board = lb.board.cpu().numpy()
+        nn = ops.dot(ynew, ynew)
+        assert abs(board[3 * step + 3] - nn) <= 2e-6 * nn
+        c = lb.coef[0:3].cpu().double().numpy()
+        bn = np.sqrt(board[3 * step + 3])
+        assert np.allclose(c, [rg / bn, ri / bn, -bn / np.sqrt(nb2)], rtol=10 * tol)
+
+
 def test_golden_lsmr_solves_run_through_the_blur_with_the_lanczos_sums(nsol, golden,
                                                                       monkeypatch):
     """The 3-D goldens above are not held by a fallback: in the default form their
@@ -675,18 +745,29 @@ def test_golden_lsmr_solves_run_through_the_blur_with_the_lanczos_sums(nsol, gol
     monkeypatch.setattr(ops, "corr3_wrap_norms", norms)
     monkeypatch.setattr(ops, "tk1_grad_norm", grad_norm)
     monkeypatch.setattr(ops, "lincomb_many", lincomb_many)
-    for use in (True, False):
+    for in_blur, use in ((True, True), (False, True), (False, False)):
+        # in_blur: both halves of a step inside the blur (nsol_corr3_wrap_lanczos_*:
+        # the default); else blur + blur + nsol_tk1_lanczos_*, the sums from the blur
+        # (use) or from nsol_tk1_grad_norm_*
+        monkeypatch.setattr(lsmr_mod, "USE_BLUR_LANCZOS", in_blur)
         monkeypatch.setattr(lsmr_mod, "USE_BLUR_NORMS", use)
         for dtype, tol in ((np.float64, 1e-9), (np.float32, F32_TOL)):
             for key in calls:
                 calls[key] = 0
+            lsmr_mod.LAST_FORM[0] = None
             s = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y,
                                       dimension=3, alpha=0.05, rho=0.5, iterations=6,
                                       iter_max=8, x_scale=float(y.max()), dtype=dtype)
             s.run()
-            assert rel_l2(s.get_x(), g["admm_lsmr_3d"]) < tol
+            assert rel_l2(s.get_x(), g["admm_lsmr_3d"],
+                          "in_blur %d norms %d %s" % (in_blur, use,
+                                                      np.dtype(dtype).name)) < tol
             assert calls["clipped"] == 6
-            if use:
+            if in_blur:
+                assert lsmr_mod.LAST_FORM[0] == "lanczos-in-blur"
+                assert calls["norms"] == 0 and calls["grad_norm"] == 0, calls
+            elif use:
+                assert lsmr_mod.LAST_FORM[0] == "lanczos"
                 assert calls["norms"] == 6 * 8 and calls["grad_norm"] == 0, calls
             else:
                 assert calls["norms"] == 0 and calls["grad_norm"] == 6 * 8, calls
