@@ -22,7 +22,7 @@ PY
 )
 echo $CFG > $ROOT/gpurun_out/${TAG}_config
 echo "config $CFG"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_fetch -o p -- python3 $ROOT/bench.py --no-cpu-baseline --pdk $CFG --steps 60 --warmup 6 > $ROOT/gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_fetch -o p -- python3 $ROOT/bench.py --no-cpu-baseline --no-verify --no-config4 --pdk $CFG --steps 60 --warmup 6 > $ROOT/gpurun_out/${TAG}_fetch.log 2>&1
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_write -o p -- python3 $ROOT/bench.py --no-cpu-baseline --pdk $CFG --steps 60 --warmup 6 > $ROOT/gpurun_out/${TAG}_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_write -o p -- python3 $ROOT/bench.py --no-cpu-baseline --no-verify --no-config4 --pdk $CFG --steps 60 --warmup 6 > $ROOT/gpurun_out/${TAG}_write.log 2>&1
 echo "write pass done"
