@@ -61,6 +61,10 @@ using namespace nsol;
 #ifndef PDK_ABLATE
 #define PDK_ABLATE 0
 #endif
+// wave priority while a step's loads (bit 0) / stores (bit 1) are issued (experiment)
+#ifndef PDK_PRIO
+#define PDK_PRIO 0
+#endif
 // cache policy of the 16-byte plane loads (experiments: 1 = sc0, 2 = nt, 16 = sc1)
 #ifndef PDK_LOAD_AUX
 #define PDK_LOAD_AUX 0
@@ -456,6 +460,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   Loads LA, LB;
   auto issue_loads = [&](Loads &L, int sp, uint32_t a) {
     // sp: plane; a: its scalar offset.  The plane above the volume is zero.
+#if PDK_PRIO & 1
+    __builtin_amdgcn_s_setprio(3);
+#endif
     bld<T, VEC>(r_xb, (sp + 1 < nzi) ? v_own : kInvalid, a + szb, L.xn);
     bld<T, VEC>(r_x, v_own, a, L.xv);
     bld<T, VEC>(r_bt, v_own, a, L.btn);
@@ -468,6 +475,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     bld<T, VEC>(r_xb, v_down, a, L.xdown);
     bld<T, VEC>(r_xb, v_up, a, L.xup);
     bld<T, VEC>(r_py, v_up, a, L.pyup);
+#if PDK_PRIO & 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   issue_loads(LA, s_first, adv);
 

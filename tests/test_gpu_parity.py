@@ -1338,6 +1338,20 @@ def test_normal_equations_lsmr_at_the_edge_of_its_guard(nsol, golden, bname, wna
                                     iter_max=iters, dtype=dtype)
         s.run()
         assert L.LAST_NE_COND[0] is not None, "the normal-equations form did not run"
+        # (13 taps, unit spacing, B = gradient: both halves of every step inside the
+        # blur; B = identity keeps its element-wise update unless asked)
+        assert L.LAST_FORM[0] == ("lanczos-in-blur" if bname == "grad" else "lanczos")
+        if bname == "ident" and dtype == np.float32:
+            L.LANCZOS_IDENTITY = True
+            try:
+                s2 = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=B, B_adj=Ba, b=y, x0=y,
+                                             alpha=weight, x_scale=float(y.max()),
+                                             iter_max=iters, dtype=dtype)
+                s2.run()
+            finally:
+                L.LANCZOS_IDENTITY = False
+            assert L.LAST_FORM[0] == "lanczos-in-blur"
+            assert rel_l2(s2.get_x(), ref, "identity through the blur") < tol
         assert rel_l2(s.get_x(), ref,
                       "%s %s %d %s cond %.3g" % (bname, wname, iters,
                                                  np.dtype(dtype).name,
