@@ -38,7 +38,9 @@ def main():
     ap.add_argument("--stats", help="rocprofv3 --stats output dir")
     ap.add_argument("--fetch", help="--pmc FETCH_SIZE output dir")
     ap.add_argument("--write", help="--pmc WRITE_SIZE output dir")
-    ap.add_argument("--kernel", default="k_pd_fused")
+    ap.add_argument("--kernel", default="k_pd_fusedk",
+                    help="substring of the timed kernel (the one-iteration k_pd_fused of "
+                         "bench.py's replay must not be picked: it has more dispatches)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--skip-first", type=int, default=1,
                     help="dispatches of --kernel to drop (p = 0 first launch)")
