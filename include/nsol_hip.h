@@ -202,7 +202,8 @@ int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t 
  * q0 equals nsol_tk1_lanczos_* (c_g = 0) and y_new nsol_lincomb3_* of the plain blur bit
  * for bit.  ws: >= 2 doubles per tile of scratch (nsol_hip_reduce_ws_doubles()).
  * Return -2 (nothing launched) where the form does not apply: rows not a multiple of 16
- * bytes, unaligned arrays, fewer than 5 or more than 13 taps, taps not symmetric. */
+ * bytes, unaligned arrays, fewer than 5 or more than 13 (float64: 9) taps, taps not
+ * symmetric. */
 int nsol_corr3_wrap_lanczos_init_f32(double *board, float *coef, double rho_grad,
                                      double rho_ident, void *stream);
 int nsol_corr3_wrap_lanczos_init_f64(double *board, double *coef, double rho_grad,

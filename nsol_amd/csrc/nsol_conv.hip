@@ -711,7 +711,9 @@ int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
 template <typename T>
 bool lanczos_taps(const double *tz_host, const double *ty_host, const double *tx_host,
                   int ntaps, Taps<T> *tz, Taps<T> *ty, Taps<T> *tx) {
-  if ((ntaps & 1) == 0 || ntaps < 5 || ntaps > 13 || !g_blur3_dma || g_blur3_lxb != kDmaLxb)
+  // (13 taps in float, 9 in double: beyond, the first half would spill -- nsol_blur3_dma.hpp)
+  if ((ntaps & 1) == 0 || ntaps < 5 || ntaps > (sizeof(T) == 4 ? 13 : 9) || !g_blur3_dma ||
+      g_blur3_lxb != kDmaLxb)
     return false;
   for (int t = 0; t < kMaxTaps; ++t) {
     tz->w[t] = t < ntaps ? (T)tz_host[t] : T(0);

@@ -648,7 +648,7 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
 @pytest.mark.parametrize("shape,sigma2,dtype", [
     ((40, 48, 64), 4.0, np.float32), ((33, 70, 128), 4.0, np.float32),
     ((64, 64, 64), 1.0, np.float32), ((24, 40, 96), 2.0, np.float32),
-    ((30, 36, 64), 4.0, np.float64), ((20, 20, 32), 1.0, np.float64)])
+    ((30, 36, 64), 1.5, np.float64), ((20, 20, 32), 1.0, np.float64)])
 @pytest.mark.parametrize("ident", [False, True])
 def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype, ident):
     """nsol_corr3_wrap_lanczos_a / _b: both halves of a Lanczos step on A'A + rho B'B
@@ -1340,7 +1340,9 @@ def test_normal_equations_lsmr_at_the_edge_of_its_guard(nsol, golden, bname, wna
         assert L.LAST_NE_COND[0] is not None, "the normal-equations form did not run"
         # (13 taps, unit spacing, B = gradient: both halves of every step inside the
         # blur; B = identity keeps its element-wise update unless asked)
-        assert L.LAST_FORM[0] == ("lanczos-in-blur" if bname == "grad" else "lanczos")
+        # (float64 at 13 taps would spill in the first half: three kernels there)
+        assert L.LAST_FORM[0] == ("lanczos-in-blur" if bname == "grad" and
+                                  dtype == np.float32 else "lanczos")
         if bname == "ident" and dtype == np.float32:
             L.LANCZOS_IDENTITY = True
             try:

@@ -135,4 +135,11 @@ def test_one_pass_blur_instantiations_do_not_spill(tmp_path_factory):
         scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
         hot = [int(p) for n, p in zip(names, scratch)
                if "k_blur3_dmaI%sLi13ELi16E" % t in n]
-        assert len(hot) == 12 and not any(hot), (src, hot)
+        # (plain, epilogue, sums) x (isotropic or not) x (ragged or not) + the two
+        # halves of a Lanczos step x (isotropic or not)
+        # (float: + the two halves of a Lanczos step x (isotropic or not))
+        assert len(hot) == (16 if t[0] == "f" else 12) and not any(hot), (src, hot)
+        # the Lanczos halves at every tap count they are built for (5 .. 13, double 5 .. 9)
+        lz = {n: int(p) for n, p in zip(names, scratch)
+              if re.search(r"k_blur3_dmaI%sLi\d+ELi16ELb[01]ELi[34]ELb0E" % t, n)}
+        assert len(lz) == (5 if t[0] == "f" else 3) * 2 * 2 and not any(lz.values()), (src, lz)
