@@ -224,6 +224,22 @@ class SolutionCoefficients(object):
 # config 4 at 1.4e-7 - 2.9e-7, 4.2 on the weight-0.05 case at 1.3e-6, 16 on a harmless
 # weight of 4).
 USE_NORMAL_EQUATIONS = True
+# Below that guard a float32 solve is not merely slower in the other form -- it is
+# outside the contract in BOTH: the float64 oracle (SciPy's algorithm) against float32
+# vectors on config 4's blur at 32^3 (tools/_probe/ne_guard_sweep.py,
+# profiles/r03_ne_guard_sweep.jsonl), relative weight 0.1 / 0.05 / 0.02 / 0.01, B = gradient:
+#     10 iterations   4e-7 / 6e-7..1e-6 / 3.6e-6 / 3.4e-6..4.0e-6
+#     20 iterations   3e-7 / 2.8e-5     / 2.2e-4 / 6.3e-4        (both forms alike)
+#     32 iterations   3e-7 / 8e-7       / 1.9e-5 / 9e-5
+# Once the process has found the dominant eigenvalues its vectors lose orthogonality and,
+# until it has converged, an iterate depends on the rounding of every step (in float64
+# the same effect is 1e-9, tests/test_gpu_parity.py, ..._at_the_edge_of_its_guard).  So a
+# float32 solve with a weak regulariser and more than PROMOTE_FROM_ITERATIONS iterations
+# runs its LSMR in float64 (twice the bytes: 0.23 -> ~0.5 s at config 4's size) and hands
+# back a float32 result that meets the reference.
+PROMOTE_WEAK_REGULARISERS = True
+PROMOTE_FROM_ITERATIONS = 10
+LAST_PROMOTED = [False]      # (diagnostics)
 NE_MIN_WEIGHT = {4: 0.1 * (1 - 1e-9), 8: 1.0e-2}   # by element size
 NE_MAX_COND = {4: 1.0e3, 8: 1.0e7}
 NE_MAX_ITER = 32
@@ -563,7 +579,8 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None,
-               own_b=True, atb=None, x_bounds=None, b_bot_scale=1.0):
+               own_b=True, atb=None, x_bounds=None, b_bot_scale=1.0,
+               allow_normal=True):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
@@ -579,7 +596,16 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     caller's array is then only read: the normal-equations form folds the factor into a
     coefficient, the bidiagonalisation scales into a copy)."""
     import torch
-    if atol == 0.0 and btol == 0.0 and \
+    if bmode == ops.B_NONE and PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 \
+            and maxiter > PROMOTE_FROM_ITERATIONS:
+        # (no regulariser at all: the same, more so)
+        LAST_PROMOTED[0] = True
+        x64, istop, itn = lsmr_fused(
+            A, A_adj, b_top.double(), None, bmode, shape, w, sa, x_like.double(), maxiter,
+            atol=atol, btol=btol, conlim=conlim, A_axpby=A_axpby, own_b=True,
+            x_bounds=x_bounds)
+        return x64.to(x_like.dtype), istop, itn
+    if atol == 0.0 and btol == 0.0 and allow_normal and \
             normal_equations_ok(bmode, sa, maxiter, x_like):
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
                                     x_like, maxiter, A_axpby=A_axpby, atb=atb,
@@ -587,7 +613,21 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                                     normb2=normb2)
         if x is not None:
             return x, istop, itn
-        # (the condition estimate came out too high: nothing was consumed, go on)
+        # (the weight is below the guard or the condition estimate came out too high:
+        # nothing was consumed)
+        if PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 and \
+                maxiter > PROMOTE_FROM_ITERATIONS:
+            # float32 vectors cannot hold the 1e-5 contract there, in EITHER form
+            # (see PROMOTE_WEAK_REGULARISERS): this solve runs in float64, and as the
+            # bidiagonalisation -- SciPy's own recurrence: in this regime an iterate
+            # depends on the form at the 1e-6 level even in float64
+            LAST_PROMOTED[0] = True
+            x64, istop, itn = lsmr_fused(
+                A, A_adj, b_top.double(), None if b_bot is None else b_bot.double(),
+                bmode, shape, w, sa, x_like.double(), maxiter, atol=atol, btol=btol,
+                conlim=conlim, A_axpby=A_axpby, normb2=None, own_b=True, atb=None,
+                x_bounds=x_bounds, b_bot_scale=b_bot_scale, allow_normal=False)
+            return x64.to(x_like.dtype), istop, itn
     if not own_b:                 # (the caller's b: consumed below, so work in a copy)
         b_top = b_top.clone()
     if b_bot is not None and b_bot_scale != 1.0:
