@@ -1029,8 +1029,9 @@ inline int current_device() {
 // plan is exploring, every REAL launch of the run uses the next candidate and
 // is bracketed by two events that are read back later with hipEventQuery -- no
 // trial launches, no host synchronisation.  After `kRounds` samples per
-// candidate (candidates >12 % behind after the first round are dropped) the
-// fastest one is kept for the life of the process.
+// candidate (candidates >12 % behind after the first round are dropped) and
+// `kFinalRounds` for those within 6 % of the best, the fastest one is kept for
+// the life of the process.
 struct Sample { hipEvent_t e0, e1; int cand; };
 struct Plan {
   std::vector<Config> cand;
@@ -1041,7 +1042,26 @@ struct Plan {
   int chosen = -1;
 };
 constexpr int kRounds = 2;
+// ... and the finalists -- whoever is within 6 % of the best after those -- are sampled
+// up to kFinalRounds times, taking turns: two samples each, minutes apart on a part whose
+// clock drifts, settled 511^3 on plans 14 % apart from run to run
+constexpr int kFinalRounds = 5;
+constexpr float kFinalBand = 1.06f;
 std::map<PlanKey, Plan> g_plans;
+
+// samples candidate i is owed (0: dropped)
+inline int plan_target(const Plan &P, int i, float best) {
+  if (P.dropped[i]) return 0;
+  if (P.done[i] >= kRounds && best > 0.f && P.best_ms[i] > kFinalBand * best) return kRounds;
+  return kFinalRounds;
+}
+inline float plan_best(const Plan &P) {
+  float best = -1.f;
+  for (int i = 0; i < (int)P.cand.size(); ++i)
+    if (!P.dropped[i] && P.done[i] >= 1 && (best < 0.f || P.best_ms[i] < best))
+      best = P.best_ms[i];
+  return best;
+}
 std::mutex g_plans_mutex;
 
 inline void plan_poll(Plan &P, int K) {
@@ -1075,8 +1095,9 @@ inline void plan_poll(Plan &P, int K) {
     for (int i = 0; i < n; ++i)
       if (!P.dropped[i] && P.best_ms[i] > 1.12f * best) P.dropped[i] = 1;
   bool all = true;
+  const float best_now = plan_best(P);
   for (int i = 0; i < n; ++i)
-    if (!P.dropped[i] && P.done[i] < kRounds) all = false;
+    if (P.done[i] < plan_target(P, i, best_now)) all = false;
   if (all) {
     int arg = 0;
     for (int i = 0; i < n; ++i)
@@ -1156,9 +1177,14 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
   // exploring: next candidate that still needs a sample (the first launch of a
   // run reads no dual variable, so it is cheaper than all others: not a sample)
   int pick = -1;
-  for (int r = 1; r <= kRounds && pick < 0 && S.has_p; ++r)
-    for (int i = 0; i < (int)P.cand.size() && pick < 0; ++i)
-      if (!P.dropped[i] && P.issued[i] < r) pick = i;
+  {
+    const float best_now = plan_best(P);
+    for (int r = 1; r <= kFinalRounds && pick < 0 && S.has_p; ++r)
+      for (int i = 0; i < (int)P.cand.size() && pick < 0; ++i) {
+        const int owed = plan_target(P, i, best_now);
+        if (P.issued[i] < (r < owed ? r : owed)) pick = i;
+      }
+  }
   if (pick < 0) {
     // every sample is in flight: run the best one known so far meanwhile
     pick = 0;

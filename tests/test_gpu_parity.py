@@ -2216,7 +2216,7 @@ def test_pd_run_hands_the_result_over_without_a_copy(nsol, iters):
 
 
 def test_online_tuner_settles_and_stays_bit_identical(nsol):
-    """256^3 is large enough for the online footprint tuner: a 240-iteration run
+    """256^3 is large enough for the online footprint tuner: a 600-iteration run
     explores (every launch a different candidate), settles, and must not differ
     in a single bit from the one-iteration kernel; the plan query reports the
     configuration afterwards."""
@@ -2225,8 +2225,8 @@ def test_online_tuner_settles_and_stays_bit_identical(nsol):
     shape = (256, 256, 256)
     flags = ops.PD_REG_TV | ops.PD_DATA_L2
     _lib.set_param("pdk_forget", 1)
-    ref = _run_pd_raw(shape, np.float32, 240, flags, enable2=0, w=(1., 1., 1.))
-    got = _run_pd_raw(shape, np.float32, 240, flags, enable2=1,
+    ref = _run_pd_raw(shape, np.float32, 600, flags, enable2=0, w=(1., 1., 1.))
+    got = _run_pd_raw(shape, np.float32, 600, flags, enable2=1,
                       pdk=dict(pdk_enable=1, pdk_min_kvox=1024), w=(1., 1., 1.))
     for a, b in zip(ref[:3], got[:3]):
         assert torch.equal(a, b)
@@ -2234,7 +2234,7 @@ def test_online_tuner_settles_and_stays_bit_identical(nsol):
     plan = ops.pd_fusedk_plan(ref[0], shape)
     assert plan is not None and plan[0] in (8, 12) and plan[1] >= 1 and plan[2] >= 8
     # a second run uses the settled plan and reproduces the result
-    again = _run_pd_raw(shape, np.float32, 240, flags, enable2=1,
+    again = _run_pd_raw(shape, np.float32, 600, flags, enable2=1,
                         pdk=dict(pdk_enable=1, pdk_min_kvox=1024), w=(1., 1., 1.))
     assert torch.equal(again[0], got[0])
     assert ops.pd_fusedk_tuned(ref[0], (256, 256, 260)) == -1
