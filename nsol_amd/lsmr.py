@@ -249,6 +249,7 @@ USE_BLUR_NORMS = True
 # instead of blur, blur and nsol_tk1_lanczos_*; the step's scalars stay on the device
 USE_BLUR_LANCZOS = True
 LANCZOS_IDENTITY = False
+_LAG = 2                     # steps the host's recurrences trail the enqueued kernels
 LAST_FORM = [None]           # (diagnostics: "lanczos-in-blur" / "lanczos" / None)
 LAST_NE_COND = [None]        # (diagnostics: the estimate of the last run)
 
@@ -429,7 +430,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     co = MinresCoefficients(maxiter + 1, beta1)
     t = torch.zeros_like(x_like)
     slots = torch.zeros(3, dtype=torch.float64, device=x_like.device)
-    fetch = ops.ScalarFetch(x_like.device, 3)
+    fetch = ops.scalar_fetchers(x_like.device, 3, 1)[0]
     istop = 7
     alfa_prev = None
     for itn in range(1, maxiter + 1):
@@ -516,57 +517,78 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
         t = A y_j, |t|^2, |grad y_j|^2, q0 = (rho / beta_j) K'K y_j - (beta_j / beta_{j-1}) y_{j-1}
         y_{j+1} = (1 / beta_j) A t + q0 - (alfa_j / beta_j) y_j, |y_{j+1}|^2
     with the coefficients formed ON THE DEVICE from the sums (lb: ops.LanczosBoard,
-    |g|^2 already on its way to board[0]): the steps are enqueued back to back and the
-    host reads the scalars once, afterwards, for the MINRES recurrences and SciPy's
-    stopping tests (a run that would have stopped early has then computed vectors it
-    does not use).  The guard on the regulariser's weight looks at step 0's sums once
-    two more steps are enqueued -- nobody waits.  Returns (x, istop, itn), (None, -1, 0)
-    when the guard fails, None when the kernels do not apply (nothing but the board's
-    initialisation was enqueued)."""
+    |g|^2 already on its way to board[0]): the steps are enqueued back to back.  The
+    host follows _LAG steps behind: the four sums of step j travel to pinned memory on
+    a side stream once step j is enqueued, and are turned into MINRES' recurrences and
+    SciPy's stopping tests while the GPU runs steps j + 1 .. j + _LAG -- at the end only
+    the last steps' arithmetic (a few tens of microseconds) stands between the last
+    kernel and the assembly of x.  A stop seen that way ends the enqueuing (the vectors
+    already on their way are not used); the guard on the regulariser's weight is step
+    0's first check.  Returns (x, istop, itn), (None, -1, 0) when the guard fails, None
+    when the kernels do not apply (nothing but the board's initialisation was
+    enqueued)."""
     import torch
     half_a, half_b = halves
     lb.init()
     ys = [g]
     t, q0 = torch.empty_like(x_like), torch.empty_like(x_like)
-    fetch = ops.ScalarFetch(x_like.device, 3)
-    look = min(2, maxiter - 1)
+    fetchers = ops.scalar_fetchers(x_like.device, 4, _LAG + 1)
+    state = {"co": None, "betas": None, "istop": 7, "normb2": None, "verdict": None}
+
+    def digest(j, v):
+        """Step j's sums (|y_j|^2, |A y_j|^2, |grad y_j|^2, |y_{j+1}|^2): True = stop."""
+        nb2, tt, gg, nb2n = (float(q) for q in v[:4])
+        if j == 0:
+            if not nb2 > 0:                                 # g = 0: x = 0
+                state["verdict"] = "zero"
+                return True
+            if rho < NE_MIN_WEIGHT[x_like.element_size()] * tt / nb2:
+                state["verdict"] = "weak"                    # regulariser too weak
+                return True
+            state["betas"] = [math.sqrt(nb2)]
+            state["co"] = MinresCoefficients(maxiter + 1, state["betas"][0])
+            state["normb2"] = rhs_norm2()
+        co = state["co"]
+        alfa = (tt + lb.rho_grad * gg) / nb2 + lb.rho_ident
+        beta_next = math.sqrt(nb2n) if nb2n > 0 else 0.0
+        co.step(alfa, beta_next)
+        stop = _scipy_stop(co, state["normb2"])
+        if j + 1 < maxiter:
+            if stop == 0 and (beta_next == 0 or not math.isfinite(beta_next)):
+                stop = 2                                  # Krylov space exhausted
+            if stop:
+                state["istop"] = stop
+                return True
+            state["betas"].append(beta_next)
+        else:
+            state["istop"] = stop or state["istop"]
+        return False
+
+    done, stopped = 0, False
     for j in range(maxiter):
         ynew = torch.empty_like(x_like)
         if not half_a(ys[-1], ys[-2] if j > 0 else None, t, q0, lb, j):
             if j == 0:
                 return None
             raise RuntimeError("nsol_corr3_wrap_lanczos_a stopped applying mid-solve")
-        if j == 0:
-            fetch.start(lb.board[0:3])
         if not half_b(t, q0, ys[-1], ynew, lb, j):
             raise RuntimeError("nsol_corr3_wrap_lanczos_b does not apply")
         ys.append(ynew)
-        if j == look:
-            v0 = fetch.wait()
-            if not float(v0[0]) > 0:                       # g = 0: x = 0
-                return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
-            if rho < NE_MIN_WEIGHT[x_like.element_size()] * float(v0[1]) / float(v0[0]):
-                return None, -1, 0       # regulariser too weak against ||A||^2
-    normb2 = rhs_norm2()
-    board = lb.board.cpu().numpy()
-    nb2, tt, gg = board[0::3], board[1::3], board[2::3]
-    betas = [math.sqrt(nb2[0])]
-    co = MinresCoefficients(maxiter + 1, betas[0])
-    istop = 7
-    for j in range(maxiter):
-        alfa = (tt[j] + lb.rho_grad * gg[j]) / nb2[j] + lb.rho_ident
-        beta_next = math.sqrt(nb2[j + 1]) if nb2[j + 1] > 0 else 0.0
-        co.step(alfa, beta_next)
-        stop = _scipy_stop(co, normb2)
-        if j + 1 < maxiter:
-            if stop == 0 and (beta_next == 0 or not math.isfinite(beta_next)):
-                stop = 2                                  # Krylov space exhausted
-            if stop:
-                istop = stop
+        fetchers[j % (_LAG + 1)].start(lb.board[3 * j:3 * j + 4])
+        if j >= _LAG:
+            stopped = digest(done, fetchers[done % (_LAG + 1)].wait())
+            done += 1
+            if stopped:
                 break
-            betas.append(beta_next)
-        else:
-            istop = stop or istop
+    last = len(ys) - 1                 # steps enqueued
+    while not stopped and done < last:
+        stopped = digest(done, fetchers[done % (_LAG + 1)].wait())
+        done += 1
+    if state["verdict"] == "zero":
+        return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
+    if state["verdict"] == "weak":
+        return None, -1, 0
+    co, betas = state["co"], state["betas"]
     k = co.itn
     LAST_NE_COND[0] = co.gmax / co.gmin if co.gmin > 0 else np.inf
     LAST_FORM[0] = "lanczos-in-blur"
@@ -574,7 +596,7 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
         return None, -1, k
     x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)],
                          bounds=x_bounds)
-    return x, istop, k
+    return x, state["istop"], k
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,

@@ -523,6 +523,18 @@ class ScalarFetch(object):
         return self.host.numpy()
 
 
+_fetchers = {}
+
+
+def scalar_fetchers(device, count, n):
+    """n ScalarFetch objects of `count` doubles each, kept per device and stream (pinned
+    memory and a side stream cost far more to create than to use)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, int(count), int(n))
+    if key not in _fetchers:
+        _fetchers[key] = [ScalarFetch(device, count) for _ in range(n)]
+    return _fetchers[key]
+
+
 _ws8 = {}
 
 
