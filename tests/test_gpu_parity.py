@@ -648,6 +648,7 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
 @pytest.mark.parametrize("shape,sigma2,dtype", [
     ((40, 48, 64), 4.0, np.float32), ((33, 70, 128), 4.0, np.float32),
     ((64, 64, 64), 1.0, np.float32), ((24, 40, 96), 2.0, np.float32),
+    ((130, 200, 264), 4.0, np.float32), ((512, 512, 512), 4.0, np.float32),
     ((30, 36, 64), 1.5, np.float64), ((20, 20, 32), 1.0, np.float64)])
 @pytest.mark.parametrize("ident", [False, True])
 def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype, ident):
