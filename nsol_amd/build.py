@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(CSRC, "libnsol_hip.so")
-SOURCES = ["nsol_blur3_f32.hip", "nsol_blur3_f64.hip", "nsol_conv.hip", "nsol_ops.hip", "nsol_pd.hip", "nsol_pd2.hip", "nsol_pdk.hip", "nsol_pdp.hip",
+SOURCES = ["nsol_blur3_f32.hip", "nsol_blur3_lz_f32.hip", "nsol_blur3_f64.hip", "nsol_blur3_lz_f64.hip", "nsol_conv.hip", "nsol_ops.hip", "nsol_pd.hip", "nsol_pd2.hip", "nsol_pdk.hip", "nsol_pdp.hip",
            "nsol_lsmr.hip", "nsol_lbfgsb.hip", "nsol_sort.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fPIC", "-shared"]

@@ -11,5 +11,4 @@ int blur3_dma_run(const float *x, float *out, int64_t nz, int64_t ny, int64_t nx
                                 result,
                                 part, part_doubles, st);
 }
-NSOL_B3L_DEF(float)
 }  // namespace nsol_blur3

@@ -11,5 +11,4 @@ int blur3_dma_run(const double *x, double *out, int64_t nz, int64_t ny, int64_t 
                                 result,
                                 part, part_doubles, st);
 }
-NSOL_B3L_DEF(double)
 }  // namespace nsol_blur3

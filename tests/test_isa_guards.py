@@ -76,7 +76,9 @@ def _assembly(src, tmp_path_factory):
 @pytest.mark.parametrize("src,min_stores", [("nsol_pdk.hip", 100),
                                             ("nsol_conv.hip", 4),
                                             ("nsol_blur3_f32.hip", 100),
-                                            ("nsol_blur3_f64.hip", 100)])
+                                            ("nsol_blur3_f64.hip", 100),
+                                            ("nsol_blur3_lz_f32.hip", 100),
+                                            ("nsol_blur3_lz_f64.hip", 50)])
 def test_no_store_data_hazard(src, min_stores, tmp_path_factory):
     """Every translation unit that issues 16-byte buffer stores (the headline
     kernel and the one-pass blur, config 4's A / A^T)."""
@@ -106,8 +108,8 @@ def test_no_store_data_hazard(src, min_stores, tmp_path_factory):
 
 def test_every_file_with_16_byte_buffer_stores_is_guarded():
     assert _sources_with_16_byte_buffer_stores() == [
-        "nsol_blur3_f32.hip", "nsol_blur3_f64.hip", "nsol_conv.hip",
-        "nsol_pdk.hip"]
+        "nsol_blur3_f32.hip", "nsol_blur3_f64.hip", "nsol_blur3_lz_f32.hip",
+        "nsol_blur3_lz_f64.hip", "nsol_conv.hip", "nsol_pdk.hip"]
 
 
 def test_headline_instantiations_do_not_spill(tmp_path_factory):
@@ -129,15 +131,17 @@ def test_one_pass_blur_instantiations_do_not_spill(tmp_path_factory):
     # config 4's A / A^T (13 taps, 16 waves: 128 registers per lane) in all its
     # forms -- isotropic or not, with the LSMR epilogue or the Lanczos sums, ragged
     # rows
-    for src, t in (("nsol_blur3_f32.hip", "fLi4E"), ("nsol_blur3_f64.hip", "dLi2E")):
-        text = _assembly(src, tmp_path_factory)
+    for suf, t in (("f32", "fLi4E"), ("f64", "dLi2E")):
+        # (the two halves of a Lanczos step are compiled in a unit of their own)
+        text = _assembly("nsol_blur3_%s.hip" % suf, tmp_path_factory) + \
+            _assembly("nsol_blur3_lz_%s.hip" % suf, tmp_path_factory)
+        src = "nsol_blur3_[lz_]%s.hip" % suf
         names = re.findall(r"\.name:\s+(\S+)", text)
         scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)
         hot = [int(p) for n, p in zip(names, scratch)
                if "k_blur3_dmaI%sLi13ELi16E" % t in n]
-        # (plain, epilogue, sums) x (isotropic or not) x (ragged or not) + the two
-        # halves of a Lanczos step x (isotropic or not)
-        # (float: + the two halves of a Lanczos step x (isotropic or not))
+        # (plain, epilogue, sums) x (isotropic or not) x (ragged or not); float: + the
+        # two halves of a Lanczos step x (isotropic or not)
         assert len(hot) == (16 if t[0] == "f" else 12) and not any(hot), (src, hot)
         # the Lanczos halves at every tap count they are built for (5 .. 13, double 5 .. 9)
         lz = {n: int(p) for n, p in zip(names, scratch)
