@@ -395,6 +395,11 @@ int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t n
  * (any entry point, any shape); -1 for another k.  For tests and tools that
  * must know which kernel a run went through. */
 int nsol_pd_fusedk_launches(int k);
+/* 1 when nsol_pd_run_* sends a run's trailing PAIR of iterations through depth 2 of
+ * k_pd_fusedk (large volume whose depth-3 plan has settled: the depth-2 form then takes
+ * the same workgroup size and tile count without exploring), 0 when through
+ * k_pd_fused2. */
+int nsol_pd_fusedk_tail2(int elem_size, int64_t nz, int64_t ny, int64_t nx);
 /* The settled configuration (waves per workgroup, tiles along x, z-chunk);
  * NSOL_EINVAL while the shape is unknown or still exploring. */
 int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx,

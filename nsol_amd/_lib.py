@@ -107,7 +107,7 @@ PARAM_DEFAULTS = {
     "pd2_zchunk": 0, "pd2_enable": 1, "pd2_variant": 0, "pd2_xcd_map": 1,
     "pdk_enable": 1, "pdk_kmax": 3, "pdk_nw": 0, "pdk_zchunk": 0, "pdk_ntx": 0,
     "pdk_xcd_map": 1, "pdk_verbose": 0, "pdk_autotune": 1, "pdk_pf2": -1,
-    "pdk_split": -1, "pdk_min_kvox": 1024, "pdk_tune_min_mvox": 16,
+    "pdk_split": -1, "pdk_tail2": 1, "pdk_min_kvox": 1024, "pdk_tune_min_mvox": 16,
     "pdp_max_spin": 1 << 21, "pdp_mute_tile": -1,
     "corr_ra": 8, "corr_xv": 1, "corr_blur3_lxb": 16, "corr_blur3_zchunk": 0, "corr_blur3_dma": 1, "corr_blur3_dma_rag": 1, "lb_gram_dma": 1,
 }

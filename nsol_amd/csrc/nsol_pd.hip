@@ -527,6 +527,8 @@ inline int fusedk_call(const double *a, double *b, const double *c, double *d,
                                  k, s, h, t, tl, th, flags, st);
 }
 
+extern "C" int nsol_pd_fusedk_tail2(int elem_size, int64_t nz, int64_t ny, int64_t nx);
+
 template <typename T>
 int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
              int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
@@ -556,7 +558,15 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
         tl3[i] = tau[n + i] * lambda;
       }
       int done = 0;
-      if (left >= 3) {
+      if (left == 2 && nsol_pd_fusedk_tail2((int)sizeof(T), nz, ny, nx)) {
+        // trailing pair of a run on a shape whose depth-3 plan has settled
+        rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
+                         ndim, nz, ny, nx, wx, wy, wz, 2, sig + n, h3, tau + n, tl3,
+                         theta + n, flags, stream);
+        if (rc == 0) done = 2;
+        else if (rc != -2) return rc;
+      }
+      if (!done && left >= 3) {
         rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
                          ndim, nz, ny, nx, wx, wy, wz, 3, sig + n, h3, tau + n, tl3,
                          theta + n, flags, stream);

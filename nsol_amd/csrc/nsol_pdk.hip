@@ -750,6 +750,8 @@ struct Tuning {
   int autotune = 1;   // time the best few model candidates once per problem shape
   int tune_min_mvox = 16;   // ... for volumes of at least this many Mi voxels
   int pf2 = -1;       // -1 = where the registers allow; 0 / 1 force
+  int tail2 = 1;        // a run's trailing pair through depth 2 of this kernel once the
+                        // shape's depth-3 plan has settled (else k_pd_fused2)
   int min_kvox = 1024;  // smaller volumes (Ki voxels) stay with the one-iteration kernel:
                         // cache resident, they want many short workgroups (crossover
                         // measured between 96^3 and 128^3, tools/crossover_pd.py)
@@ -1139,7 +1141,28 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     std::vector<Config> cand = candidates<T, K>(G);
     if (cand.empty()) return -2;
     const bool big = G.n >= ((int64_t)g_tunek.tune_min_mvox << 20);
-    if (g_tunek.autotune && big && cand.size() > 1) {
+    // Depth 2 only ever runs the trailing pair of a run: ONE launch per run, far too
+    // few to explore on.  Where the depth-3 plan of the shape has settled, depth 2
+    // does not explore either: it takes 12-wave workgroups on whole rows where a row
+    // fits one (what 81 exploring launches settle on at 512^3 -- 12 : 1 : 256, 1.02 ms
+    // a pair against 1.19 for k_pd_fused2 and for the depth-3 plan's own tiling,
+    // tools/_probe/tail2_tuned.py), else the model's best tiling with the depth-3
+    // plan's workgroup size and tile count along x.
+    int seeded = -1;
+    if (K == 2 && g_tunek.autotune && big) {
+      auto it3 = g_plans.find(PlanKey{key.device, key.esize, 3, G.nz, G.ny, G.nx});
+      if (it3 != g_plans.end() && it3->second.chosen >= 0) {
+        const Config &c3 = it3->second.cand[it3->second.chosen];
+        for (int i = 0; i < (int)cand.size() && seeded < 0; ++i)
+          if (cand[i].nw == 12 && cand[i].q.ntx == 1) seeded = i;
+        for (int i = 0; i < (int)cand.size() && seeded < 0; ++i)
+          if (cand[i].nw == c3.nw && cand[i].q.ntx == c3.q.ntx) seeded = i;
+      }
+    }
+    if (seeded >= 0) {
+      P.cand.push_back(cand[seeded]);
+      P.chosen = 0;
+    } else if (g_tunek.autotune && big && cand.size() > 1) {
       // per workgroup size: the tilings with up to 8 tiles along x plus the
       // model's best five, each also with a shorter z-chunk (more workgroups in
       // flight).  The model ranks; the measurement decides.
@@ -1265,6 +1288,7 @@ int nsol_hip_set_param_pdk(const char *name, int value) {
   else if (!strcmp(name, "pdk_pf2")) nsol_pdk::g_tunek.pf2 = value;
   else if (!strcmp(name, "pdk_split")) nsol_pdk::g_split = value;
   else if (!strcmp(name, "pdk_min_kvox")) nsol_pdk::g_tunek.min_kvox = value;
+  else if (!strcmp(name, "pdk_tail2")) nsol_pdk::g_tunek.tail2 = value;
   else if (!strcmp(name, "pdk_tune_min_mvox")) nsol_pdk::g_tunek.tune_min_mvox = value;
   else if (!strcmp(name, "pdk_forget")) {
     std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
@@ -1286,6 +1310,18 @@ int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t n
   if (it == nsol_pdk::g_plans.end()) return -1;
   nsol_pdk::plan_poll(it->second, k);
   return it->second.chosen >= 0 ? 1 : 0;
+}
+
+/* 1 when a run's trailing pair of iterations should go through depth 2 of k_pd_fusedk
+ * (the shape's depth-3 plan has settled and the knob is on), else 0 */
+extern "C" int nsol_pd_fusedk_tail2(int elem_size, int64_t nz, int64_t ny, int64_t nx) {
+  if (!nsol_pdk::g_tunek.tail2 || !nsol_pdk::g_tunek.enable || nsol_pdk::g_tunek.kmax < 3 ||
+      nz * ny * nx < ((int64_t)nsol_pdk::g_tunek.tune_min_mvox << 20))
+    return 0;                       /* (measured on volumes the online tuner handles) */
+  std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
+  auto it = nsol_pdk::g_plans.find(
+      nsol_pdk::PlanKey{nsol_pdk::current_device(), elem_size, 3, nz, ny, nx});
+  return it != nsol_pdk::g_plans.end() && it->second.chosen >= 0 ? 1 : 0;
 }
 
 int nsol_pd_fusedk_launches(int k) {
