@@ -1031,12 +1031,12 @@ inline int current_device() {
 // plan is exploring, every REAL launch of the run uses the next candidate and
 // is bracketed by two events that are read back later with hipEventQuery -- no
 // trial launches, no host synchronisation.  After `kRounds` samples per
-// candidate (candidates >12 % behind after the first round are dropped) and
-// `kFinalRounds` for those within 6 % of the best, the fastest one is kept for
-// the life of the process.
+// candidate and `kFinalRounds` for those within 6 % of the best, the finalist
+// with the smallest median is kept for the life of the process.
 struct Sample { hipEvent_t e0, e1; int cand; };
 struct Plan {
   std::vector<Config> cand;
+  std::vector<std::vector<float>> samples;
   std::vector<float> best_ms;
   std::vector<int> issued, done;
   std::vector<char> dropped;
@@ -1074,6 +1074,7 @@ inline void plan_poll(Plan &P, int K) {
     float ms = 0.f;
     if (q == hipSuccess && hipEventElapsedTime(&ms, sm.e0, sm.e1) == hipSuccess) {
       if (P.best_ms[sm.cand] < 0.f || ms < P.best_ms[sm.cand]) P.best_ms[sm.cand] = ms;
+      P.samples[sm.cand].push_back(ms);
       P.done[sm.cand]++;
     } else {
       (void)hipGetLastError();
@@ -1085,25 +1086,25 @@ inline void plan_poll(Plan &P, int K) {
   }
   if (P.chosen >= 0) return;
   const int n = (int)P.cand.size();
-  // drop the stragglers once everybody has one sample
-  bool round1 = true;
-  float best = -1.f;
-  for (int i = 0; i < n; ++i) {
-    if (P.dropped[i]) continue;
-    if (P.done[i] < 1) round1 = false;
-    else if (best < 0.f || P.best_ms[i] < best) best = P.best_ms[i];
-  }
-  if (round1)
-    for (int i = 0; i < n; ++i)
-      if (!P.dropped[i] && P.best_ms[i] > 1.12f * best) P.dropped[i] = 1;
+  // (nobody is dropped on ONE sample: a single slow launch -- the part's clock, another
+  // process -- would bar the best tiling for the life of the process; candidates
+  // outside the band simply stop at kRounds samples)
   bool all = true;
   const float best_now = plan_best(P);
   for (int i = 0; i < n; ++i)
     if (P.done[i] < plan_target(P, i, best_now)) all = false;
   if (all) {
+    // the finalists by the MEDIAN of their samples (one lucky launch must not decide
+    // either); everybody else by the minimum of two
+    auto score = [&](int i) {
+      std::vector<float> v = P.samples[i];
+      if ((int)v.size() < kFinalRounds) return P.best_ms[i] * kFinalBand;
+      std::sort(v.begin(), v.end());
+      return v[v.size() / 2];
+    };
     int arg = 0;
     for (int i = 0; i < n; ++i)
-      if (!P.dropped[i] && (P.dropped[arg] || P.best_ms[i] < P.best_ms[arg])) arg = i;
+      if (!P.dropped[i] && (P.dropped[arg] || score(i) < score(arg))) arg = i;
     P.chosen = arg;
     if (g_tunek.verbose) {
       for (int i = 0; i < n; ++i)
@@ -1183,6 +1184,7 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     }
     const size_t n = P.cand.size();
     P.best_ms.assign(n, -1.f);
+    P.samples.assign(n, std::vector<float>());
     P.issued.assign(n, 0);
     P.done.assign(n, 0);
     P.dropped.assign(n, 0);
