@@ -71,7 +71,11 @@ def profiled_traffic(kernel, size):
     problem size.  Returns (bytes or None, source or None)."""
     import glob
     name = PMC_NAMES.get(kernel)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_admm_pmc.jsonl")))
+    # (the stable name first: tools/install_profiles.sh keeps a copy of the newest
+    # battery's table there, so the citation outlives the renaming of a battery's files)
+    stable = os.path.join(ROOT, "profiles", "latest_admm_pmc.jsonl")
+    files = [stable] if os.path.exists(stable) else \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "*_admm_pmc.jsonl")))
     if size != 512 or name is None or not files:
         return None, None
     fetch = write = None
