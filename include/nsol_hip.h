@@ -485,6 +485,46 @@ int nsol_pd_run_f64(double *xbar0, double *xbar1, double *x, double *x_alt,
                     const double *tau_host, const double *theta_host,
                     int iterations, int p_is_zero, double gamma_huber,
                     int flags, int *final_slot_host, void *stream);
+/* The same run on a 3-D volume whose arrays hold their rows at a PITCH >= nx elements
+ * (a multiple of 16 bytes; planes ny * pitch apart, the components of p nz * ny * pitch
+ * apart): the layout for volumes whose rows are not whole 16-byte vectors (511^3,
+ * 181 x 217 x 181 ...).  Accesses are aligned, a row's partial vector is masked in
+ * registers exactly as in the contiguous ragged form (same bits in the valid elements),
+ * and the padding behind a row's end may hold anything before and after the call (it
+ * is never read as data).  x_alt as for nsol_pd_run_*; the single trailing iteration of a
+ * run goes through nsol_pd_fused_iter_*'s kernel on the same strides.
+ * nsol_pd_fusedk_iter_pitched_*: one launch of depth k = 2 / 3 on that layout;
+ * nsol_pd_fusedk_tail2_pitched: see nsol_pd_fusedk_tail2. */
+int nsol_pd_run_pitched_f32(float *xbar0, float *xbar1, float *x, float *x_alt,
+                            const float *bt, float *p0, float *p1, int ndim, int64_t nz,
+                            int64_t ny, int64_t nx, int64_t pitch, double wx, double wy,
+                            double wz, double lambda, const double *sigma_host,
+                            const double *tau_host, const double *theta_host,
+                            int iterations, int p_is_zero, double gamma_huber, int flags,
+                            int *final_slot_host, void *stream);
+int nsol_pd_run_pitched_f64(double *xbar0, double *xbar1, double *x, double *x_alt,
+                            const double *bt, double *p0, double *p1, int ndim, int64_t nz,
+                            int64_t ny, int64_t nx, int64_t pitch, double wx, double wy,
+                            double wz, double lambda, const double *sigma_host,
+                            const double *tau_host, const double *theta_host,
+                            int iterations, int p_is_zero, double gamma_huber, int flags,
+                            int *final_slot_host, void *stream);
+int nsol_pd_fusedk_iter_pitched_f32(const float *xbar_in, float *xbar_out, const float *x_in,
+                                    float *x_out, const float *bt, const float *p_in,
+                                    float *p_out, int ndim, int64_t nz, int64_t ny,
+                                    int64_t nx, int64_t pitch, double wx, double wy,
+                                    double wz, int k, const double *sigma,
+                                    const double *hden, const double *tau, const double *tl,
+                                    const double *theta, int flags, void *stream);
+int nsol_pd_fusedk_iter_pitched_f64(const double *xbar_in, double *xbar_out,
+                                    const double *x_in, double *x_out, const double *bt,
+                                    const double *p_in, double *p_out, int ndim, int64_t nz,
+                                    int64_t ny, int64_t nx, int64_t pitch, double wx,
+                                    double wy, double wz, int k, const double *sigma,
+                                    const double *hden, const double *tau, const double *tl,
+                                    const double *theta, int flags, void *stream);
+int nsol_pd_fusedk_tail2_pitched(int elem_size, int64_t nz, int64_t ny, int64_t nx,
+                                 int64_t pitch);
 
 /* ---------------------------------------------------------------------- *
  * ADMM outer update, admm_linear_solver.py:202-218, 239-253

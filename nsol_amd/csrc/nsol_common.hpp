@@ -46,6 +46,8 @@ struct Geom {
   int ndim;
   int slabs;    // stencil kernels deal the rows of a plane to the XCDs in slabs
                 // (voxel_at in nsol_stencil.hpp; runtime knob "stencil_slabs")
+  int padded;   // rows are held at a pitch sy > nx (whole 16-byte vectors): the
+                // elements behind a row's end are padding, free to be overwritten
 };
 
 template <typename T>
@@ -57,6 +59,20 @@ inline Geom<T> make_geom(int ndim, int64_t nz, int64_t ny, int64_t nx,
   g.wx = static_cast<T>(wx); g.wy = static_cast<T>(wy); g.wz = static_cast<T>(wz);
   g.ndim = ndim;
   g.slabs = g_stencil_slabs;
+  g.padded = 0;
+  return g;
+}
+
+// The same volume with its rows at a pitch >= nx (elements): strides and the component
+// stride of a gradient field follow the pitch, the extents stay.  pitch <= 0: contiguous.
+template <typename T>
+inline Geom<T> make_geom_pitched(int ndim, int64_t nz, int64_t ny, int64_t nx, int64_t pitch,
+                                 double wx, double wy, double wz) {
+  Geom<T> g = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  if (pitch > nx) {
+    g.sy = pitch; g.sz = ny * pitch; g.n = nz * ny * pitch;
+    g.padded = 1;
+  }
   return g;
 }
 

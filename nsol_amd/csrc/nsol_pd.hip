@@ -432,12 +432,14 @@ int fused_iter_impl(const T *xbar_in, T *xbar_out, T *x, const T *bt,
                     const T *p_in, T *p_out, int ndim, int64_t nz, int64_t ny,
                     int64_t nx, double wx, double wy, double wz, double sigma,
                     double hden, double tau, double tl, double theta, int flags,
-                    void *stream) {
+                    void *stream, int64_t pitch = 0) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (!xbar_in || !xbar_out || !x || !bt || !p_out || xbar_in == xbar_out ||
       p_in == p_out)
     return NSOL_EINVAL;
-  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  // (rows at a pitch: only the strides change -- the kernel below indexes rows and
+  // planes by G.sy / G.sz and a gradient field's components by G.n)
+  const Geom<T> G = make_geom_pitched<T>(ndim, nz, ny, nx, pitch, wx, wy, wz);
   const PdScalars<T> S =
       make_scalars<T>(sigma, hden, tau, tl, theta, flags, p_in != nullptr);
   hipStream_t st = as_stream(stream);
@@ -445,6 +447,7 @@ int fused_iter_impl(const T *xbar_in, T *xbar_out, T *x, const T *bt,
   const bool vec_ok = (nx % VW == 0) && aligned16(xbar_in) && aligned16(xbar_out) &&
                       aligned16(x) && aligned16(bt) && aligned16(p_out) &&
                       (!p_in || aligned16(p_in)) && ((nz * ny * nx) % VW == 0);
+  if (G.padded && !(g_tune.rag && nx >= 2 * VW) && !vec_ok) return NSOL_EINVAL;
   if (vec_ok) {
     if (nx / VW >= kWave)
       return launch_fused_ry<T, VW, 64>(xbar_in, xbar_out, x, bt, p_in, p_out, G, S, st);
@@ -529,14 +532,50 @@ inline int fusedk_call(const double *a, double *b, const double *c, double *d,
 
 extern "C" int nsol_pd_fusedk_tail2(int elem_size, int64_t nz, int64_t ny, int64_t nx);
 
+extern "C" int nsol_pd_fusedk_tail2_pitched(int elem_size, int64_t nz, int64_t ny, int64_t nx,
+                                            int64_t pitch);
+extern "C" int nsol_pd_fusedk_iter_pitched_f32(
+    const float *, float *, const float *, float *, const float *, const float *, float *, int,
+    int64_t, int64_t, int64_t, int64_t, double, double, double, int, const double *,
+    const double *, const double *, const double *, const double *, int, void *);
+extern "C" int nsol_pd_fusedk_iter_pitched_f64(
+    const double *, double *, const double *, double *, const double *, const double *,
+    double *, int, int64_t, int64_t, int64_t, int64_t, double, double, double, int,
+    const double *, const double *, const double *, const double *, const double *, int,
+    void *);
+inline int fusedk_pitched(const float *a, float *b, const float *c, float *d, const float *e,
+                          const float *f, float *g, int ndim, int64_t nz, int64_t ny,
+                          int64_t nx, int64_t pitch, double wx, double wy, double wz, int k,
+                          const double *s, const double *h, const double *t, const double *tl,
+                          const double *th, int flags, void *st) {
+  return nsol_pd_fusedk_iter_pitched_f32(a, b, c, d, e, f, g, ndim, nz, ny, nx, pitch, wx, wy,
+                                         wz, k, s, h, t, tl, th, flags, st);
+}
+inline int fusedk_pitched(const double *a, double *b, const double *c, double *d,
+                          const double *e, const double *f, double *g, int ndim, int64_t nz,
+                          int64_t ny, int64_t nx, int64_t pitch, double wx, double wy,
+                          double wz, int k, const double *s, const double *h, const double *t,
+                          const double *tl, const double *th, int flags, void *st) {
+  return nsol_pd_fusedk_iter_pitched_f64(a, b, c, d, e, f, g, ndim, nz, ny, nx, pitch, wx, wy,
+                                         wz, k, s, h, t, tl, th, flags, st);
+}
+
+// pitch > nx: every array holds its rows at that pitch (elements; whole 16-byte vectors),
+// planes ny * pitch apart, the components of p nz * ny * pitch apart -- the layout
+// nsol_amd's solver keeps volumes in whose rows are not whole vectors: aligned accesses,
+// the row's partial vector masked in registers, the padding free to hold anything.
 template <typename T>
 int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
              int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
              double wz, double lambda, const double *sig, const double *tau,
              const double *theta, int iterations, int p_is_zero,
-             double gamma_huber, int flags, int *final_slot, void *stream) {
+             double gamma_huber, int flags, int *final_slot, void *stream,
+             int64_t pitch = 0) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (iterations < 0 || !sig || !tau || !theta || !x) return NSOL_EINVAL;
+  const bool pitched = pitch > nx;
+  if (pitch > 0 && (pitch < nx || ndim != 3 || pitch % (16 / (int64_t)sizeof(T)) != 0))
+    return NSOL_EINVAL;
   const bool may_swap = (flags & NSOL_PD_RUN_X_MAY_SWAP) != 0 && final_slot != nullptr;
   flags &= ~NSOL_PD_RUN_X_MAY_SWAP;
   T *xb[2] = {xbar0, xbar1};
@@ -558,7 +597,25 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
         tl3[i] = tau[n + i] * lambda;
       }
       int done = 0;
-      if (left == 2 && nsol_pd_fusedk_tail2((int)sizeof(T), nz, ny, nx)) {
+      if (pitched) {
+        // rows at a pitch: depth 3, then depth 2 of k_pd_fusedk (k_pd_fused2 wants
+        // contiguous whole rows), then one iteration at a time
+        for (int depth = left >= 3 ? 3 : 2; depth >= 2 && !done; --depth) {
+          rc = fusedk_pitched(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
+                              ndim, nz, ny, nx, pitch, wx, wy, wz, depth, sig + n, h3,
+                              tau + n, tl3, theta + n, flags, stream);
+          if (rc == 0) done = depth;
+          else if (rc != -2) return rc;
+        }
+        if (done) {
+          n += done;
+          slot ^= 1;
+          T *t = xcur; xcur = xoth; xoth = t;
+          continue;
+        }
+        rc = -2;
+      }
+      if (!pitched && left == 2 && nsol_pd_fusedk_tail2((int)sizeof(T), nz, ny, nx)) {
         // trailing pair of a run on a shape whose depth-3 plan has settled
         rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
                          ndim, nz, ny, nx, wx, wy, wz, 2, sig + n, h3, tau + n, tl3,
@@ -566,21 +623,21 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
         if (rc == 0) done = 2;
         else if (rc != -2) return rc;
       }
-      if (!done && left >= 3) {
+      if (!pitched && !done && left >= 3) {
         rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
                          ndim, nz, ny, nx, wx, wy, wz, 3, sig + n, h3, tau + n, tl3,
                          theta + n, flags, stream);
         if (rc == 0) done = 3;
         else if (rc != -2) return rc;
       }
-      if (!done) {
+      if (!pitched && !done) {
         rc = fused2_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
                          ndim, nz, ny, nx, wx, wy, wz, sig + n, h3, tau + n, tl3,
                          theta + n, flags, stream);
         if (rc == 0) done = 2;
         else if (rc != -2) return rc;
       }
-      if (!done) {   // e.g. rows too short for the full-row footprints
+      if (!pitched && !done) {   // e.g. rows too short for the full-row footprints
         rc = fusedk_call(xb[slot], xb[slot ^ 1], xcur, xoth, bt, pin, pp[slot ^ 1],
                          ndim, nz, ny, nx, wx, wy, wz, 2, sig + n, h3, tau + n, tl3,
                          theta + n, flags, stream);
@@ -595,7 +652,7 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
       }
     }
     const double hden = huber ? 1.0 + sig[n] * gamma_huber : 1.0;
-    if (g_tune.force_two_pass) {
+    if (g_tune.force_two_pass && !pitched) {
       rc = dual_step_impl<T>(xb[slot], pin, pp[slot ^ 1], ndim, nz, ny, nx, wx, wy,
                              wz, sig[n], hden, stream);
       if (rc) return rc;
@@ -605,14 +662,15 @@ int run_impl(T *xbar0, T *xbar1, T *x, T *x_alt, const T *bt, T *p0, T *p1,
     } else {
       rc = fused_iter_impl<T>(xb[slot], xb[slot ^ 1], xcur, bt, pin, pp[slot ^ 1],
                               ndim, nz, ny, nx, wx, wy, wz, sig[n], hden, tau[n],
-                              tau[n] * lambda, theta[n], flags, stream);
+                              tau[n] * lambda, theta[n], flags, stream, pitch);
     }
     if (rc) return rc;
     n += 1;
     slot ^= 1;
   }
   if (xcur != x && !may_swap) {
-    hipError_t e = hipMemcpyAsync(x, xcur, sizeof(T) * (size_t)(nz * ny * nx),
+    hipError_t e = hipMemcpyAsync(x, xcur,
+                                  sizeof(T) * (size_t)(nz * ny * (pitched ? pitch : nx)),
                                   hipMemcpyDeviceToDevice, as_stream(stream));
     if (e != hipSuccess) return (int)e;
   }
@@ -677,5 +735,20 @@ int nsol_hip_set_param(const char *name, int value) {
 
 NSOL_PD_DEF(float, f32)
 NSOL_PD_DEF(double, f64)
+
+#define NSOL_PD_PITCHED(T, SUF)                                                   \
+  int nsol_pd_run_pitched_##SUF(T *xb0, T *xb1, T *x, T *x_alt, const T *bt, T *p0, \
+                                T *p1, int ndim, int64_t nz, int64_t ny, int64_t nx, \
+                                int64_t pitch, double wx, double wy, double wz,    \
+                                double lambda, const double *sg, const double *ta, \
+                                const double *th, int iters, int p_is_zero,        \
+                                double gh, int flags, int *final_slot, void *s) {  \
+    return run_impl<T>(xb0, xb1, x, x_alt, bt, p0, p1, ndim, nz, ny, nx, wx, wy,   \
+                       wz, lambda, sg, ta, th, iters, p_is_zero, gh, flags,        \
+                       final_slot, s, pitch);                                      \
+  }
+NSOL_PD_PITCHED(float, f32)
+NSOL_PD_PITCHED(double, f64)
+#undef NSOL_PD_PITCHED
 
 }  // extern "C"

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   };
   auto store_vec = [&](rsrc_t r, uint32_t vo, const T (&v)[VEC]) {
     if constexpr (RAG) {
-      if (nval < VEC) {
+      // (rows held at a pitch: what sticks out of the row is padding -- whole store)
+      if (nval < VEC && !G.padded) {
         bst_part<T, VEC>(r, vo, v, nval);
         return;
       }
@@ -1017,9 +1018,10 @@ std::vector<Config> candidates(const Geom<T> &G) {
 struct PlanKey {
   int device, esize, k;
   int64_t nz, ny, nx;
+  int64_t pitch = 0;     // row pitch of a padded layout (0: contiguous rows)
   bool operator<(const PlanKey &o) const {
-    return std::tie(device, esize, k, nz, ny, nx) <
-           std::tie(o.device, o.esize, o.k, o.nz, o.ny, o.nx);
+    return std::tie(device, esize, k, nz, ny, nx, pitch) <
+           std::tie(o.device, o.esize, o.k, o.nz, o.ny, o.nx, o.pitch);
   }
 };
 inline int current_device() {
@@ -1134,7 +1136,8 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     if (cand.empty()) return -2;
     return NSOL_GO(cand[0]);
   }
-  const PlanKey key{current_device(), (int)sizeof(T), K, G.nz, G.ny, G.nx};
+  const PlanKey key{current_device(), (int)sizeof(T), K, G.nz, G.ny, G.nx,
+                    G.padded ? G.sy : 0};
   std::lock_guard<std::mutex> lock(g_plans_mutex);
   auto it = g_plans.find(key);
   if (it == g_plans.end()) {
@@ -1151,7 +1154,7 @@ int fusedk_k(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt
     // plan's workgroup size and tile count along x.
     int seeded = -1;
     if (K == 2 && g_tunek.autotune && big) {
-      auto it3 = g_plans.find(PlanKey{key.device, key.esize, 3, G.nz, G.ny, G.nx});
+      auto it3 = g_plans.find(PlanKey{key.device, key.esize, 3, G.nz, G.ny, G.nx, key.pitch});
       if (it3 != g_plans.end() && it3->second.chosen >= 0) {
         const Config &c3 = it3->second.cand[it3->second.chosen];
         for (int i = 0; i < (int)cand.size() && seeded < 0; ++i)
@@ -1247,13 +1250,15 @@ int fusedk_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T 
                 const T *p_in, T *p_out, int ndim, int64_t nz, int64_t ny,
                 int64_t nx, double wx, double wy, double wz, int k,
                 const double *sigma, const double *hden, const double *tau,
-                const double *tl, const double *theta, int flags, void *stream) {
+                const double *tl, const double *theta, int flags, void *stream,
+                int64_t pitch = 0) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
   if (!xbar_in || !xbar_out || !x_in || !x_out || !bt || !p_out || !sigma ||
       !hden || !tau || !tl || !theta || xbar_in == xbar_out || p_in == p_out ||
       x_in == x_out || k < 2 || k > 3)
     return NSOL_EINVAL;
   constexpr int VW = 16 / sizeof(T);
+  if (pitch > 0 && (pitch < nx || pitch % VW != 0)) return NSOL_EINVAL;
   // (rows that are not a multiple of 16 bytes take the RAG instantiation: their
   // accesses are 4-byte aligned anyway, so only the element size matters then)
   const bool rag = nx % VW != 0;
@@ -1264,7 +1269,7 @@ int fusedk_impl(const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T 
                 !al16(bt) || !al16(p_out) || (p_in && !al16(p_in)) ||
                 (nz * ny * nx) % VW != 0)))
     return -2;
-  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  const Geom<T> G = make_geom_pitched<T>(ndim, nz, ny, nx, pitch, wx, wy, wz);
   hipStream_t st = as_stream(stream);
   if (k == 2)
     return fusedk_k<T, 2>(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, G, sigma,
@@ -1316,13 +1321,20 @@ int nsol_pd_fusedk_tuned(int elem_size, int k, int64_t nz, int64_t ny, int64_t n
 
 /* 1 when a run's trailing pair of iterations should go through depth 2 of k_pd_fusedk
  * (the shape's depth-3 plan has settled and the knob is on), else 0 */
+extern "C" int nsol_pd_fusedk_tail2_pitched(int elem_size, int64_t nz, int64_t ny, int64_t nx,
+                                            int64_t pitch);
 extern "C" int nsol_pd_fusedk_tail2(int elem_size, int64_t nz, int64_t ny, int64_t nx) {
+  return nsol_pd_fusedk_tail2_pitched(elem_size, nz, ny, nx, 0);
+}
+extern "C" int nsol_pd_fusedk_tail2_pitched(int elem_size, int64_t nz, int64_t ny, int64_t nx,
+                                            int64_t pitch) {
   if (!nsol_pdk::g_tunek.tail2 || !nsol_pdk::g_tunek.enable || nsol_pdk::g_tunek.kmax < 3 ||
       nz * ny * nx < ((int64_t)nsol_pdk::g_tunek.tune_min_mvox << 20))
     return 0;                       /* (measured on volumes the online tuner handles) */
   std::lock_guard<std::mutex> lock(nsol_pdk::g_plans_mutex);
   auto it = nsol_pdk::g_plans.find(
-      nsol_pdk::PlanKey{nsol_pdk::current_device(), elem_size, 3, nz, ny, nx});
+      nsol_pdk::PlanKey{nsol_pdk::current_device(), elem_size, 3, nz, ny, nx,
+                        pitch > nx ? pitch : 0});
   return it != nsol_pdk::g_plans.end() && it->second.chosen >= 0 ? 1 : 0;
 }
 
@@ -1343,6 +1355,21 @@ int nsol_pd_fusedk_plan(int elem_size, int k, int64_t nz, int64_t ny, int64_t nx
   if (zchunk) *zchunk = c.zchunk;
   return 0;
 }
+
+#define NSOL_PDK_PITCHED(T, SUF)                                                       \
+  int nsol_pd_fusedk_iter_pitched_##SUF(                                               \
+      const T *xbar_in, T *xbar_out, const T *x_in, T *x_out, const T *bt, const T *p_in, \
+      T *p_out, int ndim, int64_t nz, int64_t ny, int64_t nx, int64_t pitch, double wx, \
+      double wy, double wz, int k, const double *sigma, const double *hden,            \
+      const double *tau, const double *tl, const double *theta, int flags,             \
+      void *stream) {                                                                  \
+    return nsol_pdk::fusedk_impl<T>(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out,   \
+                                    ndim, nz, ny, nx, wx, wy, wz, k, sigma, hden, tau, \
+                                    tl, theta, flags, stream, pitch);                  \
+  }
+NSOL_PDK_PITCHED(float, f32)
+NSOL_PDK_PITCHED(double, f64)
+#undef NSOL_PDK_PITCHED
 
 int nsol_pd_fusedk_iter_f32(const float *xbar_in, float *xbar_out, const float *x_in,
                             float *x_out, const float *bt, const float *p_in,

@@ -841,10 +841,38 @@ def persist_pays(shape, iterations):
 PD_RUN_X_MAY_SWAP = 0x100
 
 
+def row_pitch(shape, like):
+    """Elements between the starts of consecutive rows of a padded 3-D layout: the row
+    length rounded up to whole 16-byte vectors (0 where the rows are whole already, or
+    the volume is not 3-D)."""
+    if len(tuple(shape)) != 3:
+        return 0
+    vec = 16 // like.element_size()
+    nx = int(shape[2])
+    return 0 if nx % vec == 0 else (nx + vec - 1) // vec * vec
+
+
+def to_pitched(t, shape, pitch, comps=1, fill=0.0):
+    """A flat (comps x volume) tensor re-laid with its rows at `pitch` (padding = fill)."""
+    nz, ny, nx = (int(v) for v in shape)
+    out = torch.full((comps * nz * ny * pitch,), fill, dtype=t.dtype, device=t.device)
+    out.view(comps * nz, ny, pitch)[:, :, :nx].copy_(t.view(comps * nz, ny, nx))
+    return out
+
+
+def from_pitched(t, shape, pitch, comps=1):
+    """The contiguous tensor back out of a pitched one."""
+    nz, ny, nx = (int(v) for v in shape)
+    return t.view(comps * nz, ny, pitch)[:, :, :nx].contiguous().view(-1)
+
+
 def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
-           p_is_zero, gamma_huber, flags, x_alt=None, swap_ok=False):
+           p_is_zero, gamma_huber, flags, x_alt=None, swap_ok=False, pitch=0):
     """Enqueue len(sigma) iterations; returns the slot (0/1) of xbar/p that
     holds the final state.  x holds the final primal iterate.
+
+    pitch > 0: every array is held with its rows at that pitch (row_pitch /
+    to_pitched; nsol_pd_run_pitched_*).
 
     swap_ok: x and x_alt are whole tensors nobody else aliases -- when the
     multi-iteration kernels leave the final iterate in x_alt, the two tensors
@@ -856,6 +884,21 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
         # an earlier persistent run may feed this one: its verdict first (the
         # device is drained here; runs of cache-resident volumes are ~1 ms)
         settle_persist_runs()
+    if pitch:
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        slot = ctypes.c_int(0)
+        _lib.check(_fn("pd_run_pitched", x)(
+            _p(xbar0), _p(xbar1), _p(x), _p(x_alt), _p(bt), _p(p0), _p(p1), ndim,
+            nz, ny, nx, int(pitch), w[0], w[1], w[2], float(lmbda), sigma.ctypes.data,
+            tau.ctypes.data, theta.ctypes.data, int(sigma.size), int(bool(p_is_zero)),
+            float(gamma_huber),
+            int(flags) | (PD_RUN_X_MAY_SWAP if swap_ok and x_alt is not None else 0),
+            ctypes.addressof(slot), stream_ptr()), "nsol_pd_run_pitched")
+        if slot.value & 2:
+            x.data, x_alt.data = x_alt.data, x.data
+        return int(slot.value) & 1
     if PD_PERSIST and persist_pays(shape, np.size(sigma)):
         # the result goes to the other half of the ping-pong arrays (and to the
         # x scratch volume): the inputs stay as they are until the run's error

@@ -2296,6 +2296,76 @@ def test_full_size_512_properties(nsol):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("shape,dtype", [
+    ((20, 30, 258), np.float32), ((17, 9, 515), np.float32), ((9, 70, 261), np.float32),
+    ((12, 33, 771), np.float32), ((120, 250, 1021), np.float32), ((257, 255, 254), np.float32),
+    ((21, 13, 131), np.float64), ((10, 37, 257), np.float64), ((64, 150, 513), np.float64)])
+@pytest.mark.parametrize("iters", [1, 2, 3, 8])
+def test_rows_at_a_pitch_give_the_contiguous_result_bit_for_bit(nsol, shape, dtype, iters):
+    """nsol_pd_run_pitched_*: a volume whose rows are not whole 16-byte vectors, held
+    with its rows at a pitch of whole vectors (aligned accesses, the row's partial
+    vector masked in registers, garbage allowed in the padding), against the same run
+    on the contiguous arrays -- all three state arrays, every flag combination, runs
+    that end on a triple, a pair and a single iteration."""
+    import torch
+    from nsol_amd import ops, _lib
+    from nsol_amd.primal_dual_solver import step_schedule
+    n = int(np.prod(shape))
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    sig, ta, th = step_schedule("ALG2", 12.0, 1 / 0.05, iters)
+    _lib.set_param("pdk_min_kvox", 0)
+    pitch = ops.row_pitch(shape, torch.empty(1, dtype=td))
+    assert pitch > shape[2] and pitch % (16 // np.dtype(dtype).itemsize) == 0
+    for flags in (ops.PD_REG_HUBER | ops.PD_DATA_L1, ops.PD_REG_TV | ops.PD_DATA_L2):
+        w = (1.0, 1.0, 1.0) if flags & ops.PD_REG_HUBER else (1.0, 0.5, 2.0)
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        bt = torch.rand(n, device="cuda", dtype=td, generator=gen)
+        p0 = torch.rand(3 * n, device="cuda", dtype=td, generator=gen) - 0.5
+        # contiguous
+        x, xa = bt.clone(), torch.empty_like(bt)
+        xb = [bt.clone(), torch.empty_like(bt)]
+        p = [p0.clone(), torch.empty_like(p0)]
+        slot = ops.pd_run(xb[0], xb[1], x, bt, p[0], p[1], shape, w, 20.0, sig, ta, th,
+                          False, 0.05, flags, x_alt=xa, swap_ok=True)
+        ref = (x, xb[slot], p[slot])
+        # at a pitch, with NaNs in the padding of every input
+        nan = float("nan")
+        btq = ops.to_pitched(bt, shape, pitch, fill=nan)
+        xq, xaq = btq.clone(), torch.full_like(btq, nan)
+        xbq = [btq.clone(), torch.full_like(btq, nan)]
+        pq = [ops.to_pitched(p0, shape, pitch, comps=3, fill=nan),
+              torch.full((3 * btq.numel(),), nan, dtype=td, device="cuda")]
+        launches = ops.pd_fusedk_launches(3) + ops.pd_fusedk_launches(2)
+        slot = ops.pd_run(xbq[0], xbq[1], xq, btq, pq[0], pq[1], shape, w, 20.0, sig, ta,
+                          th, False, 0.05, flags, x_alt=xaq, swap_ok=True, pitch=pitch)
+        if iters >= 2:
+            assert ops.pd_fusedk_launches(3) + ops.pd_fusedk_launches(2) > launches
+        got = (ops.from_pitched(xq, shape, pitch), ops.from_pitched(xbq[slot], shape, pitch),
+               ops.from_pitched(pq[slot], shape, pitch, comps=3))
+        for name, a, b in zip(("x", "xbar", "p"), ref, got):
+            assert torch.equal(a, b), (shape, iters, flags, name)
+
+
+def test_solver_keeps_ragged_volumes_at_a_pitch(nsol):
+    """PrimalDualSolver on a 3-D volume of >= 1 Mi voxels whose rows are not whole
+    vectors: the run goes through nsol_pd_run_pitched_* and returns what the contiguous
+    run returns, bit for bit."""
+    import nsol_amd.primal_dual_solver as pd
+    shape = (70, 131, 127)
+    obs = 60.0 + 25.0 * np.random.default_rng(4).standard_normal(shape)
+    outs = []
+    for use in (True, False):
+        pd.USE_ROW_PITCH = use
+        try:
+            s = _pd_solver(obs, "TV", "L1", 0.6, 23, 16.0, "ALG2", np.float32)
+            s.run()
+        finally:
+            pd.USE_ROW_PITCH = True
+        assert s.get_execution() == "fused"
+        outs.append(s.get_x())
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("plan", [(12, 2, 103), (8, 3, 64), (12, 2, 64)])
 def test_timed_plans_at_512_are_bit_identical(nsol, plan):
     """The configuration bench.py times (the tuner settles on 12 waves x 2 tiles

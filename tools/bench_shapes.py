@@ -40,6 +40,31 @@ for shape in shapes:
                       "ns_per_voxel": round(ms * 1e6 / n, 4),
                       "plan": ops.pd_fusedk_plan(x, shape),
                       "tuned": ops.pd_fusedk_tuned(x, shape)}), flush=True)
+    # the same volume with its rows at a pitch of whole 16-byte vectors (what the solver
+    # does for such shapes: nsol_pd_run_pitched_*)
+    pitch = ops.row_pitch(shape, bt)
+    if pitch:
+        btq = ops.to_pitched(bt, shape, pitch)
+        del x, xa, xb, p
+        xq, xaq = btq.clone(), torch.zeros_like(btq)
+        xbq = [btq.clone(), torch.zeros_like(btq)]
+        pq = [torch.zeros(3 * btq.numel(), device="cuda") for _ in range(2)]
+        for _ in range(12):
+            ops.pd_run(xbq[0], xbq[1], xq, btq, pq[0], pq[1], shape, (1.0, 1.0, 1.0), 1 / 0.03,
+                       sig[:60], ta[:60], th[:60], True, 0.05, flags, x_alt=xaq, pitch=pitch)
+            torch.cuda.synchronize()
+        ts = []
+        for r in range(5):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.pd_run(xbq[0], xbq[1], xq, btq, pq[0], pq[1], shape, (1.0, 1.0, 1.0), 1 / 0.03,
+                       sig, ta, th, r == 0, 0.05, flags, x_alt=xaq, pitch=pitch)
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters)
+        print(json.dumps({"shape": shape, "rows_at_pitch": pitch,
+                          "ms_per_iteration": round(float(np.median(ts[1:])), 4)}), flush=True)
+        del btq, xq, xaq, xbq, pq
+        x = xa = xb = p = None
     del bt, x, xa, xb, p
     torch.cuda.empty_cache()
 # the one-iteration kernel alone on ragged rows (2-D images and trailing
