@@ -109,7 +109,7 @@ PARAM_DEFAULTS = {
     "pdk_xcd_map": 1, "pdk_verbose": 0, "pdk_autotune": 1, "pdk_pf2": -1,
     "pdk_split": -1, "pdk_tail2": 1, "pdk_min_kvox": 1024, "pdk_tune_min_mvox": 16,
     "pdp_max_spin": 1 << 21, "pdp_mute_tile": -1,
-    "corr_ra": 8, "corr_xv": 1, "corr_blur3_lxb": 16, "corr_blur3_zchunk": 0, "corr_blur3_dma": 1, "corr_blur3_dma_rag": 1, "lb_gram_dma": 1,
+    "corr_ra": 8, "corr_xv": 1, "corr_blur3_lxb": 16, "corr_blur3_zchunk": 0, "corr_blur3_dma": 1, "corr_blur3_dma_rag": 1, "lb_gram_dma": 1, "lb_gram_mfma": 1,
 }
 _touched = set()
 

@@ -54,6 +54,7 @@ class ADMMLinearSolver(LinearSolver):
             self._observer.add_x(self.get_x())
 
         x = self._x0_device().clone()
+        self._warm = None
         n = x.numel()
         B = BridgedCallable(self._B, self._dtype)
         desc = trace_operator(self._B, n)
@@ -125,6 +126,8 @@ class ADMMLinearSolver(LinearSolver):
                 self._observer.add_x(self.get_x())
         self._x = x
 
+    _warm = None
+
     def _solve_tikhonov_least_squares(self, x, b_reg, prescaled=None):
         # admm :220-237: data_loss_scale and bounds are NOT forwarded
         tikhonov = tk.TikhonovLinearSolver(
@@ -134,7 +137,13 @@ class ADMMLinearSolver(LinearSolver):
             minimizer=self._minimizer, verbose=self._verbose,
             dtype=self._dtype, _borrow=True)
         tikhonov._prescaled_b_reg = prescaled
+        # (minimizer="L-BFGS-B": cost and gradient at the point the last solve
+        # returned, see tikhonov_linear_solver.REUSE_OBJECTIVE_AT_X0)
+        tikhonov._warm_key = ("admm", id(self), float(self._rho), self._data_loss,
+                              self._minimizer)
+        tikhonov._warm_start = self._warm
         tikhonov.run()
+        self._warm = tikhonov._warm_result
         return tikhonov._x
 
     def _prox_g(self, t, tau, dimension):

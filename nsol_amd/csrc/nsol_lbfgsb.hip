@@ -747,6 +747,273 @@ __global__ __launch_bounds__(kBlock) void k_gram2_final(const double *ws, int nb
   }
 }
 
+// ---- the same pass with the products on the matrix cores ---------------------
+// k_masked_gram_dma is bound by its float64 VALU work and its LDS reads together (per
+// four voxels and ten stored pairs: 480 conversions, 960 FMAs, 120 ds_read_b128; the
+// two do not overlap across the barrier of a 512-voxel tile): 3.3 ms at 512^3 where the
+// bytes take 2.  v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4 x 4 x 4 blocks per
+// instruction (gfx950: 8 ns per instruction and SIMD, 65 TFLOP/s; v_mfma_f64_16x16x4
+// sustains 45 and would pad 20 vectors to 32).  Here the four blocks are four groups of
+// four VOXELS of one pair of vector blocks: lane l supplies element (l & 3) of a vector
+// block at voxel (l >> 2) of a 16-voxel group -- the same register serves as the A
+// operand (row i = l & 3) and as the B operand (column j = l & 3), operand layout
+//   block (l >> 2) & 3, index l & 3, k = l >> 4          (tools/_probe/mfma_f64_4x4_probe.hip)
+// -- so a wave reads NB values per lane and group (one ds_read_b32 / _b64 each, widened
+// and masked ONCE) and issues NB (NB + 1) / 2 MFMAs on them; the result register of lane
+// l is entry (i = l >> 4, j = l & 3) of the pair block for its voxel quarter (l >> 2) & 3.
+// Every wave takes whole groups of every tile (no pair-block owners, no idle lanes);
+// staging, the reduced gradient (RG) and the workspace layout are k_masked_gram_dma's.
+// Products of widened floats are exact in double, so the sums differ from the VALU
+// form only in their (fixed) order.
+template <typename T, int TB, int NB, bool RG>
+__global__ __launch_bounds__(kGram2Threads) void k_masked_gram_mfma(
+    GramPtrs<T> P, int nvec, const int8_t *iw, int64_t n, double *ws,
+    GramRG<T> R = GramRG<T>()) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_raw[];
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int kTile = TB / (int)sizeof(T);                   // voxels per tile
+  constexpr int kQuads = kTile / VEC;                          // 16-byte groups per row
+  // rows (l & 3) of a block on different banks for the element reads: ds_read_b32 banks
+  // are (a / 4) % 32 per 32-lane half (8 voxels x 4 rows), ds_read_b64's (a / 4) % 64
+  constexpr int kPitch = TB + (sizeof(T) == 4 ? 32 : 64);      // bytes between rows
+  constexpr int kMaskBytes = kTile;                            // int8 per voxel
+  constexpr int kRowPieces = TB / 1024;                        // 1 KiB per wave-instruction
+  constexpr int kMaskPieces = (kMaskBytes + 1023) / 1024;
+  constexpr int rows = NB * kGram2B;
+  constexpr int kExtra = RG ? 3 : 0;                           // base vectors of r
+  constexpr int mask_at = (rows + kExtra) * kPitch;
+  constexpr int buf_bytes = mask_at + ((kMaskBytes + 15) & ~15);
+  constexpr int NP = NB * (NB + 1) / 2;                        // pair blocks
+  constexpr int kGroups = kTile / 16;                          // 16-voxel groups per tile
+  constexpr int kRWaves = kTile / kWave;                       // (RG) waves that form r
+  static_assert(kGroups % kGram2Waves == 0 && (!RG || (kRWaves >= 1 && kRWaves <= kGram2Waves)), "tile");
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r4 = lane & 3, vox = lane >> 2;
+  double acc[NP], accb[NB];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) acc[p] = 0.0;
+#pragma unroll
+  for (int X = 0; X < NB; ++X) accb[X] = 0.0;
+  // rows beyond nvec (padding of the last block) stay zero in every buffer
+  for (int b = 0; b < kGram2Bufs; ++b)
+    for (int v = nvec; v < rows; ++v)
+      for (int e = tid * 16; e < TB; e += kGram2Threads * 16)
+        *reinterpret_cast<uint4 *>(gram_raw + b * buf_bytes + v * kPitch + e) =
+            make_uint4(0, 0, 0, 0);
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  const int nsrc = nvec + kExtra;                             // staged vectors
+  const int npieces = kRowPieces * nsrc + (iw ? kMaskPieces : 0);
+  const int my_pieces = (npieces - wave + kGram2Waves - 1) / kGram2Waves;   // wave-uniform
+  auto stage = [&](int64_t t, int b) {
+    const int64_t base = t * kTile;
+    unsigned char *dst = gram_raw + b * buf_bytes;
+    for (int k = wave; k < npieces; k += kGram2Waves) {
+      if (k < kRowPieces * nsrc) {
+        const int v = k / kRowPieces, h = k - v * kRowPieces;
+        const int64_t e = base + (int64_t)h * (1024 / (int)sizeof(T)) + (int64_t)lane * VEC;
+        const T *src = v < nvec ? P.p[v] : R.base[v < nvec ? 0 : v - nvec];
+        const int lrow = v < nvec ? v : rows + (v - nvec);
+        if (e < n)                                       // n % VEC == 0 (host check)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(src + e),
+              (__attribute__((address_space(3))) void *)(dst + lrow * kPitch + h * 1024),
+              16, 0, 0);
+      } else {
+        const int h = k - kRowPieces * nsrc;
+        const int64_t e = base + (int64_t)h * 1024 + (int64_t)lane * 16;
+        if (h * 1024 + lane * 16 < kMaskBytes && e < n)   // n % 16 == 0 with a mask
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(iw + e),
+              (__attribute__((address_space(3))) void *)(dst + mask_at + h * 1024),
+              16, 0, 0);
+      }
+    }
+  };
+  auto full = [&](int64_t t) { return (t + 1) * kTile <= n; };
+  auto sync_keep = [&](int newer) {
+    switch (newer) {
+      case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+  };
+  int64_t t = blockIdx.x;
+  const int64_t step = gridDim.x;
+  if (t < ntiles) stage(t, 0);
+  if (t + step < ntiles) stage(t + step, 1);
+  sync_keep((t + step < ntiles && full(t + step)) ? my_pieces : 0);
+  int cur = 0;
+  for (; t < ntiles; t += step) {
+    const int64_t t2 = t + 2 * step;
+    int nxt2 = cur + 2; if (nxt2 >= kGram2Bufs) nxt2 -= kGram2Bufs;
+    if (t2 < ntiles) stage(t2, nxt2);
+    const unsigned char *bufp = gram_raw + cur * buf_bytes;
+    const int64_t base = t * kTile;
+    int stored = 0;                                    // (wave-uniform) stores of r issued
+    if constexpr (RG) {
+      // one element of r per lane (k_wcomb's sum, same order: the rows beyond nvec hold
+      // zeros and carry zero coefficients), by the last kRWaves waves on top of their
+      // groups -- element-wise so that half the waves share the work (two waves with a
+      // 16-byte group per lane held the other fourteen at the barrier)
+      constexpr int first = (kGram2Waves - kRWaves) * kWave;
+      const int e = tid - first;                                    // voxel of the tile
+      if (wave >= kGram2Waves - kRWaves && base + (wave * kWave - first) < n) stored = 1;
+      if (e >= 0 && base + e < n) {
+        const unsigned char *col = bufp + e * (int)sizeof(T);
+        T accv = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          accv += R.bcoef[k] * *reinterpret_cast<const T *>(col + (rows + k) * kPitch);
+#pragma unroll
+        for (int k = 0; k < rows; ++k)
+          accv += R.wcoef[k] * *reinterpret_cast<const T *>(col + k * kPitch);
+        if (iw && (int8_t)bufp[mask_at + e] > 0) accv = T(0);
+        R.out[base + e] = accv;
+      }
+    }
+    {
+      constexpr int G = kGroups / kGram2Waves;             // groups of this wave per tile
+      const unsigned char *mine = bufp + r4 * kPitch + (wave * 16 + vox) * (int)sizeof(T);
+      const unsigned char *mk = bufp + mask_at + wave * 16 + vox;
+      // every LDS read of the tile first (one wait), then the products
+      T vals[G][NB], braw[G][3];
+      int8_t mb[G];
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        constexpr int kGroupStride = kGram2Waves * 16;     // voxels between this wave's groups
+#pragma unroll
+        for (int X = 0; X < NB; ++X)
+          vals[gi][X] = *reinterpret_cast<const T *>(mine + X * kGram2B * kPitch +
+                                                     gi * kGroupStride * (int)sizeof(T));
+        if constexpr (RG) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            braw[gi][k] = *reinterpret_cast<const T *>(
+                bufp + (rows + k) * kPitch + (wave * 16 + vox + gi * kGroupStride) * (int)sizeof(T));
+        }
+        mb[gi] = iw ? (int8_t)mk[gi * kGroupStride] : (int8_t)0;
+      }
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        const int g0 = (wave + gi * kGram2Waves) * 16;     // first voxel of the group
+        // (what lies beyond the end of the vectors is stale LDS)
+        const bool keep = (base + g0 + vox < n) & (mb[gi] <= 0);
+        double a[NB];
+#pragma unroll
+        for (int X = 0; X < NB; ++X) a[X] = (double)(keep ? vals[gi][X] : T(0));
+        if constexpr (RG) {
+          T bq = T(0);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bq += R.bcoef[k] * braw[gi][k];
+          // (it must not meet the zeros of the masked side as a NaN)
+          const double bb = (double)(keep ? bq : T(0));
+#pragma unroll
+          for (int X = 0; X < NB; ++X) accb[X] = __builtin_fma(a[X], bb, accb[X]);
+        }
+        int p = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+          for (int bj = bi; bj < NB; ++bj, ++p)
+            acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[bi], a[bj], acc[p], 0, 0, 0);
+      }
+    }
+    sync_keep((t2 < ntiles && full(t2)) ? my_pieces + stored : 0);
+    if (++cur == kGram2Bufs) cur = 0;
+  }
+  // the four voxel quarters of every entry, then the waves, in a fixed order
+  double *red = reinterpret_cast<double *>(gram_raw);   // [waves][NP * 16]
+  constexpr int E = kGram2B * kGram2B;
+  {
+    const int i = lane >> 4, j = lane & 3, quarter = (lane >> 2) & 3;
+    int p = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+      for (int bj = bi; bj < NB; ++bj, ++p) {
+        double x = acc[p];
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        // (RG) the lower triangle of a diagonal block, which nobody reads, carries the
+        // products of the block's vectors with b instead (k_gram2_final's slots)
+        if (quarter == 0 && !(RG && bi == bj && i > j)) red[wave * (NP * E) + p * E + i * kGram2B + j] = x;
+      }
+    if constexpr (RG) {
+      int pd = 0;
+#pragma unroll
+      for (int X = 0; X < NB; ++X) {
+        double x = accb[X];
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        const int slot = lane == 0 ? 1 * kGram2B : (lane == 1 ? 2 * kGram2B
+                                                  : (lane == 2 ? 2 * kGram2B + 1 : 3 * kGram2B));
+        if (lane < 4) red[wave * (NP * E) + pd * E + slot] = x;
+        pd += NB - X;
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < NP * E; o += kGram2Threads) {
+    double sum = 0.0;
+    for (int w = 0; w < kGram2Waves; ++w) sum += red[w * (NP * E) + o];
+    ws[(int64_t)blockIdx.x * kGram2Ent + o] = sum;
+  }
+}
+
+int g_gram_mfma = 1;             // 1: k_masked_gram_mfma in place of k_masked_gram_dma
+
+template <typename T, int TB, int NB, bool RG>
+int masked_gram_mfma_launch(const GramPtrs<T> &P, int nvec, const int8_t *iwhere, int64_t n,
+                            double *result, double *ws, hipStream_t st, const GramRG<T> &R) {
+  constexpr int kTile = TB / (int)sizeof(T);
+  constexpr int kPitch = TB + (sizeof(T) == 4 ? 32 : 64);
+  constexpr size_t lds = (size_t)kGram2Bufs *
+      ((size_t)(NB * kGram2B + (RG ? 3 : 0)) * kPitch + ((kTile + 15) & ~15));
+  static_assert(lds <= 160 * 1024, "three tiles in LDS");
+  static_assert(lds >= (size_t)kGram2Waves * (NB * (NB + 1) / 2) * 16 * sizeof(double), "reduction");
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  int64_t blocks = 256;                              // one 16-wave workgroup per CU
+  if (blocks > kGramBlocks) blocks = kGramBlocks;
+  if (blocks > ntiles) blocks = ntiles;
+  auto kern = k_masked_gram_mfma<T, TB, NB, RG>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGram2Threads), lds, st, P, nvec,
+                     iwhere, n, ws, R);
+  hipLaunchKernelGGL(k_gram2_final, dim3(nvec * (nvec + 1) / 2 + (RG ? nvec : 0)),
+                     dim3(kBlock), 0, st, ws, (int)blocks, nvec, NB, result);
+  return launch_status();
+}
+
+// tile size by the rows to stage (k_masked_gram_dma's rule)
+template <typename T, bool RG>
+int masked_gram_mfma_dispatch(const GramPtrs<T> &P, int nvec, const int8_t *iwhere, int64_t n,
+                              double *result, double *ws, hipStream_t st, const GramRG<T> &R) {
+  const int nb = (nvec + kGram2B - 1) / kGram2B;
+  switch (nb) {
+    case 1: return masked_gram_mfma_launch<T, RG ? 4096 : 8192, 1, RG>(P, nvec, iwhere, n, result, ws, st, R);
+    case 2: return masked_gram_mfma_launch<T, 4096, 2, RG>(P, nvec, iwhere, n, result, ws, st, R);
+    case 3: return masked_gram_mfma_launch<T, RG ? 2048 : 4096, 3, RG>(P, nvec, iwhere, n, result, ws, st, R);
+    case 4: return masked_gram_mfma_launch<T, 2048, 4, RG>(P, nvec, iwhere, n, result, ws, st, R);
+    case 5: return masked_gram_mfma_launch<T, 2048, 5, RG>(P, nvec, iwhere, n, result, ws, st, R);
+    case 6: if constexpr (!RG) return masked_gram_mfma_launch<T, 2048, 6, RG>(P, nvec, iwhere, n, result, ws, st, R);
+  }
+  return -2;
+}
+
 int g_gram_dma = 1;              // 1: k_masked_gram_dma where it applies; 0: k_masked_gram
 
 template <typename T, int TB, bool RG>
@@ -794,11 +1061,19 @@ int masked_gram_dma_launch(const GramPtrs<T> &P, int nvec, const int8_t *iwhere,
     for (int k = 0; k < 3; ++k)
       if (!rg->base[k] || ((uintptr_t)rg->base[k] & 15u)) return -2;
     if (!rg->out || ((uintptr_t)rg->out & 15u)) return -2;
+    if (g_gram_mfma) {
+      const int rc = masked_gram_mfma_dispatch<T, true>(P, nvec, iwhere, n, result, ws, st, *rg);
+      if (rc != -2) return rc;
+    }
     if (rows <= 6) return masked_gram_dma_launch_tb<T, 8192, true>(P, nvec, iwhere, n, result, ws, st, *rg);
     if (rows <= 12) return masked_gram_dma_launch_tb<T, 4096, true>(P, nvec, iwhere, n, result, ws, st, *rg);
     return masked_gram_dma_launch_tb<T, 2048, true>(P, nvec, iwhere, n, result, ws, st, *rg);
   }
   const GramRG<T> none = GramRG<T>();
+  if (g_gram_mfma) {
+    const int rc = masked_gram_mfma_dispatch<T, false>(P, nvec, iwhere, n, result, ws, st, none);
+    if (rc != -2) return rc;
+  }
   if (rows <= 4) return masked_gram_dma_launch_tb<T, 8192, false>(P, nvec, iwhere, n, result, ws, st, none);
   if (rows <= 12) return masked_gram_dma_launch_tb<T, 4096, false>(P, nvec, iwhere, n, result, ws, st, none);
   return masked_gram_dma_launch_tb<T, 2048, false>(P, nvec, iwhere, n, result, ws, st, none);
@@ -1394,10 +1669,11 @@ int nsol_lb_count_free(const int8_t *iwhere, int64_t n, double *result,
 }
 
 extern "C" {
-/* experiment knobs of this file: "lb_gram_dma" */
+/* experiment knobs of this file: "lb_gram_dma", "lb_gram_mfma" */
 int nsol_hip_set_param_lb(const char *name, int value) {
   if (!name) return NSOL_EINVAL;
   if (!strcmp(name, "lb_gram_dma")) g_gram_dma = value;
+  else if (!strcmp(name, "lb_gram_mfma")) g_gram_mfma = value;
   else return NSOL_EINVAL;
   return 0;
 }

@@ -330,12 +330,17 @@ def solve_k(fac, wv, c):
 # Driver
 # ---------------------------------------------------------------------------
 def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
-             factr=1.0e7, pgtol=1.0e-5, maxls=20, maxfun=15000):
+             factr=1.0e7, pgtol=1.0e-5, maxls=20, maxfun=15000, start=None):
     """Minimise f subject to lo <= x <= hi (uniform bounds, +-inf allowed).
 
     fun_and_grad(x) -> (float f, vector g) with backend vectors.  Returns
     (x, info dict).  Follows scipy's iteration accounting: stops after
-    `maxiter` accepted iterations."""
+    `maxiter` accepted iterations.
+
+    start: (f, g) at x0 when the caller already holds them (x0 feasible, so that
+    the clip below returns its values: e.g. the point an earlier call on the same
+    objective returned, with info["fun"] / info["jac"]); the first evaluation
+    is then not repeated (it still counts in nfev, as scipy would report it)."""
     be = backend
     # A backend whose kernels want whole vectors (DeviceBackend.pad_to: 16
     # elements -- 16-byte accesses and one mask byte per element) gets the
@@ -351,18 +356,22 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
         def padded(xp):
             f, g = fun_and_grad(be.head(xp, n_in))
             return f, be.pad(g, n_pad)
+        if start is not None:
+            start = (start[0], be.pad(start[1], n_pad))
         xp, info = minimize(padded, be.pad(x0, n_pad), lo, hi, be,
                             maxiter=maxiter, m=m, factr=factr, pgtol=pgtol,
-                            maxls=maxls, maxfun=maxfun)
+                            maxls=maxls, maxfun=maxfun, start=start)
+        if info.get("jac") is not None:
+            info["jac"] = be.copy(be.head(info["jac"], n_in))
         return be.copy(be.head(xp, n_in)), info
     has_lo, has_hi = np.isfinite(lo), np.isfinite(hi)
     cnstnd = has_lo or has_hi
     boxed = has_lo and has_hi
-    x = be.clip(x0, lo, hi)
+    x = be.clip(x0, lo, hi) if start is None else x0
     cm = CompactMatrix(m)
     ws, wy = [], []                   # stored s_k, y_k (oldest first)
     iwhere = be.init_where(x, lo, hi)
-    f, g = fun_and_grad(x)
+    f, g = fun_and_grad(x) if start is None else start
     nfgv = 1
     it = 0
     nskip = 0
@@ -371,6 +380,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     info = {"task": "START", "nit": 0, "nfev": 1}
     if sbgnrm <= pgtol:
         info["task"] = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL"
+        info["fun"], info["jac"] = f, g
         return x, info
 
     while True:
@@ -558,6 +568,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     info["nit"] = it
     info["nfev"] = nfgv
     info["fun"] = f
+    info["jac"] = g               # (f, g belong to the point returned)
     return x, info
 
 

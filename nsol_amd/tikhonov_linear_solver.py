@@ -37,6 +37,12 @@ USE_DEVICE_LBFGSB = True
 # robust-loss objective with B = gradient: 1/2||Bx||^2 and B_adj(Bx) from one
 # pass over x (nsol_tk1_reg_cost_grad_*); False = grad, dot, grad_adj, lincomb2
 USE_FUSED_TK1_REG = True
+# ADMMLinearSolver with minimizer="L-BFGS-B" minimises the same objective in every
+# outer iteration (the reference's cost and gradient ignore b_reg), each time from the
+# point the last solve returned: True = that point's cost and gradient are handed to
+# the next solve instead of being evaluated again (bit for bit the same values), and
+# its projection onto the bounds (the identity on it) is not repeated
+REUSE_OBJECTIVE_AT_X0 = True
 
 
 # A^T b for the (operator, data) pairs seen last: an outer loop (ADMM, primal-dual
@@ -126,6 +132,8 @@ class TikhonovLinearSolver(LinearSolver):
                 # LSMR starts from zero (SciPy's default): x0 only gives the
                 # shape, so its projection waits until somebody asks for x0
                 self._x0_clip_pending = True
+            elif self._warm_start_applies(x0):
+                pass                # (a point this minimizer returned: inside the bounds)
             else:
                 x0 = self._clip_x0()
 
@@ -371,6 +379,27 @@ class TikhonovLinearSolver(LinearSolver):
             return cost, grad
         return fun_and_grad
 
+    _warm_start = None              # set by the outer solver (see _run_minimize)
+    _warm_result = None
+
+    def _warm_start_applies(self, x0):
+        warm = self._warm_start
+        return REUSE_OBJECTIVE_AT_X0 and warm is not None and \
+            self._minimizer == "L-BFGS-B" and USE_DEVICE_LBFGSB and \
+            is_device_tensor(x0) and warm["x"].data_ptr() == x0.data_ptr() and \
+            warm["x"].numel() == x0.numel() and warm["x"].dtype == x0.dtype and \
+            self._bounds is not None and \
+            warm["bounds"] == (float(self._bounds[0]), float(self._bounds[1])) and \
+            self._warm_key is not None and warm["key"] == self._objective_key()
+
+    # named by the outer solver that builds one solver per iteration around the same
+    # operators, data, weight and loss (its own identity): what _device_objective's
+    # value depends on besides x (b_reg does not enter it: the reference's quirk)
+    _warm_key = None
+
+    def _objective_key(self):
+        return self._warm_key
+
     def _native_gradient(self, n):
         """(shape, inverse spacings) when B / B_adj are nsol_amd's gradient
         and its adjoint on an n-voxel volume; None otherwise."""
@@ -392,10 +421,23 @@ class TikhonovLinearSolver(LinearSolver):
             from . import lbfgsb
             from .lbfgsb_device import DeviceBackend
             lo, hi = self._bounds
+            # An outer solver that minimises the SAME objective again from the point the
+            # last solve returned (ADMMLinearSolver with this minimizer: the reference's
+            # cost ignores b_reg, tikhonov :201-208) hands over that point's f and g:
+            # the first evaluation would recompute them bit for bit
+            start = None
+            if self._warm_start_applies(x0):
+                start = (self._warm_start["f"], self._warm_start["g"])
             x, info = lbfgsb.minimize(self._device_objective(), x0, float(lo),
                                       float(hi), DeviceBackend(),
-                                      maxiter=self._iter_max)
+                                      maxiter=self._iter_max, start=start)
             self._minimize_info = info
+            self._warm_result = None
+            if info.get("jac") is not None:
+                self._warm_result = {"x": x, "f": info["fun"], "g": info["jac"],
+                                     "bounds": (float(lo), float(hi)),
+                                     "key": self._objective_key(),
+                                     "reused": start is not None}
             return x
         A, A_adj, B, B_adj = self._callables()
         b = self._dev(self._b)

@@ -835,6 +835,53 @@ def test_admm_lbfgsb_huber_matches_reference_goldens(nsol, golden, k,
     assert rel_l2(s.get_x(), g["admm_lbfgsb_huber_" + k]) < 1e-8
 
 
+@pytest.mark.parametrize("k,dtype", [("1d", np.float64), ("2d", np.float32),
+                                     ("3d", np.float32), ("3d", np.float64)])
+def test_admm_lbfgsb_hands_the_objective_at_x0_to_the_next_solve(nsol, golden, k,
+                                                                 dtype):
+    """ADMMLinearSolver with minimizer='L-BFGS-B' minimises the same objective in
+    every outer iteration from the point the last solve returned; handing over that
+    point's cost and gradient (tikhonov_linear_solver.REUSE_OBJECTIVE_AT_X0) gives
+    bit for bit the run that evaluates them again, with one evaluation and two
+    projections fewer per outer iteration after the first."""
+    import nsol_amd.admm_linear_solver as admm
+    import nsol_amd.tikhonov_linear_solver as tk
+    from nsol_amd import lbfgsb
+    g, shape, A, Aa, D, Da = _dec_ops(golden, k)
+    y = g["y_" + k]
+    evals = []
+    orig = tk.TikhonovLinearSolver._device_objective
+
+    def counting(self):
+        f = orig(self)
+
+        def fg(x):
+            evals.append(1)
+            return f(x)
+        return fg
+
+    def run(reuse):
+        del evals[:]
+        tk.REUSE_OBJECTIVE_AT_X0 = reuse
+        s = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y,
+                                  dimension=len(shape), alpha=0.05, rho=0.5,
+                                  iterations=4, iter_max=5, minimizer="L-BFGS-B",
+                                  data_loss="huber", x_scale=float(y.max()),
+                                  dtype=dtype)
+        s.run()
+        return s.get_x_device().clone(), len(evals)
+    tk.TikhonovLinearSolver._device_objective = counting
+    try:
+        a, na = run(False)
+        b, nb = run(True)
+    finally:
+        tk.TikhonovLinearSolver._device_objective = orig
+        tk.REUSE_OBJECTIVE_AT_X0 = True
+    import torch
+    assert torch.equal(a, b)
+    assert nb == na - 3, (na, nb)
+
+
 @pytest.mark.parametrize("lossname", ["huber", "soft_l1", "cauchy", "arctan",
                                       "linear"])
 def test_tikhonov_minimize_losses(nsol, golden, lossname, lbfgsb_form):

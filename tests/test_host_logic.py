@@ -248,6 +248,37 @@ def test_lbfgsb_iteration_logic_tracks_scipy(lo, hi, n, iters):
     assert np.linalg.norm(x - ref.x) <= 1e-10 * max(np.linalg.norm(ref.x), 1)
 
 
+def test_lbfgsb_restarts_from_a_returned_point_without_reevaluating_it():
+    """minimize(..., start=(f, g)): a second solve of the same objective from the
+    point (and with the cost and gradient) the first one returned walks exactly the
+    iterates of a second solve that evaluates its starting point again, with one
+    evaluation fewer -- what ADMMLinearSolver does with minimizer='L-BFGS-B'."""
+    from nsol_amd import lbfgsb
+    from lbfgsb_numpy_backend import NumpyBackend
+    rng = np.random.default_rng(3)
+    n = 60
+    A = rng.standard_normal((n + 5, n))
+    b = 3.0 * rng.standard_normal(n + 5)
+    calls = []
+
+    def fg(x):
+        calls.append(1)
+        r = A @ x - b
+        z = r * r
+        return float(np.sum(np.sqrt(1 + z) - 1)), A.T @ (r / np.sqrt(1 + z))
+    x0 = rng.standard_normal(n) + 1.0
+    x1, info1 = lbfgsb.minimize(fg, x0, 0.0, np.inf, NumpyBackend(), maxiter=4)
+    assert info1["fun"] == fg(x1)[0] and np.array_equal(info1["jac"], fg(x1)[1])
+    del calls[:]
+    xa, ia = lbfgsb.minimize(fg, x1, 0.0, np.inf, NumpyBackend(), maxiter=4)
+    plain = len(calls)
+    del calls[:]
+    xb, ib = lbfgsb.minimize(fg, x1, 0.0, np.inf, NumpyBackend(), maxiter=4,
+                             start=(info1["fun"], info1["jac"]))
+    assert len(calls) == plain - 1
+    assert np.array_equal(xa, xb) and ia["nit"] == ib["nit"] and ia["nfev"] == ib["nfev"]
+
+
 def test_shard_indices():
     from nsol_amd.batch import shard_indices
     assert shard_indices(8, 1, 4) == [1, 5]

@@ -25,7 +25,7 @@ def timed(fn, reps=6):
     return float(np.median(ts))
 
 
-for c in (2, 5, 10):
+for c in (2, 5, 8, 10):
     ws = [r() for _ in range(c)]
     wy = [r() for _ in range(c)]
     coef = list(np.linspace(0.1, 1.0, c))
@@ -36,6 +36,15 @@ for c in (2, 5, 10):
         ("masked_grams (register-staged kernel)", lambda: (
             _lib.set_param("lb_gram_dma", 0), be.masked_grams(ws, wy, free),
             _lib.set_param("lb_gram_dma", 1)), 8.0 * c + 1),
+        ("masked_grams (VALU products, LDS-DMA tiles)", lambda: (
+            _lib.set_param("lb_gram_mfma", 0), be.masked_grams(ws, wy, free),
+            _lib.set_param("lb_gram_mfma", 1)), 8.0 * c + 1),
+        ("masked_grams_rgrad", lambda: be.masked_grams_rgrad(
+            ws, wy, free, z, x, g, 0.7, coef, coef), 8.0 * c + 1 + 16.0),
+        ("masked_grams_rgrad (VALU products)", lambda: (
+            _lib.set_param("lb_gram_mfma", 0), be.masked_grams_rgrad(
+                ws, wy, free, z, x, g, 0.7, coef, coef),
+            _lib.set_param("lb_gram_mfma", 1)), 8.0 * c + 1 + 16.0),
         ("reduced_gradient (wcomb)", lambda: be.reduced_gradient(
             z, x, g, 0.7, ws, wy, coef, coef, free), 4.0 * (3 + 2 * c + 1) + 1),
         ("subspace_direction (wcomb)", lambda: be.subspace_direction(
