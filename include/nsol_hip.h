@@ -679,6 +679,22 @@ int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
                                int ndim, int64_t nz, int64_t ny, int64_t nx,
                                double wx, double wy, double wz, double alpha,
                                double *result, double *ws, void *stream);
+/* The same pass with what L-BFGS-B asks of every new gradient while it is in
+ * registers (scipy's lnsrlb / projgr behind tikhonov_linear_solver.py:214-220):
+ * result[0] = sum |K x|^2, result[1] = grad'd (d may be NULL: 0), result[2] =
+ * max_i |P(x - grad)_i - x_i| for the bounds lo <= x <= hi (+-INFINITY: none), as
+ * nsol_dot_* and nsol_lb_projgr_* return them.  grad as above.
+ * ws: 3 * nsol_hip_reduce_ws_doubles() doubles; result: device double[3]. */
+int nsol_tk1_reg_objective_f32(const float *x, const float *g, float *grad,
+                               const float *d, int ndim, int64_t nz, int64_t ny,
+                               int64_t nx, double wx, double wy, double wz,
+                               double alpha, double lo, double hi, double *result,
+                               double *ws, void *stream);
+int nsol_tk1_reg_objective_f64(const double *x, const double *g, double *grad,
+                               const double *d, int ndim, int64_t nz, int64_t ny,
+                               int64_t nx, double wx, double wy, double wz,
+                               double alpha, double lo, double hi, double *result,
+                               double *ws, void *stream);
 /* The same stencil for LSMR run as Lanczos on the normal equations
  * M = A^T A + alpha K^T K (lsmr_normal in nsol_amd/lsmr.py, behind
  * tikhonov_linear_solver.py:146-158):

@@ -24,6 +24,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, kWave));
+  return v;
+}
+
 __device__ __forceinline__ void store_partial(double v, double *ws) {
   __shared__ double s[kBlock / kWave];
   v = wave_sum_d(v);
@@ -248,8 +254,13 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
   // but x, nothing written).  MODE 2: the three-term Lanczos update of the normal
   // equations, grad = c_g g + alpha K'K x + c_x x + c_z z (z may be null) with the
   // sum of squares of the RESULT -- one pass where MODE 0 and a combination took two.
+  // MODE 3: MODE 0 with what L-BFGS-B asks of every new gradient while it is in
+  // registers: its product with the search direction z (may be null) and the largest
+  // |projected gradient| for the bounds c_x <= x <= c_z (+-inf: none), as
+  // nsol_dot_* / nsol_lb_projgr_* form them; three partials per workgroup, the second
+  // and third kReducePartials and 2 kReducePartials doubles behind the first.
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
-  double acc = 0.0;
+  double acc = 0.0, accd = 0.0, pg = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
@@ -297,9 +308,30 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     }
     if constexpr (MODE == 1) continue;
     vlc<RAG, T, VEC>(c, g + c.i, nb);
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 3) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) out[k] = T(1) * nb[k] + alpha * out[k];
+      if constexpr (MODE == 3) {
+        if (z) {
+          vlc<RAG, T, VEC>(c, z + c.i, nb);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k)
+            if (!RAG || k < c.nval) accd += (double)out[k] * (double)nb[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          if (!RAG || k < c.nval) {
+            T gi = out[k];
+            if (gi < T(0)) {
+              const T u = v[k] - c_z;
+              gi = u > gi ? u : gi;
+            } else {
+              const T l = v[k] - c_x;
+              gi = l < gi ? l : gi;
+            }
+            pg = fmax(pg, fabs((double)gi));
+          }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) out[k] = c_g * nb[k] + alpha * out[k] + c_x * v[k];
@@ -314,7 +346,44 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
     }
     vs<RAG, T, VEC>(c.nval, grad + c.i, out);
   }
-  store_partial3(acc, ws);
+  if constexpr (MODE == 3) {
+    // (one after the other: store_partial3's scratch is shared)
+    store_partial3(acc, ws);
+    __syncthreads();
+    store_partial3(accd, ws + kReducePartials);
+    __syncthreads();
+    pg = wave_max_d(pg);
+    __shared__ double smax[kBlock / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) smax[threadIdx.x / kWave] = pg;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int k = 0; k < kBlock / kWave; ++k) t = fmax(t, smax[k]);
+      ws[2 * (int64_t)kReducePartials + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+  } else {
+    store_partial3(acc, ws);
+  }
+}
+
+// result[0], result[1]: sums of the first two runs of partials; result[2]: maximum of
+// the third (one workgroup each, fixed order)
+__global__ __launch_bounds__(1024) void k_final_objective(const double *ws, int64_t nparts,
+                                                           double *result) {
+  const bool is_max = blockIdx.x == 2;
+  const double *src = ws + (int64_t)blockIdx.x * kReducePartials;
+  double v = 0.0;
+  for (int64_t k = threadIdx.x; k < nparts; k += 1024) v = is_max ? fmax(v, src[k]) : v + src[k];
+  __shared__ double s[16];
+  v = is_max ? wave_max_d(v) : wave_sum_d(v);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t = is_max ? fmax(t, s[k]) : t + s[k];
+    result[blockIdx.x] = t;
+  }
 }
 
 inline int rgrid(int64_t n) {
@@ -415,6 +484,28 @@ int tk1_reg_impl(const T *x, const T *g, T *grad, int ndim, int64_t nz, int64_t 
                        dim3(kBlock), 0, as_stream(stream), x, g, grad, G, (T)alpha, ws);
     hipLaunchKernelGGL(k_final_big, dim3(1), dim3(1024), 0, as_stream(stream), ws,
                        nb, result);
+    return launch_status();
+  });
+}
+
+// MODE 3 of k_tk1_reg (see there): result[0] = sum |K x|^2, [1] = grad'd, [2] = max |proj grad|
+template <typename T>
+int tk1_objective_impl(const T *x, const T *g, T *grad, const T *d, int ndim, int64_t nz,
+                       int64_t ny, int64_t nx, double wx, double wy, double wz, double alpha,
+                       double lo, double hi, double *result, double *ws, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !g || !grad || !result || !ws || x == grad || d == grad) return NSOL_EINVAL;
+  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  const bool al = ptr16(x) && ptr16(g) && ptr16(grad) && (!d || ptr16(d)) && G.n % 4 == 0;
+  return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
+    constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
+    constexpr bool RG = decltype(rag)::value;
+    const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
+    hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG, 3>), (stencil_grid<V, R>(nz, ny, nx)),
+                       dim3(kBlock), 0, as_stream(stream), x, g, grad, G, (T)alpha, ws, d,
+                       T(1), (T)lo, (T)hi);
+    hipLaunchKernelGGL(k_final_objective, dim3(3), dim3(1024), 0, as_stream(stream), ws, nb,
+                       result);
     return launch_status();
   });
 }
@@ -527,6 +618,14 @@ int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
                              double *ws, void *stream) {                         \
     return tk1_lanczos_impl<T>(x, g, z, out, ndim, nz, ny, nx, wx, wy, wz,       \
                                alpha, c_g, c_x, c_z, result, ws, stream);        \
+  }                                                                              \
+  int nsol_tk1_reg_objective_##SUF(const T *x, const T *g, T *grad, const T *d,  \
+                                   int ndim, int64_t nz, int64_t ny, int64_t nx, \
+                                   double wx, double wy, double wz, double alpha, \
+                                   double lo, double hi, double *result,         \
+                                   double *ws, void *stream) {                   \
+    return tk1_objective_impl<T>(x, g, grad, d, ndim, nz, ny, nx, wx, wy, wz,    \
+                                 alpha, lo, hi, result, ws, stream);             \
   }
 NSOL_TK1_DEF(float, f32)
 NSOL_TK1_DEF(double, f64)

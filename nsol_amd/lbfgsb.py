@@ -337,10 +337,15 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     (x, info dict).  Follows scipy's iteration accounting: stops after
     `maxiter` accepted iterations.
 
-    start: (f, g) at x0 when the caller already holds them (x0 feasible, so that
-    the clip below returns its values: e.g. the point an earlier call on the same
-    objective returned, with info["fun"] / info["jac"]); the first evaluation
-    is then not repeated (it still counts in nfev, as scipy would report it)."""
+    start: (f, g[, |proj g|_inf]) at x0 when the caller already holds them (x0
+    feasible, so that the clip below returns its values: e.g. the point an earlier
+    call on the same objective returned, with info["fun"] / info["jac"] /
+    info["pg"]); the first evaluation is then not repeated (it still counts in
+    nfev, as scipy would report it).
+
+    fun_and_grad.with_extras(x, d, lo, hi) -> (f, g, g'd or None, |proj g|_inf), when
+    the objective offers it, replaces the evaluation, backend.dot(g, d) and
+    backend.projgr(x, g, lo, hi) of every new point (d may be None)."""
     be = backend
     # A backend whose kernels want whole vectors (DeviceBackend.pad_to: 16
     # elements -- 16-byte accesses and one mask byte per element) gets the
@@ -357,7 +362,14 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             f, g = fun_and_grad(be.head(xp, n_in))
             return f, be.pad(g, n_pad)
         if start is not None:
-            start = (start[0], be.pad(start[1], n_pad))
+            start = (start[0], be.pad(start[1], n_pad)) + tuple(start[2:])
+        if getattr(fun_and_grad, "with_extras", None) is not None:
+            def padded_extras(xp, dp, lo_, hi_):
+                f, g, gd, pg = fun_and_grad.with_extras(
+                    be.head(xp, n_in), None if dp is None else be.head(dp, n_in),
+                    lo_, hi_)
+                return f, be.pad(g, n_pad), gd, pg
+            padded.with_extras = padded_extras
         xp, info = minimize(padded, be.pad(x0, n_pad), lo, hi, be,
                             maxiter=maxiter, m=m, factr=factr, pgtol=pgtol,
                             maxls=maxls, maxfun=maxfun, start=start)
@@ -371,16 +383,24 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     cm = CompactMatrix(m)
     ws, wy = [], []                   # stored s_k, y_k (oldest first)
     iwhere = be.init_where(x, lo, hi)
-    f, g = fun_and_grad(x) if start is None else start
+    ext = getattr(fun_and_grad, "with_extras", None)
+    pg = None
+    if start is not None:
+        f, g = start[0], start[1]
+        pg = start[2] if len(start) > 2 else None
+    elif ext is not None:
+        f, g, _, pg = ext(x, None, lo, hi)
+    else:
+        f, g = fun_and_grad(x)
     nfgv = 1
     it = 0
     nskip = 0
     updatd = False
-    sbgnrm = be.projgr(x, g, lo, hi)
+    sbgnrm = be.projgr(x, g, lo, hi) if pg is None else pg
     info = {"task": "START", "nit": 0, "nfev": 1}
     if sbgnrm <= pgtol:
         info["task"] = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL"
-        info["fun"], info["jac"] = f, g
+        info["fun"], info["jac"], info["pg"] = f, g, sbgnrm
         return x, info
 
     while True:
@@ -491,8 +511,12 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                     x = z
                 else:
                     x = be.lincomb2(stp, d, 1.0, xold)
-                f, g = fun_and_grad(x)
-                gd = be.dot(g, d)
+                if ext is not None:
+                    f, g, gd, pg = ext(x, d, lo, hi)
+                else:
+                    f, g = fun_and_grad(x)
+                    gd = be.dot(g, d)
+                    pg = None
                 ls.step(f, gd)
             stp = ls.stp
         if restart:
@@ -506,7 +530,8 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             continue
         # ---------------- new iterate ---------------------------------------
         it += 1
-        sbgnrm = be.projgr(x, g, lo, hi)
+        # (x, g are those of the search's last evaluation)
+        sbgnrm = be.projgr(x, g, lo, hi) if pg is None else pg
         if it >= maxiter:
             info["task"] = "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT"
             break
@@ -569,6 +594,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     info["nfev"] = nfgv
     info["fun"] = f
     info["jac"] = g               # (f, g belong to the point returned)
+    info["pg"] = sbgnrm           # (of the same point: a failed search changes neither)
     return x, info
 
 

@@ -469,6 +469,28 @@ def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None, result=None):
     return (res if result is not None else float(res.item())), out
 
 
+_ws3 = {}
+
+
+def tk1_reg_objective(x, g, d, shape, w, alpha, lo, hi, out, result):
+    """tk1_reg_cost_grad with the new gradient's product with d (None: 0) and its
+    largest projected component for lo <= x <= hi in result[1], result[2] (result:
+    the caller's three-element float64 device slots; nothing is read back here)."""
+    _same(x, g)
+    if d is not None:
+        _same(x, d)
+    ndim, nz, ny, nx = dims3(shape)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _ws3:
+        _ws3[key] = torch.empty(3 * _lib.load().nsol_hip_reduce_ws_doubles(),
+                                dtype=torch.float64, device=x.device)
+    _lib.check(_fn("tk1_reg_objective", x)(
+        _p(x), _p(g), _p(out), _p(d), ndim, nz, ny, nx, w[0], w[1], w[2], float(alpha),
+        float(lo), float(hi), _p(result), _p(_ws3[key]), stream_ptr()),
+        "nsol_tk1_reg_objective")
+    return out
+
+
 def tk1_grad_norm(x, shape, w, result=None):
     """sum |grad x|^2 alone (one read of x); result: the caller's device slot."""
     _chk(x)

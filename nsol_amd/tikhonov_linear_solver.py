@@ -43,6 +43,10 @@ USE_FUSED_TK1_REG = True
 # the next solve instead of being evaluated again (bit for bit the same values), and
 # its projection onto the bounds (the identity on it) is not repeated
 REUSE_OBJECTIVE_AT_X0 = True
+# the device L-BFGS-B driver's g'd and projected-gradient norm of every new gradient
+# from the kernel that forms it (nsol_tk1_reg_objective_*) instead of a pass and a
+# read-back each (B = gradient only)
+USE_OBJECTIVE_EXTRAS = True
 
 
 # A^T b for the (operator, data) pairs seen last: an outer loop (ADMM, primal-dual
@@ -346,27 +350,38 @@ class TikhonovLinearSolver(LinearSolver):
 
         slots = []
 
-        def fun_and_grad(x):
+        def fun_and_grad(x, extras=None):
             r = A(x)
             # in place unless A handed x itself back (an identity operator)
             own = r.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()
             if native is not None:
                 # B = gradient, B_adj its adjoint: 1/2||Bx||^2 and B_adj(Bx)
                 # from one pass over x (same values as the branch below).  The
-                # two sums wait in device slots until all four kernels are
-                # enqueued: one read-back instead of two, behind them
+                # sums wait in device slots until all four kernels are
+                # enqueued: one read-back instead of two, behind them.  With
+                # `extras` = (d, lo, hi) the last kernel also leaves g'd and the
+                # largest projected component of g there (what L-BFGS-B asks of
+                # every new gradient: no pass of their own, no further read-back)
                 import torch
                 if not slots:
-                    slots.append(torch.empty(2, dtype=torch.float64,
+                    slots.append(torch.empty(4, dtype=torch.float64,
                                              device=r.device))
                 _, g = ops.loss_cost_grad(r, loss, fscale,
                                           out=r if own else None, minus=b,
                                           result=slots[0][0:1])
                 grad = A_adj(g)
                 shape, w = native
+                if extras is not None:
+                    d, lo, hi = extras
+                    ops.tk1_reg_objective(x, grad, d, shape, w, alpha, lo, hi,
+                                          out=grad, result=slots[0][1:4])
+                    sums = slots[0].cpu()
+                    return (float(sums[0]) + alpha * (0.5 * float(sums[1])), grad,
+                            float(sums[2]) if d is not None else None,
+                            float(sums[3]))
                 _, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
                                                 out=grad, result=slots[0][1:2])
-                sums = slots[0].cpu()
+                sums = slots[0][:2].cpu()
                 return float(sums[0]) + alpha * (0.5 * float(sums[1])), grad
             cost, g = ops.loss_cost_grad(r, loss, fscale, out=r if own else None,
                                          minus=b)
@@ -377,6 +392,9 @@ class TikhonovLinearSolver(LinearSolver):
                 cost = cost + alpha * (0.5 * ops.dot(Bx, Bx))
                 grad = ops.lincomb2(1.0, grad, alpha, B_adj(Bx))
             return cost, grad
+        if native is not None and USE_OBJECTIVE_EXTRAS:
+            # (f, g, g'd, |proj g|_inf) from the same kernels: lbfgsb.minimize's protocol
+            fun_and_grad.with_extras = lambda x, d, lo, hi: fun_and_grad(x, (d, lo, hi))
         return fun_and_grad
 
     _warm_start = None              # set by the outer solver (see _run_minimize)
@@ -427,7 +445,8 @@ class TikhonovLinearSolver(LinearSolver):
             # the first evaluation would recompute them bit for bit
             start = None
             if self._warm_start_applies(x0):
-                start = (self._warm_start["f"], self._warm_start["g"])
+                start = (self._warm_start["f"], self._warm_start["g"],
+                         self._warm_start.get("pg"))
             x, info = lbfgsb.minimize(self._device_objective(), x0, float(lo),
                                       float(hi), DeviceBackend(),
                                       maxiter=self._iter_max, start=start)
@@ -435,6 +454,7 @@ class TikhonovLinearSolver(LinearSolver):
             self._warm_result = None
             if info.get("jac") is not None:
                 self._warm_result = {"x": x, "f": info["fun"], "g": info["jac"],
+                                     "pg": info.get("pg"),
                                      "bounds": (float(lo), float(hi)),
                                      "key": self._objective_key(),
                                      "reused": start is not None}

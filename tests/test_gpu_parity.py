@@ -882,6 +882,72 @@ def test_admm_lbfgsb_hands_the_objective_at_x0_to_the_next_solve(nsol, golden, k
     assert nb == na - 3, (na, nb)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,lo,hi", [((40, 36, 64), 0.0, np.inf),
+                                         ((33, 31, 29), 0.1, 0.9),
+                                         ((48, 48), -np.inf, 0.7),
+                                         ((1000,), -np.inf, np.inf),
+                                         ((64, 64, 64), 0.0, 1.0)])
+def test_objective_pass_also_gives_the_line_search_its_scalars(nsol, dtype, shape,
+                                                               lo, hi):
+    """nsol_tk1_reg_objective_*: the gradient and sum |K x|^2 of
+    nsol_tk1_reg_cost_grad_* bit for bit, with g'd as nsol_dot_* and the projected
+    gradient norm as nsol_lb_projgr_* return them."""
+    import torch
+    from nsol_amd import ops
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.rand(n, device="cuda", dtype=td, generator=gen)
+    if np.isfinite(lo) or np.isfinite(hi):
+        x = x.clamp(max(lo, -1e30), min(hi, 1e30))
+    g = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    d = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    w = ops.inv_spacing(np.ones(len(shape)) * 0.7, len(shape))
+    cost, ref = ops.tk1_reg_cost_grad(x, g, shape, w, 0.37)
+    slots = torch.zeros(3, dtype=torch.float64, device="cuda")
+    out = ops.tk1_reg_objective(x, g, d, shape, w, 0.37, lo, hi,
+                                out=torch.empty_like(g), result=slots)
+    got = slots.cpu().numpy()
+    assert torch.equal(out, ref)
+    assert got[0] == cost
+    gd = ops.dot(ref, d)
+    assert abs(got[1] - gd) <= 1e-13 * float(ref.abs().double() @ d.abs().double())
+    assert got[2] == DeviceBackend().projgr(x, ref, lo, hi)
+    # in place on g, no direction
+    ops.tk1_reg_objective(x, g, None, shape, w, 0.37, lo, hi, out=g, result=slots)
+    assert torch.equal(g, ref) and float(slots[1]) == 0.0
+
+
+@pytest.mark.parametrize("k,dtype", [("1d", np.float64), ("2d", np.float32),
+                                     ("3d", np.float32), ("3d", np.float64)])
+def test_lbfgsb_with_the_scalars_from_the_objective_pass(nsol, golden, k, dtype):
+    """The device L-BFGS-B with g'd and the projected gradient norm taken from the
+    kernel that forms the gradient (tikhonov_linear_solver.USE_OBJECTIVE_EXTRAS)
+    against the run with a pass and a read-back each: the same iterations and
+    evaluations, iterates equal to rounding of the sums' order."""
+    import nsol_amd.tikhonov_linear_solver as tk
+    g, shape, A, Aa, D, Da = _dec_ops(golden, k)
+    y = g["y_" + k]
+
+    def run(extras):
+        tk.USE_OBJECTIVE_EXTRAS = extras
+        s = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=D, B_adj=Da, b=y, x0=y,
+                                    alpha=0.05, x_scale=float(y.max()), iter_max=8,
+                                    minimizer="L-BFGS-B", data_loss="huber",
+                                    data_loss_scale=0.1, dtype=dtype)
+        s.run()
+        return s.get_x(), s._minimize_info
+    try:
+        a, ia = run(False)
+        b, ib = run(True)
+    finally:
+        tk.USE_OBJECTIVE_EXTRAS = True
+    assert ia["nit"] == ib["nit"] and ia["nfev"] == ib["nfev"]
+    assert rel_l2(b, a) < (1e-12 if dtype == np.float64 else 1e-6)
+
+
 @pytest.mark.parametrize("lossname", ["huber", "soft_l1", "cauchy", "arctan",
                                       "linear"])
 def test_tikhonov_minimize_losses(nsol, golden, lossname, lbfgsb_form):
