@@ -131,5 +131,13 @@ def empty_like(t, n=None):
     return torch.empty(int(n), dtype=t.dtype, device=t.device)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (the raw query:
+    a tenth of the cost of building a torch.cuda.Stream object, and an L-BFGS-B
+    iteration asks a few dozen times)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

@@ -29,6 +29,10 @@ EPSMCH = np.finfo(np.float64).eps
 # separate passes (the A/B reference of the tests) even when the backend offers
 # them fused
 FUSE_SUBSPACE_STEP = True
+# True: scalars of kernels that follow each other without a decision in between are
+# read back together where the backend offers it (cauchy_setup + W'd; the count of
+# free variables + the subspace matrix)
+MERGE_READBACKS = True
 # False: [Y S]'Z r by a pass of its own even when the Gram pass delivered it
 USE_GRAM_RHS = True
 BIG = 1.0e10
@@ -228,15 +232,15 @@ class CompactMatrix(object):
         self.theta = 1.0
 
     def form_t(self):
+        # T = theta * S'S + L D^-1 L'  (L: strictly lower part of S'Y, D its diagonal);
+        # the sums over the stored pairs as matrix products: interpreter loops over
+        # col^3 / 3 terms held the GPU idle for a tenth of a millisecond per iteration
         c, th = self.col, self.theta
-        T = np.zeros((c, c))
-        for i in range(c):
-            for j in range(i, c):
-                k1 = min(i, j)
-                acc = 0.0
-                for k in range(k1):
-                    acc += self.sy[i, k] * self.sy[j, k] / self.sy[k, k]
-                T[i, j] = acc + th * self.ss[i, j]
+        sy = self.sy[:c, :c]
+        ls = np.tril(sy, -1)
+        ss = np.triu(self.ss[:c, :c])
+        ss = ss + np.triu(ss, 1).T
+        T = th * ss + (ls / np.diag(sy)[None, :]).dot(ls.T)
         T = np.triu(T) + np.triu(T, 1).T
         try:
             self.wt = np.linalg.cholesky(T).T        # upper: T = wt^T wt
@@ -249,36 +253,43 @@ class CompactMatrix(object):
         c = self.col
         if c == 0:
             return np.zeros(0)
-        sy, wt = self.sy, self.wt
-        p = np.zeros(2 * c)
-        p[c] = v[c]
-        for i in range(1, c):
-            acc = 0.0
-            for k in range(i):
-                acc += sy[i, k] * v[k] / sy[k, k]
-            p[c + i] = v[c + i] + acc
-        p[c:] = _solve_upper_t(wt, p[c:])            # wt^T z = rhs
-        for i in range(c):
-            p[i] = v[i] / math.sqrt(sy[i, i])
-        p[c:] = _solve_upper(wt, p[c:])              # wt z = rhs
-        for i in range(c):
-            p[i] = -p[i] / math.sqrt(sy[i, i])
-        for i in range(c):
-            acc = 0.0
-            for k in range(i + 1, c):
-                acc += sy[k, i] * p[c + k] / sy[i, i]
-            p[i] += acc
-        return p
+        sy, wt = self.sy[:c, :c], self.wt
+        v = np.asarray(v, dtype=np.float64)
+        dg = np.diag(sy)
+        ls = np.tril(sy, -1)
+        p2 = v[c:] + ls.dot(v[:c] / dg)
+        p2 = _solve_upper_t(wt, p2)                  # wt^T z = rhs
+        p2 = _solve_upper(wt, p2)                    # wt z = rhs
+        p1 = -(v[:c] / np.sqrt(dg)) / np.sqrt(dg)
+        p1 = p1 + ls.T.dot(p2) / dg
+        return np.concatenate((p1, p2))
+
+
+def middle_matrix(cm):
+    """The 2col x 2col middle matrix M itself (bmv column by column, with the loops
+    over the stored pairs as matrix products: the Cauchy search wants all of M once
+    per iteration, and 2col calls of bmv were a millisecond of interpreter time)."""
+    c = cm.col
+    sy, wt = cm.sy[:c, :c], cm.wt
+    dg = np.diag(sy).copy()
+    ls = np.tril(sy, -1)
+    v = np.eye(2 * c)
+    p2 = v[c:] + ls.dot(v[:c] / dg[:, None])
+    p2 = _solve_upper_t(wt, p2)
+    p2 = _solve_upper(wt, p2)
+    p1 = -(v[:c] / np.sqrt(dg)[:, None]) / np.sqrt(dg)[:, None]
+    p1 = p1 + ls.T.dot(p2) / dg[:, None]
+    return np.vstack((p1, p2))
 
 
 def _solve_upper(R, b):
-    import scipy.linalg
-    return scipy.linalg.solve_triangular(R, b, lower=False)
+    from scipy.linalg import solve_triangular
+    return solve_triangular(R, b, lower=False, check_finite=False)
 
 
 def _solve_upper_t(R, b):
-    import scipy.linalg
-    return scipy.linalg.solve_triangular(R, b, lower=False, trans='T')
+    from scipy.linalg import solve_triangular
+    return solve_triangular(R, b, lower=False, trans='T', check_finite=False)
 
 
 def form_k(cm, yzzy, szzs, szzy):
@@ -289,15 +300,10 @@ def form_k(cm, yzzy, szzs, szzy):
     saas = (np.triu(cm.ss[:c, :c]) + np.triu(cm.ss[:c, :c], 1).T) - szzs
     # (1,1) block  D + Y'ZZ'Y/theta
     k11 = yzzy / th + np.diag(np.diag(cm.sy[:c, :c]))
-    # (1,2) block  -L_a' + R_z'  (row: y index, column: s index)
-    k12 = np.zeros((c, c))
-    for iy in range(c):           # s index
-        for jy in range(c):       # y index
-            if jy < iy:
-                la = cm.sy[iy, jy] - szzy[iy, jy]     # S'AA'Y, strictly lower
-                k12[jy, iy] = -la
-            else:
-                k12[jy, iy] = szzy[iy, jy]            # R_z (upper incl. diag)
+    # (1,2) block  -L_a' + R_z'  (row: y index, column: s index): above the
+    # diagonal the strictly lower part of S'AA'Y = S'Y - S'ZZ'Y, negated and
+    # transposed; on and below it R_z (the upper part of S'ZZ'Y incl. its diagonal)
+    k12 = np.triu(szzy).T - np.tril(cm.sy[:c, :c] - szzy, -1).T
     try:
         r11 = np.linalg.cholesky(k11).T               # k11 = r11^T r11
     except np.linalg.LinAlgError:
@@ -416,7 +422,11 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             nfree_all = False
         # ---------------- subspace minimisation ---------------------------
         step = None
-        nfree = be.count_free(iwhere) if not nfree_all else be.size(x)
+        # (with the fused Gram pass below the count is enqueued ahead of it and read
+        # back with its result: the pass is wasted in the rare case of no free variable)
+        late_count = MERGE_READBACKS and not nfree_all and col != 0 and cnstnd and \
+            hasattr(be, "masked_grams_rgrad")
+        nfree = be.size(x) if nfree_all else (-1 if late_count else be.count_free(iwhere))
         if nfree != 0 and col != 0:
             ok = True
             if nfree_all:
@@ -433,8 +443,18 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 coef_y = mc[:col]
                 coef_s = theta * mc[col:]
                 if hasattr(be, "masked_grams_rgrad"):
-                    fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
-                                                  coef_s, coef_y)
+                    if late_count:
+                        fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
+                                                      coef_s, coef_y, count=True)
+                        if fused is not None:
+                            nfree = fused[-1]
+                            fused = fused[:-1]
+                    else:
+                        fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
+                                                      coef_s, coef_y)
+            if nfree < 0:
+                nfree = be.count_free(iwhere)
+        if nfree != 0 and col != 0:       # (a late count may have found none free)
             wtzr = None
             if fused is not None:
                 yzzy, szzs, szzy, r, wtzr = fused
@@ -618,7 +638,12 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     col, theta = cm.col, cm.theta
     if sbgnrm <= 0.0:
         return be.copy(x), np.zeros(2 * col), iwhere
-    d, tbk, iwhere, st = be.cauchy_setup(x, g, lo, hi, iwhere)
+    both = None
+    if col > 0 and MERGE_READBACKS and hasattr(be, "cauchy_setup_dots"):
+        # (the products W'd enqueued behind the set-up that forms d: one read-back)
+        d, tbk, iwhere, st, both = be.cauchy_setup_dots(x, g, lo, hi, iwhere, wy + ws)
+    else:
+        d, tbk, iwhere, st = be.cauchy_setup(x, g, lo, hi, iwhere)
     nbreak = st["nbreak"]
     bnded = st["bnded"]
     STATS["cauchy_calls"] += 1
@@ -627,7 +652,9 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     S.f1 = st["f1"]
     S.p = np.zeros(2 * col)
     if col > 0:
-        both = np.asarray(be.dots(wy + ws, d))     # one pass, one read-back
+        if both is None:
+            both = be.dots(wy + ws, d)             # one pass, one read-back
+        both = np.asarray(both)
         S.p[:col] = both[:col]
         S.p[col:] = theta * both[col:]
     if not st["any_move"]:
@@ -638,7 +665,7 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     mmat = None
     if col > 0:
         S.f2 -= float(np.dot(cm.bmv(S.p), S.p))
-        mmat = np.array([cm.bmv(e) for e in np.eye(2 * col)]).T   # v = mmat @ w
+        mmat = middle_matrix(cm)                                   # v = mmat @ w
     S.dtm = -S.f1 / S.f2
     S.tsum = 0.0
     S.tj = 0.0

@@ -156,10 +156,12 @@ class DeviceBackend(object):
         return yy, ss, h[2]
 
     def masked_grams_rgrad(self, ws_list, wy_list, free, z, x, g, theta, coef_s,
-                           coef_y):
+                           coef_y, count=False):
         """masked_grams and reduced_gradient from ONE pass over the 2c vectors
         (nsol_lb_masked_gram_rgrad_*), with [Y S]'Z r (Y first) for the subspace
-        right-hand side; None where that kernel does not apply."""
+        right-hand side; None where that kernel does not apply.  count: the number
+        of free variables (count_free) enqueued ahead and read back with the rest,
+        appended to the result."""
         import ctypes
         c = len(ws_list)
         vecs = list(wy_list) + list(ws_list)           # Y first, then S
@@ -172,12 +174,17 @@ class DeviceBackend(object):
             self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
                                         dtype=torch.float64, device=like.device)
         npairs = nv * (nv + 1) // 2
-        out = torch.empty(npairs + nv, dtype=torch.float64, device=like.device)
+        out = torch.empty(npairs + nv + 1, dtype=torch.float64, device=like.device)
         r = torch.empty_like(like)
         ptrs = (ctypes.c_void_p * nv)(*[v.data_ptr() for v in vecs])
         base = (ctypes.c_void_p * 3)(z.data_ptr(), x.data_ptr(), g.data_ptr())
         bco = np.array([-theta, theta, -1.0], dtype=np.float64)
         wco = np.ascontiguousarray(list(coef_y) + list(coef_s), dtype=np.float64)
+        if count:
+            wsb, _ = self._bufs(like)
+            self._check(lib.nsol_lb_count_free(
+                _p(free), free.numel(), out.data_ptr() + 8 * (npairs + nv), _p(wsb),
+                stream_ptr()), "count_free")
         rc = _fn("masked_gram_rgrad", like)(
             ptrs, nv, _p(free), like.numel(), _p(out), _p(self._gram_ws),
             ctypes.cast(base, ctypes.c_void_p), bco.ctypes.data, wco.ctypes.data,
@@ -190,8 +197,9 @@ class DeviceBackend(object):
         gm[np.triu_indices(nv)] = flat[:npairs]
         gm = gm + np.triu(gm, 1).T
         # W'Z r for r = Z (b + W wco): from the matrix and the products with b
-        wtzr = flat[npairs:] + gm @ wco
-        return gm[:c, :c], gm[c:, c:], gm[c:, :c], r, wtzr
+        wtzr = flat[npairs:npairs + nv] + gm @ wco
+        res = (gm[:c, :c], gm[c:, c:], gm[c:, :c], r, wtzr)
+        return res + (int(round(float(flat[npairs + nv]))),) if count else res
 
     def _masked_grams_one_pass(self, ws_list, wy_list, free):
         """All entries from ONE pass over the 2c vectors (nsol_lb_masked_gram_*)."""
@@ -230,6 +238,32 @@ class DeviceBackend(object):
               "bnded": int(round(r[2])) == 0, "any_move": int(round(r[3])) > 0}
         self._x = x
         return d, tbk, iw, st
+
+    def cauchy_setup_dots(self, x, g, lo, hi, iwhere, vecs):
+        """cauchy_setup and dots(vecs, d) enqueued one behind the other, their
+        scalars read back together."""
+        lib = _lib.load()
+        ws, _ = self._bufs(x)
+        nv = len(vecs)
+        both = torch.empty(4 + nv, dtype=torch.float64, device=x.device)
+        d = torch.empty_like(x)
+        tbk = torch.empty_like(x)
+        iw = iwhere.clone()
+        self._check(_fn("cauchy_setup", x)(
+            _p(x), _p(g), x.numel(), float(lo), float(hi), _p(iw), _p(d),
+            _p(tbk), _p(both), _p(ws), stream_ptr()), "cauchy_setup")
+        if self._gram_ws is None or self._gram_ws.device != x.device:
+            self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
+                                        dtype=torch.float64, device=x.device)
+        ptrs = (ctypes.c_void_p * nv)(*[w.data_ptr() for w in vecs])
+        self._check(_fn("mdots", d)(ptrs, nv, _p(d), None, d.numel(),
+                                    both.data_ptr() + 32, _p(self._gram_ws),
+                                    stream_ptr()), "mdots")
+        r = both.cpu().numpy()
+        st = {"f1": -float(r[0]), "nbreak": int(round(r[1])),
+              "bnded": int(round(r[2])) == 0, "any_move": int(round(r[3])) > 0}
+        self._x = x
+        return d, tbk, iw, st, [float(t) for t in r[4:]]
 
     def breakpoint_walker(self, tbk, d, ws_list, wy_list, theta, lo, hi,
                           f2_org, mmat):

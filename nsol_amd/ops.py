@@ -407,7 +407,7 @@ _ws = {}
 
 
 def _workspace(dev):
-    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    key = (dev.index, stream_ptr())
     if key not in _ws:
         n = _lib.load().nsol_hip_reduce_ws_doubles()
         _ws[key] = (torch.empty(n, dtype=torch.float64, device=dev),
@@ -480,7 +480,7 @@ def tk1_reg_objective(x, g, d, shape, w, alpha, lo, hi, out, result):
     if d is not None:
         _same(x, d)
     ndim, nz, ny, nx = dims3(shape)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (x.device.index, stream_ptr())
     if key not in _ws3:
         _ws3[key] = torch.empty(3 * _lib.load().nsol_hip_reduce_ws_doubles(),
                                 dtype=torch.float64, device=x.device)
@@ -551,7 +551,7 @@ _fetchers = {}
 def scalar_fetchers(device, count, n):
     """n ScalarFetch objects of `count` doubles each, kept per device and stream (pinned
     memory and a side stream cost far more to create than to use)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream, int(count), int(n))
+    key = (device.index, stream_ptr(), int(count), int(n))
     if key not in _fetchers:
         _fetchers[key] = [ScalarFetch(device, count) for _ in range(n)]
     return _fetchers[key]
@@ -564,7 +564,7 @@ def pair_stats(x, y, mx=0.0, my=0.0):
     """NumPy array of the 8 sums documented at nsol_pair_stats_* (syncs)."""
     _same(x, y)
     ws, _ = _workspace(x.device)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = (x.device.index, stream_ptr())
     if key not in _ws8:
         _ws8[key] = torch.empty(8, dtype=torch.float64, device=x.device)
     res = _ws8[key]
