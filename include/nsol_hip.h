@@ -231,6 +231,25 @@ int nsol_corr3_wrap_lanczos_b_f64(const double *t, const double *q0, const doubl
                                   const double *taps_x, int ntaps, double rho_grad,
                                   double rho_ident, double *board, int step, double *coef,
                                   double *ws, int64_t ws_doubles, void *stream);
+
+/* The blur with the data term of the robust-loss objective as its epilogue
+ * (tikhonov_linear_solver.py:201-208: `residual = A(x) - b`, `loss(residual^2)`,
+ * `A_adj(gradient_loss * residual)`): g = rho'(r^2) r for r = A x - b and
+ * *result = 1/2 sum rho(r^2), what nsol_corr3_wrap_* followed by
+ * nsol_loss_residual_cost_grad_* produce (g bit for bit, the sum in another order)
+ * without A x going to memory.  loss: NSOL_LOSS_LINEAR / _SOFT_L1 / _HUBER.  ws: one
+ * double per tile of scratch (nsol_hip_reduce_ws_doubles() suffices).  Returns -2
+ * (nothing launched) for the other losses and where nsol_corr3_wrap_lanczos_a_* does. */
+int nsol_corr3_wrap_loss_f32(const float *x, const float *b, float *g, int64_t nz,
+                             int64_t ny, int64_t nx, const double *taps_z,
+                             const double *taps_y, const double *taps_x, int ntaps,
+                             int loss, double f_scale, double *result, double *ws,
+                             int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_loss_f64(const double *x, const double *b, double *g, int64_t nz,
+                             int64_t ny, int64_t nx, const double *taps_z,
+                             const double *taps_y, const double *taps_x, int ntaps,
+                             int loss, double f_scale, double *result, double *ws,
+                             int64_t ws_doubles, void *stream);
 /* dense N-D correlation with DEVICE taps [kz][ky][kx] and centre (cz,cy,cx):
  *   out[i] = sum_t taps[t] * x[i + t - c].  Replaces linear_operators.py:60-68
  * (scipy.ndimage.convolve with an arbitrary kernel; the host flips the kernel

@@ -101,6 +101,19 @@ int blur3_lanczos_b(const double *t, const double *q0, const double *y, double *
                     const Taps<double> &ty, const Taps<double> &tx, int ntaps, double rho_g,
                     double rho_i, double *board, int step, double *coef, double *part,
                     int64_t part_doubles, hipStream_t st);
+// The data term of the robust-loss objective as the blur's epilogue (epi 5): g = rho'(r^2) r
+// for r = A x - b and *result = sum rho(r^2); loss one of linear / soft_l1 / huber, s2 =
+// f_scale^2, gm the Huber threshold.  -2: does not apply (nothing launched).
+__attribute__((visibility("hidden")))
+int blur3_loss_epilogue(const float *x, const float *b, float *g, int64_t nz, int64_t ny,
+                        int64_t nx, const Taps<float> &tz, const Taps<float> &ty,
+                        const Taps<float> &tx, int ntaps, int loss, double s2, double gm,
+                        double *result, double *part, int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_loss_epilogue(const double *x, const double *b, double *g, int64_t nz, int64_t ny,
+                        int64_t nx, const Taps<double> &tz, const Taps<double> &ty,
+                        const Taps<double> &tx, int ntaps, int loss, double s2, double gm,
+                        double *result, double *part, int64_t part_doubles, hipStream_t st);
 __attribute__((visibility("hidden")))
 int blur3_lanczos_init(double *board, float *coef, double rho_g, double rho_i, hipStream_t st);
 __attribute__((visibility("hidden")))
@@ -157,6 +170,29 @@ __device__ __forceinline__ double fma1(double a, double b, double c) {
 }
 
 
+// The robust losses that cost a handful of operations (linear, soft_l1, huber), with
+// the expressions of nsol_ops.hip's loss_eval: rho(f2) and rho'(f2) for f2 = r^2.
+template <typename T>
+__device__ __forceinline__ void blur3_loss(int loss, T f2, T s2, T gm, T &rho, T &drho) {
+  const T z = f2 / s2;
+  if (loss == NSOL_LOSS_SOFT_L1) {
+    const T q = t_sqrt(T(1) + z);
+    rho = T(2) * (q - T(1)) * s2;
+    drho = T(1) / q;
+  } else if (loss == NSOL_LOSS_HUBER) {
+    const T g2 = gm * gm;
+    if (z < g2) { rho = z * s2; drho = T(1); }
+    else {
+      const T q = t_sqrt(z);
+      rho = (T(2) * gm * q - g2) * s2;
+      drho = gm / q;
+    }
+  } else {
+    rho = f2;
+    drho = T(1);
+  }
+}
+
 // phases U .. M-1 of one trip through the loop body (each with its position in the
 // ring as a compile-time constant); stops at the end of the z chunk
 template <int U, int M, typename F>
@@ -202,6 +238,13 @@ __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
 // ONE tile per array: a lane moves its values of this plane to registers first and the
 // next plane's piece is requested into the same tile (a wave only ever reads what its own
 // piece brought).
+//
+// EPI == 5: the data term of the robust-loss objective (tikhonov_linear_solver.py:
+// 201-208) as the epilogue of A x: with b = aux1 staged like EPI 1's old io tile, the
+// kernel stores rho'(r^2) r for r = A x - b and leaves sum rho(r^2) in part[tile] --
+// what nsol_loss_cost_grad_* makes of a stored A x in a pass of its own (ca = f_scale^2,
+// cb = the Huber threshold, cc = the loss; the element-wise values are that kernel's bit
+// for bit, the sum is taken in another order).  No RAG form.
 //
 // RAG: rows that are not a multiple of 16 bytes (or operands that are not 16-byte
 // aligned).  LDS-DMA takes 16-byte pieces from any 4-byte aligned source and honours
@@ -556,7 +599,19 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       }
       val = splat<V, T>(ca) * val + splat<V, T>(cb) * old;
     }
-    if constexpr (EPI != 0) {
+    if constexpr (EPI == 5) {
+      const V bv = obuf[(size_t)ob * tile_vecs + (size_t)row * lxb + lx];
+      const int kind = (int)cc;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const T r = T(1) * val[e] + T(-1) * bv[e];          // (as nsol_lincomb2 forms A x - b)
+        T rho, drho;
+        blur3_loss(kind, r * r, ca, cb, rho, drho);
+        if (owner) sumsq += (double)rho;
+        val[e] = drho * r;
+      }
+    }
+    if constexpr (EPI != 0 && EPI != 5) {
       if (owner) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
@@ -609,9 +664,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     old_off = (uint32_t)(yy * nx + xe);
   }
   auto stage_old = [&](int64_t z, int ob) {
-    if constexpr (EPI == 1)
+    if constexpr (EPI == 1 || EPI == 5)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(out + z * plane + old_off),
+          (const __attribute__((address_space(1))) void *)((EPI == 5 ? aux1 : out) + z * plane +
+                                                           old_off),
           (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
                                                      (size_t)wave * 64),
           16, 0, 0);
@@ -771,8 +827,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       phase_end((more ? my_stage_ops : 0) + 1 + (storing ? my_store_ops : 0));
       return;
     }
-    if (EPI == 1 && st + 1 >= 2 * R && st + 1 < nsteps)
-      stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io of the next output plane
+    if ((EPI == 1 || EPI == 5) && st + 1 >= 2 * R && st + 1 < nsteps)
+      stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io (b) of the next output plane
     if (more) stage(next_plane(), r_cur);           // plane st + 3, two phases ahead
     // (The x pass of plane st + 1 and the y / z passes of plane st are independent,
     // but letting half of the waves of a SIMD run them in the opposite order, so that
@@ -837,7 +893,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
 #pragma unroll 1
   for (int st0 = 0; st0 < nsteps; st0 += M) {
     blur3_phases<0, M>(st0, nsteps, phase);
-    if constexpr (EPI >= 2) {
+    if constexpr (EPI >= 2 && EPI != 5) {
       sumsq += (double)sacc;
       gsum += (double)gacc;
       sacc = gacc = T(0);
@@ -870,7 +926,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
 
 // sum of the per-tile partials in a fixed order (block b: the b-th run of n partials)
 __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, int n,
-                                                            double *result) {
+                                                            double *result,
+                                                            double scale = 1.0) {
   __shared__ double s[kBlock];
   part += (size_t)blockIdx.x * n;
   double t = 0.0;
@@ -880,7 +937,7 @@ __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, 
   if (threadIdx.x == 0) {
     double r = 0.0;
     for (int i = 0; i < kBlock; ++i) r += s[i];
-    result[blockIdx.x] = r;
+    result[blockIdx.x] = r * scale;
   }
 }
 
@@ -959,7 +1016,7 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   constexpr int npieces = (frows * (dl + 2 * NBH) + 63) / 64;
   // own-position tiles staged beside the raw tiles: EPI 1 two (old io, double buffered),
   // EPI 3 two (y_prev, double buffered), EPI 4 two (q0 and y, one buffer each)
-  constexpr int otiles = EPI == 1 ? 2 : (EPI == 3 ? 2 : (EPI == 4 ? 2 : 0));
+  constexpr int otiles = EPI == 1 ? 2 : (EPI == 3 ? 2 : (EPI == 4 ? 2 : (EPI == 5 ? 2 : 0)));
   constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl +
                            (size_t)otiles * dtyr * dl) * 16;
   constexpr size_t lds_patch = 3 * (size_t)((frows * 4 + 63) / 64) * 16 * 16;   // (RAG)
@@ -1024,6 +1081,15 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                                        (int)lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return -2; }
   }
+  if constexpr (EPI == 5) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
+                       nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
+                       per_xcd, (T)ca, (T)cb, (T)cc, part, lz->aux1, (const T *)nullptr,
+                       (T *)nullptr, (const T *)nullptr);
+    hipLaunchKernelGGL(k_blur3_epi_final, dim3(1), dim3(kBlock), 0, st, part, (int)tiles,
+                       result, 0.5);                     // (1/2 sum rho, as nsol_loss_*)
+    return launch_status();
+  }
   if constexpr (EPI >= 3) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(NWD * 64), lds, st, x, out,
                        nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
@@ -1040,7 +1106,7 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                      (const T *)nullptr, (T *)nullptr, (const T *)nullptr);
   if (EPI != 0)
     hipLaunchKernelGGL(k_blur3_epi_final, dim3(EPI == 2 ? 2 : 1), dim3(kBlock), 0, st, part,
-                       (int)tiles, result);
+                       (int)tiles, result, 1.0);
   return launch_status();
   }
 }
@@ -1087,6 +1153,24 @@ int blur3_lanczos_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t n
 #undef NSOL_B3L_CASE
 }
 
+template <typename T>
+int blur3_loss_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
+                        const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, int ntaps,
+                        const LanczosArgs<T> &lz, int loss, double s2, double gm, double *result,
+                        double *part, int64_t part_doubles, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+#define NSOL_B3S_CASE(N)                                                                    \
+  case N:                                                                                   \
+    return launch_blur3_dma<T, VEC, N, 16, 5>(x, out, nz, ny, nx, tz, ty, tx, st, s2, gm,   \
+                                              (double)loss, result, part, part_doubles, &lz);
+  switch (ntaps) {
+    NSOL_B3S_CASE(5) NSOL_B3S_CASE(7) NSOL_B3S_CASE(9) NSOL_B3S_CASE(11) NSOL_B3S_CASE(13)
+    NSOL_B3S_CASE(15) NSOL_B3S_CASE(17)
+    default: return -2;
+  }
+#undef NSOL_B3S_CASE
+}
+
 }  // namespace
 
 #define NSOL_B3L_DEF(T)                                                                      \
@@ -1105,6 +1189,14 @@ int blur3_lanczos_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t n
     const LanczosArgs<T> lz{q0, y, nullptr, coef, board, step, rho_g, rho_i};                \
     return blur3_lanczos_dispatch<T, 4>(t, y_new, nz, ny, nx, tz, ty, tx, ntaps, lz, part,   \
                                         part_doubles, st);                                   \
+  }                                                                                          \
+  int blur3_loss_epilogue(const T *x, const T *b, T *g, int64_t nz, int64_t ny, int64_t nx,  \
+                          const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, int ntaps, \
+                          int loss, double s2, double gm, double *result, double *part,      \
+                          int64_t part_doubles, hipStream_t st) {                            \
+    const LanczosArgs<T> lz{b, nullptr, nullptr, nullptr, nullptr, 0, 0.0, 0.0};             \
+    return blur3_loss_dispatch<T>(x, g, nz, ny, nx, tz, ty, tx, ntaps, lz, loss, s2, gm,     \
+                                  result, part, part_doubles, st);                           \
   }                                                                                          \
   int blur3_lanczos_init(double *board, T *coef, double rho_g, double rho_i,                 \
                          hipStream_t st) {                                                   \

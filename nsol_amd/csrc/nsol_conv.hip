@@ -758,6 +758,25 @@ int lanczos_b_impl(const T *t, const T *q0, const T *y, T *y_new, int64_t nz, in
                          board, step, coef, ws, ws_doubles, as_stream(stream));
 }
 
+// nsol_corr3_wrap_loss_*: A x with the robust-loss data term as its epilogue
+// (nsol_blur3_dma.hpp, EPI 5); -2 where that form does not apply (the caller then runs
+// the blur and nsol_loss_residual_cost_grad_*)
+template <typename T>
+int loss_epilogue_impl(const T *x, const T *b, T *g, int64_t nz, int64_t ny, int64_t nx,
+                       const double *tz_host, const double *ty_host, const double *tx_host,
+                       int ntaps, int loss, double f_scale, double *result, double *ws,
+                       int64_t ws_doubles, void *stream) {
+  if (!x || !b || !g || x == g || b == g || !tz_host || !ty_host || !tx_host || !result ||
+      !ws || nz < 1 || ny < 1 || nx < 1 || loss < 0 || loss > 4 || !(f_scale > 0.0))
+    return NSOL_EINVAL;
+  if (loss != NSOL_LOSS_LINEAR && loss != NSOL_LOSS_SOFT_L1 && loss != NSOL_LOSS_HUBER)
+    return -2;                       // (log1p / atan in double do not fit the blur's registers)
+  Taps<T> tz, ty, tx;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  return blur3_loss_epilogue(x, b, g, nz, ny, nx, tz, ty, tx, ntaps, loss, f_scale * f_scale,
+                             1.345, result, ws, ws_doubles, as_stream(stream));
+}
+
 template <typename T, int VEC, int NT>
 int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                  const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, bool symmetric,
@@ -995,6 +1014,18 @@ int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t 
   }
 NSOL_LANCZOS_DEF(float, f32)
 NSOL_LANCZOS_DEF(double, f64)
+#define NSOL_LOSS_EPI_DEF(T, SUF)                                                         \
+  int nsol_corr3_wrap_loss_##SUF(const T *x, const T *b, T *g, int64_t nz, int64_t ny,    \
+                                 int64_t nx, const double *taps_z, const double *taps_y,  \
+                                 const double *taps_x, int ntaps, int loss,               \
+                                 double f_scale, double *result, double *ws,              \
+                                 int64_t ws_doubles, void *stream) {                      \
+    return loss_epilogue_impl<T>(x, b, g, nz, ny, nx, taps_z, taps_y, taps_x, ntaps,      \
+                                 loss, f_scale, result, ws, ws_doubles, stream);          \
+  }
+NSOL_LOSS_EPI_DEF(float, f32)
+NSOL_LOSS_EPI_DEF(double, f64)
+#undef NSOL_LOSS_EPI_DEF
 #undef NSOL_LANCZOS_DEF
 int nsol_corr_dense_f32(const float *x, float *out, int64_t nz, int64_t ny,
                         int64_t nx, const float *taps, int kz, int ky, int kx,

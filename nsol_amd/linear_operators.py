@@ -236,6 +236,15 @@ class ConvolutionOperator(DeviceOperator):
             return ops.corr3_lanczos_b(t, q0, y, y_new, in_shape, tz, ty, tx, lb, step)
         return half_a, half_b
 
+    def apply_loss(self, x, b, in_shape, loss, f_scale, result):
+        """rho'(r^2) r for r = A x - b with 1/2 sum rho(r^2) in the device slot `result`,
+        from the one-pass blur (ops.corr3_wrap_loss); None where it does not apply."""
+        if not (USE_FUSED_BLUR3 and USE_BLUR_EPILOGUE and self._passes and
+                len(in_shape) == 3 and self._fusable3()):
+            return None
+        return ops.corr3_wrap_loss(x, b, in_shape, self._passes[0][1], self._passes[1][1],
+                                   self._passes[2][1], loss, f_scale, result)
+
     def _apply(self, x, in_shape):
         if len(in_shape) != self.dimension:
             raise RuntimeError("%dD convolution applied to %d axes" %

@@ -261,6 +261,28 @@ def corr3_lanczos_a(y, y_prev, t, q0, shape, taps_z, taps_y, taps_x, lb, step):
     return True
 
 
+def corr3_wrap_loss(x, b, shape, taps_z, taps_y, taps_x, loss, f_scale, result):
+    """rho'(r^2) r for r = blur(x) - b with 1/2 sum rho(r^2) in result[0] (the caller's
+    device slot), from the blur itself; None when that kernel does not apply (nothing
+    launched): then corr3_wrap and loss_cost_grad(minus=b)."""
+    _same(x, b)
+    ndim, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(v, dtype=np.float64)
+                  for v in (taps_z, taps_y, taps_x))
+    if ndim != 3 or nz * ny * nx != x.numel() or not (tz.size == ty.size == tx.size):
+        return None
+    ws, _ = _workspace(x.device)
+    g = empty_like(x)
+    rc = _fn("corr3_wrap_loss", x)(
+        _p(x), _p(b), _p(g), nz, ny, nx, tz.ctypes.data, ty.ctypes.data, tx.ctypes.data,
+        int(tz.size), LOSSES[loss], float(f_scale), _p(result), _p(ws), int(ws.numel()),
+        stream_ptr())
+    if rc == -2:
+        return None
+    _lib.check(rc, "nsol_corr3_wrap_loss")
+    return g
+
+
 def corr3_lanczos_b(t, q0, y, y_new, shape, taps_z, taps_y, taps_x, lb, step):
     """Second half: y_new = ca blur(t) + q0 + cy y with |y_new|^2 onto the board."""
     _same(t, q0, y, y_new)

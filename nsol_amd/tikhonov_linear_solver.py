@@ -47,6 +47,10 @@ REUSE_OBJECTIVE_AT_X0 = True
 # from the kernel that forms it (nsol_tk1_reg_objective_*) instead of a pass and a
 # read-back each (B = gradient only)
 USE_OBJECTIVE_EXTRAS = True
+# robust-loss objective with A = nsol_amd's blur and B = gradient: the data term
+# rho'(r^2) r, 1/2 sum rho(r^2) as the epilogue of A x (nsol_corr3_wrap_loss_*) instead
+# of a pass over a stored A x
+USE_LOSS_EPILOGUE = True
 
 
 # A^T b for the (operator, data) pairs seen last: an outer loop (ADMM, primal-dual
@@ -349,8 +353,24 @@ class TikhonovLinearSolver(LinearSolver):
             if use_reg and USE_FUSED_TK1_REG else None
 
         slots = []
+        # A = nsol_amd's blur seen through the caller's lambda: the data term as the
+        # epilogue of A x (no A x in memory, no pass of its own)
+        blur_loss = None
+        if native is not None and USE_LOSS_EPILOGUE:
+            d = trace_operator(self._A, b.numel())
+            if d is not None and d[0] == "conv" and int(np.prod(d[2])) == b.numel() \
+                    and hasattr(d[1], "apply_loss"):
+                blur_loss = (d[1], tuple(d[2]))
 
         def fun_and_grad(x, extras=None):
+            if blur_loss is not None:
+                import torch
+                if not slots:
+                    slots.append(torch.empty(4, dtype=torch.float64, device=x.device))
+                g = blur_loss[0].apply_loss(x, b, blur_loss[1], loss, fscale,
+                                            slots[0][0:1])
+                if g is not None:
+                    return finish(x, g, extras)
             r = A(x)
             # in place unless A handed x itself back (an identity operator)
             own = r.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()
@@ -369,20 +389,7 @@ class TikhonovLinearSolver(LinearSolver):
                 _, g = ops.loss_cost_grad(r, loss, fscale,
                                           out=r if own else None, minus=b,
                                           result=slots[0][0:1])
-                grad = A_adj(g)
-                shape, w = native
-                if extras is not None:
-                    d, lo, hi = extras
-                    ops.tk1_reg_objective(x, grad, d, shape, w, alpha, lo, hi,
-                                          out=grad, result=slots[0][1:4])
-                    sums = slots[0].cpu()
-                    return (float(sums[0]) + alpha * (0.5 * float(sums[1])), grad,
-                            float(sums[2]) if d is not None else None,
-                            float(sums[3]))
-                _, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
-                                                out=grad, result=slots[0][1:2])
-                sums = slots[0][:2].cpu()
-                return float(sums[0]) + alpha * (0.5 * float(sums[1])), grad
+                return finish(x, g, extras)
             cost, g = ops.loss_cost_grad(r, loss, fscale, out=r if own else None,
                                          minus=b)
             grad = A_adj(g)
@@ -392,6 +399,24 @@ class TikhonovLinearSolver(LinearSolver):
                 cost = cost + alpha * (0.5 * ops.dot(Bx, Bx))
                 grad = ops.lincomb2(1.0, grad, alpha, B_adj(Bx))
             return cost, grad
+
+        def finish(x, g, extras):
+            """The rest of the native evaluation from g = rho'(r^2) r (its cost waits in
+            slots[0][0])."""
+            grad = A_adj(g)
+            shape, w = native
+            if extras is not None:
+                d, lo, hi = extras
+                ops.tk1_reg_objective(x, grad, d, shape, w, alpha, lo, hi,
+                                      out=grad, result=slots[0][1:4])
+                sums = slots[0].cpu()
+                return (float(sums[0]) + alpha * (0.5 * float(sums[1])), grad,
+                        float(sums[2]) if d is not None else None,
+                        float(sums[3]))
+            _, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
+                                            out=grad, result=slots[0][1:2])
+            sums = slots[0][:2].cpu()
+            return float(sums[0]) + alpha * (0.5 * float(sums[1])), grad
         if native is not None and USE_OBJECTIVE_EXTRAS:
             # (f, g, g'd, |proj g|_inf) from the same kernels: lbfgsb.minimize's protocol
             fun_and_grad.with_extras = lambda x, d, lo, hi: fun_and_grad(x, (d, lo, hi))

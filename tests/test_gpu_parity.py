@@ -920,6 +920,74 @@ def test_objective_pass_also_gives_the_line_search_its_scalars(nsol, dtype, shap
     assert torch.equal(g, ref) and float(slots[1]) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("lossname", ["linear", "soft_l1", "huber"])
+@pytest.mark.parametrize("shape,sigma", [((40, 36, 64), 2.0), ((33, 48, 128), 1.0),
+                                         ((64, 64, 64), 1.5), ((17, 70, 96), 0.8)])
+def test_blur_takes_the_loss_as_its_epilogue(nsol, dtype, lossname, shape, sigma):
+    """nsol_corr3_wrap_loss_*: rho'(r^2) r for r = A x - b bit for bit what
+    nsol_corr3_wrap_* and nsol_loss_residual_cost_grad_* produce, the cost to the
+    order of its sum."""
+    import torch
+    import nsol_amd.linear_operators as LO
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    lo = LO.LinearOperators3D()
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([sigma ** 2] * 3))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.rand(n, device="cuda", dtype=td, generator=gen)
+    b = torch.rand(n, device="cuda", dtype=td, generator=gen)
+    r = A(x.view(*shape)).reshape(-1)
+    cost, g_ref = ops.loss_cost_grad(r.clone(), lossname, 0.1, minus=b)
+    slot = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g = A.apply_loss(x, b, shape, lossname, 0.1, slot)
+    if g is None:
+        ntaps = len(A._passes[0][1])
+        assert ntaps < 5 or ntaps > (13 if dtype == np.float32 else 9)
+        return
+    assert torch.equal(g, g_ref)
+    assert abs(float(slot[0]) - cost) <= 1e-13 * abs(cost)
+
+
+def test_blur_epilogue_leaves_the_heavy_losses_to_the_loss_kernel(nsol):
+    import torch
+    import nsol_amd.linear_operators as LO
+    lo = LO.LinearOperators3D()
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([4.0] * 3))
+    x = torch.rand(32 * 32 * 64, device="cuda")
+    slot = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for lossname in ("cauchy", "arctan"):
+        assert A.apply_loss(x, x.clone(), (32, 32, 64), lossname, 0.1, slot) is None
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_objective_with_the_loss_in_the_blur_matches_the_separate_passes(nsol, golden,
+                                                                         dtype):
+    """TikhonovLinearSolver's device objective (minimizer='L-BFGS-B', Huber loss) with
+    the data term taken by the blur (USE_LOSS_EPILOGUE) against blur, loss kernel:
+    the gradient bit for bit, the cost to the order of its sum."""
+    import torch
+    import nsol_amd.tikhonov_linear_solver as tk
+    g, shape, A, Aa, D, Da = _dec_ops(golden, "3d")
+    y = g["y_3d"]
+    out = []
+    for flag in (False, True):
+        tk.USE_LOSS_EPILOGUE = flag
+        try:
+            s = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=D, B_adj=Da, b=y, x0=y,
+                                        alpha=0.05, x_scale=float(y.max()), iter_max=3,
+                                        minimizer="L-BFGS-B", data_loss="huber",
+                                        data_loss_scale=0.1, dtype=dtype)
+            f = s._device_objective()
+            x = s._x0_device().clone() * 0.9
+            out.append(f(x))
+        finally:
+            tk.USE_LOSS_EPILOGUE = True
+    assert torch.equal(out[0][1], out[1][1])
+    assert abs(out[0][0] - out[1][0]) <= 1e-13 * abs(out[0][0])
+
+
 @pytest.mark.parametrize("k,dtype", [("1d", np.float64), ("2d", np.float32),
                                      ("3d", np.float32), ("3d", np.float64)])
 def test_lbfgsb_with_the_scalars_from_the_objective_pass(nsol, golden, k, dtype):
