@@ -241,7 +241,9 @@ def cpu_baseline_lbfgsb(sample_n, iter_max):
 # with the reduced gradient formed in the same pass
 def lb_bytes(c):
     return {"k_mdots": 4 * (2 * c + 1) + 1, "k_wcomb": 4 * (2 * c + 2) + 1,
-            "k_masked_gram_dma": 4 * (2 * c + 4) + 1}
+            "k_masked_gram_mfma": 4 * (2 * c + 4) + 1,
+            # the 2c vectors, r, xcp, x, g and the mask read; xn and d written
+            "k_subspace_step": 4 * (2 * c + 4) + 1 + 8}
 
 
 def time_kernels_lbfgsb(shape, c=10, reps=6):
@@ -261,8 +263,10 @@ def time_kernels_lbfgsb(shape, c=10, reps=6):
     coef = list(np.linspace(0.1, 1.0, c))
     fns = {"k_mdots": lambda: be.dots(wy + ws, x, free),
            "k_wcomb": lambda: be.subspace_direction(z, ws, wy, coef, coef, 0.7, free),
-           "k_masked_gram_dma": lambda: be.masked_grams_rgrad(
-               ws, wy, free, z, x, g, 0.7, coef, coef)}
+           "k_masked_gram_mfma": lambda: be.masked_grams_rgrad(
+               ws, wy, free, z, x, g, 0.7, coef, coef),
+           "k_subspace_step": lambda: be.subspace_step(
+               z, ws, wy, coef, coef, 0.7, free, x, x, g, 0.0, float("inf"))}
     ev = HipEvents()
     stream = torch.cuda.current_stream().cuda_stream
     out = {}
@@ -285,9 +289,10 @@ def time_kernels_lbfgsb(shape, c=10, reps=6):
 def count_lbfgsb_calls(run):
     """Calls of the O(m n) products during one (untimed) run."""
     from nsol_amd.lbfgsb_device import DeviceBackend
-    counts = {"k_mdots": 0, "k_wcomb": 0, "k_masked_gram_dma": 0}
+    counts = {"k_mdots": 0, "k_wcomb": 0, "k_masked_gram_mfma": 0, "k_subspace_step": 0}
     orig = {k: getattr(DeviceBackend, k) for k in
-            ("dots", "_wcomb", "masked_grams_rgrad")}
+            ("dots", "_wcomb", "masked_grams_rgrad", "subspace_step",
+             "cauchy_setup_dots")}
 
     def wrap(name, key):
         def f(self, *a, **kw):
@@ -296,7 +301,9 @@ def count_lbfgsb_calls(run):
         return f
     DeviceBackend.dots = wrap("dots", "k_mdots")
     DeviceBackend._wcomb = wrap("_wcomb", "k_wcomb")
-    DeviceBackend.masked_grams_rgrad = wrap("masked_grams_rgrad", "k_masked_gram_dma")
+    DeviceBackend.masked_grams_rgrad = wrap("masked_grams_rgrad", "k_masked_gram_mfma")
+    DeviceBackend.subspace_step = wrap("subspace_step", "k_subspace_step")
+    DeviceBackend.cauchy_setup_dots = wrap("cauchy_setup_dots", "k_mdots")
     try:
         run()
     finally:

@@ -702,15 +702,19 @@ int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
  * registers (scipy's lnsrlb / projgr behind tikhonov_linear_solver.py:214-220):
  * result[0] = sum |K x|^2, result[1] = grad'd (d may be NULL: 0), result[2] =
  * max_i |P(x - grad)_i - x_i| for the bounds lo <= x <= hi (+-INFINITY: none), as
- * nsol_dot_* and nsol_lb_projgr_* return them.  grad as above.
- * ws: 3 * nsol_hip_reduce_ws_doubles() doubles; result: device double[3]. */
+ * nsol_dot_* and nsol_lb_projgr_* return them; with gold (the gradient at the start of
+ * the iteration; may be NULL) ydiff = grad - gold and result[3] = its sum of squares,
+ * as nsol_lb_diff_dots_* (the y of the BFGS update, scipy's matupd).  grad as above.
+ * ws: 4 * nsol_hip_reduce_ws_doubles() doubles; result: device double[4]. */
 int nsol_tk1_reg_objective_f32(const float *x, const float *g, float *grad,
-                               const float *d, int ndim, int64_t nz, int64_t ny,
+                               const float *d, const float *gold, float *ydiff,
+                               int ndim, int64_t nz, int64_t ny,
                                int64_t nx, double wx, double wy, double wz,
                                double alpha, double lo, double hi, double *result,
                                double *ws, void *stream);
 int nsol_tk1_reg_objective_f64(const double *x, const double *g, double *grad,
-                               const double *d, int ndim, int64_t nz, int64_t ny,
+                               const double *d, const double *gold, double *ydiff,
+                               int ndim, int64_t nz, int64_t ny,
                                int64_t nx, double wx, double wy, double wz,
                                double alpha, double lo, double hi, double *result,
                                double *ws, void *stream);

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
                                                      const T *g, T *grad, Geom<T> G,
                                                      T alpha, double *ws,
                                                      const T *z = nullptr, T c_g = T(1),
-                                                     T c_x = T(0), T c_z = T(0)) {
+                                                     T c_x = T(0), T c_z = T(0),
+                                                     const T *gold = nullptr,
+                                                     T *ydiff = nullptr) {
   // MODE 0: grad = g + alpha K'K x, sum |K x|^2.  MODE 1: the sum only (nothing read
   // but x, nothing written).  MODE 2: the three-term Lanczos update of the normal
   // equations, grad = c_g g + alpha K'K x + c_x x + c_z z (z may be null) with the
@@ -257,10 +259,11 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
   // MODE 3: MODE 0 with what L-BFGS-B asks of every new gradient while it is in
   // registers: its product with the search direction z (may be null) and the largest
   // |projected gradient| for the bounds c_x <= x <= c_z (+-inf: none), as
-  // nsol_dot_* / nsol_lb_projgr_* form them; three partials per workgroup, the second
-  // and third kReducePartials and 2 kReducePartials doubles behind the first.
+  // nsol_dot_* / nsol_lb_projgr_* form them, and (gold, ydiff given) the change of the
+  // gradient ydiff = grad - gold with its sum of squares as nsol_lb_diff_dots_* does;
+  // four partials per workgroup, kReducePartials doubles apart.
   const int64_t nrg = row_groups<T, VEC, ROWS>(G);
-  double acc = 0.0, accd = 0.0, pg = 0.0;
+  double acc = 0.0, accd = 0.0, pg = 0.0, accy = 0.0;
   for (int64_t rg = blockIdx.y; rg < nrg; rg += gridDim.y) {
     const Voxel c = voxel_at<T, VEC, ROWS>(G, rg);
     if (!c.ok) continue;
@@ -331,6 +334,15 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
             }
             pg = fmax(pg, fabs((double)gi));
           }
+        if (gold) {
+          vlc<RAG, T, VEC>(c, gold + c.i, nb);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            nb[k] = T(1) * out[k] + T(-1) * nb[k];
+            if (!RAG || k < c.nval) accy += (double)nb[k] * (double)nb[k];
+          }
+          vs<RAG, T, VEC>(c.nval, ydiff + c.i, nb);
+        }
       }
     } else {
 #pragma unroll
@@ -361,13 +373,15 @@ __global__ __launch_bounds__(kBlock) void k_tk1_reg(const T *__restrict__ x,
       for (int k = 0; k < kBlock / kWave; ++k) t = fmax(t, smax[k]);
       ws[2 * (int64_t)kReducePartials + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
     }
+    __syncthreads();
+    store_partial3(accy, ws + 3 * (int64_t)kReducePartials);
   } else {
     store_partial3(acc, ws);
   }
 }
 
-// result[0], result[1]: sums of the first two runs of partials; result[2]: maximum of
-// the third (one workgroup each, fixed order)
+// result[0], [1], [3]: sums of the first, second and fourth run of partials; result[2]:
+// maximum of the third (one workgroup each, fixed order)
 __global__ __launch_bounds__(1024) void k_final_objective(const double *ws, int64_t nparts,
                                                            double *result) {
   const bool is_max = blockIdx.x == 2;
@@ -490,22 +504,26 @@ int tk1_reg_impl(const T *x, const T *g, T *grad, int ndim, int64_t nz, int64_t 
 
 // MODE 3 of k_tk1_reg (see there): result[0] = sum |K x|^2, [1] = grad'd, [2] = max |proj grad|
 template <typename T>
-int tk1_objective_impl(const T *x, const T *g, T *grad, const T *d, int ndim, int64_t nz,
+int tk1_objective_impl(const T *x, const T *g, T *grad, const T *d, const T *gold, T *ydiff,
+                       int ndim, int64_t nz,
                        int64_t ny, int64_t nx, double wx, double wy, double wz, double alpha,
                        double lo, double hi, double *result, double *ws, void *stream) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (!x || !g || !grad || !result || !ws || x == grad || d == grad) return NSOL_EINVAL;
+  if (!x || !g || !grad || !result || !ws || x == grad || d == grad || (gold && !ydiff) ||
+      (gold && (gold == grad || ydiff == grad || ydiff == x || ydiff == g || ydiff == d)))
+    return NSOL_EINVAL;
   const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
-  const bool al = ptr16(x) && ptr16(g) && ptr16(grad) && (!d || ptr16(d)) && G.n % 4 == 0;
+  const bool al = ptr16(x) && ptr16(g) && ptr16(grad) && (!d || ptr16(d)) &&
+                  (!gold || (ptr16(gold) && ptr16(ydiff))) && G.n % 4 == 0;
   return dispatch_stencil<T>(nz, ny, nx, al, [&](auto vec, auto rows, auto rag) {
     constexpr int V = decltype(vec)::value, R = decltype(rows)::value;
     constexpr bool RG = decltype(rag)::value;
     const int64_t nb = grid_blocks<V, R>(nz, ny, nx);
     hipLaunchKernelGGL((k_tk1_reg<T, V, R, RG, 3>), (stencil_grid<V, R>(nz, ny, nx)),
                        dim3(kBlock), 0, as_stream(stream), x, g, grad, G, (T)alpha, ws, d,
-                       T(1), (T)lo, (T)hi);
-    hipLaunchKernelGGL(k_final_objective, dim3(3), dim3(1024), 0, as_stream(stream), ws, nb,
-                       result);
+                       T(1), (T)lo, (T)hi, gold, ydiff);
+    hipLaunchKernelGGL(k_final_objective, dim3(gold ? 4 : 3), dim3(1024), 0,
+                       as_stream(stream), ws, nb, result);
     return launch_status();
   });
 }
@@ -620,12 +638,13 @@ int nsol_tk1_reg_cost_grad_f64(const double *x, const double *g, double *grad,
                                alpha, c_g, c_x, c_z, result, ws, stream);        \
   }                                                                              \
   int nsol_tk1_reg_objective_##SUF(const T *x, const T *g, T *grad, const T *d,  \
+                                   const T *gold, T *ydiff,                      \
                                    int ndim, int64_t nz, int64_t ny, int64_t nx, \
                                    double wx, double wy, double wz, double alpha, \
                                    double lo, double hi, double *result,         \
                                    double *ws, void *stream) {                   \
-    return tk1_objective_impl<T>(x, g, grad, d, ndim, nz, ny, nx, wx, wy, wz,    \
-                                 alpha, lo, hi, result, ws, stream);             \
+    return tk1_objective_impl<T>(x, g, grad, d, gold, ydiff, ndim, nz, ny, nx,   \
+                                 wx, wy, wz, alpha, lo, hi, result, ws, stream); \
   }
 NSOL_TK1_DEF(float, f32)
 NSOL_TK1_DEF(double, f64)

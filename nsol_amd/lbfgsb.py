@@ -349,9 +349,10 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
     info["pg"]); the first evaluation is then not repeated (it still counts in
     nfev, as scipy would report it).
 
-    fun_and_grad.with_extras(x, d, lo, hi) -> (f, g, g'd or None, |proj g|_inf), when
-    the objective offers it, replaces the evaluation, backend.dot(g, d) and
-    backend.projgr(x, g, lo, hi) of every new point (d may be None)."""
+    fun_and_grad.with_extras(x, d, lo, hi, gold) -> (f, g, g'd or None, |proj g|_inf,
+    g - gold or None, its squared norm or None), when the objective offers it, replaces
+    the evaluation, backend.dot(g, d), backend.projgr(x, g, lo, hi) and
+    backend.diff_dots(g, gold) of every new point (d, gold may be None)."""
     be = backend
     # A backend whose kernels want whole vectors (DeviceBackend.pad_to: 16
     # elements -- 16-byte accesses and one mask byte per element) gets the
@@ -370,11 +371,12 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
         if start is not None:
             start = (start[0], be.pad(start[1], n_pad)) + tuple(start[2:])
         if getattr(fun_and_grad, "with_extras", None) is not None:
-            def padded_extras(xp, dp, lo_, hi_):
-                f, g, gd, pg = fun_and_grad.with_extras(
+            def padded_extras(xp, dp, lo_, hi_, goldp=None):
+                f, g, gd, pg, yd, rr = fun_and_grad.with_extras(
                     be.head(xp, n_in), None if dp is None else be.head(dp, n_in),
-                    lo_, hi_)
-                return f, be.pad(g, n_pad), gd, pg
+                    lo_, hi_, None if goldp is None else be.head(goldp, n_in))
+                return (f, be.pad(g, n_pad), gd, pg,
+                        None if yd is None else be.pad(yd, n_pad), rr)
             padded.with_extras = padded_extras
         xp, info = minimize(padded, be.pad(x0, n_pad), lo, hi, be,
                             maxiter=maxiter, m=m, factr=factr, pgtol=pgtol,
@@ -395,7 +397,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
         f, g = start[0], start[1]
         pg = start[2] if len(start) > 2 else None
     elif ext is not None:
-        f, g, _, pg = ext(x, None, lo, hi)
+        f, g, _, pg = ext(x, None, lo, hi)[:4]
     else:
         f, g = fun_and_grad(x)
     nfgv = 1
@@ -500,6 +502,7 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
         # and gradient are kept by reference)
         xold = x
         gold = g
+        ynew = rrnew = None
         fold = f
         gdold = gd
         restart = False
@@ -532,11 +535,11 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 else:
                     x = be.lincomb2(stp, d, 1.0, xold)
                 if ext is not None:
-                    f, g, gd, pg = ext(x, d, lo, hi)
+                    f, g, gd, pg, ynew, rrnew = ext(x, d, lo, hi, gold)
                 else:
                     f, g = fun_and_grad(x)
                     gd = be.dot(g, d)
-                    pg = None
+                    pg = ynew = rrnew = None
                 ls.step(f, gd)
             stp = ls.stp
         if restart:
@@ -566,7 +569,10 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             info["task"] = "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"
             break
         # ---------------- BFGS update ---------------------------------------
-        r, rr, _ = be.diff_dots(g, gold)          # y = g - g_old, y'y
+        if ynew is not None:
+            r, rr = ynew, rrnew                   # (came with the last evaluation)
+        else:
+            r, rr, _ = be.diff_dots(g, gold)      # y = g - g_old, y'y
         if stp == 1.0:
             dr = gd - gdold
             ddum = -gdold

@@ -494,22 +494,26 @@ def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None, result=None):
 _ws3 = {}
 
 
-def tk1_reg_objective(x, g, d, shape, w, alpha, lo, hi, out, result):
+def tk1_reg_objective(x, g, d, shape, w, alpha, lo, hi, out, result, gold=None,
+                      ydiff=None):
     """tk1_reg_cost_grad with the new gradient's product with d (None: 0) and its
-    largest projected component for lo <= x <= hi in result[1], result[2] (result:
-    the caller's three-element float64 device slots; nothing is read back here)."""
+    largest projected component for lo <= x <= hi in result[1], result[2]; with gold,
+    ydiff = out - gold and its sum of squares in result[3] (result: the caller's
+    four-element float64 device slots; nothing is read back here)."""
     _same(x, g)
     if d is not None:
         _same(x, d)
+    if gold is not None:
+        _same(x, gold, ydiff)
     ndim, nz, ny, nx = dims3(shape)
     key = (x.device.index, stream_ptr())
     if key not in _ws3:
-        _ws3[key] = torch.empty(3 * _lib.load().nsol_hip_reduce_ws_doubles(),
+        _ws3[key] = torch.empty(4 * _lib.load().nsol_hip_reduce_ws_doubles(),
                                 dtype=torch.float64, device=x.device)
     _lib.check(_fn("tk1_reg_objective", x)(
-        _p(x), _p(g), _p(out), _p(d), ndim, nz, ny, nx, w[0], w[1], w[2], float(alpha),
-        float(lo), float(hi), _p(result), _p(_ws3[key]), stream_ptr()),
-        "nsol_tk1_reg_objective")
+        _p(x), _p(g), _p(out), _p(d), _p(gold), _p(ydiff), ndim, nz, ny, nx, w[0], w[1],
+        w[2], float(alpha), float(lo), float(hi), _p(result), _p(_ws3[key]),
+        stream_ptr()), "nsol_tk1_reg_objective")
     return out
 
 

@@ -366,7 +366,7 @@ class TikhonovLinearSolver(LinearSolver):
             if blur_loss is not None:
                 import torch
                 if not slots:
-                    slots.append(torch.empty(4, dtype=torch.float64, device=x.device))
+                    slots.append(torch.empty(5, dtype=torch.float64, device=x.device))
                 g = blur_loss[0].apply_loss(x, b, blur_loss[1], loss, fscale,
                                             slots[0][0:1])
                 if g is not None:
@@ -384,7 +384,7 @@ class TikhonovLinearSolver(LinearSolver):
                 # every new gradient: no pass of their own, no further read-back)
                 import torch
                 if not slots:
-                    slots.append(torch.empty(4, dtype=torch.float64,
+                    slots.append(torch.empty(5, dtype=torch.float64,
                                              device=r.device))
                 _, g = ops.loss_cost_grad(r, loss, fscale,
                                           out=r if own else None, minus=b,
@@ -406,20 +406,25 @@ class TikhonovLinearSolver(LinearSolver):
             grad = A_adj(g)
             shape, w = native
             if extras is not None:
-                d, lo, hi = extras
+                d, lo, hi, gold = extras
+                ydiff = ops.empty_like(grad) if gold is not None else None
                 ops.tk1_reg_objective(x, grad, d, shape, w, alpha, lo, hi,
-                                      out=grad, result=slots[0][1:4])
+                                      out=grad, result=slots[0][1:5], gold=gold,
+                                      ydiff=ydiff)
                 sums = slots[0].cpu()
                 return (float(sums[0]) + alpha * (0.5 * float(sums[1])), grad,
                         float(sums[2]) if d is not None else None,
-                        float(sums[3]))
+                        float(sums[3]), ydiff,
+                        float(sums[4]) if gold is not None else None)
             _, grad = ops.tk1_reg_cost_grad(x, grad, shape, w, alpha,
                                             out=grad, result=slots[0][1:2])
             sums = slots[0][:2].cpu()
             return float(sums[0]) + alpha * (0.5 * float(sums[1])), grad
         if native is not None and USE_OBJECTIVE_EXTRAS:
-            # (f, g, g'd, |proj g|_inf) from the same kernels: lbfgsb.minimize's protocol
-            fun_and_grad.with_extras = lambda x, d, lo, hi: fun_and_grad(x, (d, lo, hi))
+            # (f, g, g'd, |proj g|_inf, g - gold, its squared norm) from the same kernels:
+            # lbfgsb.minimize's protocol
+            fun_and_grad.with_extras = lambda x, d, lo, hi, gold=None: \
+                fun_and_grad(x, (d, lo, hi, gold))
         return fun_and_grad
 
     _warm_start = None              # set by the outer solver (see _run_minimize)

@@ -906,7 +906,7 @@ def test_objective_pass_also_gives_the_line_search_its_scalars(nsol, dtype, shap
     d = torch.randn(n, device="cuda", dtype=td, generator=gen)
     w = ops.inv_spacing(np.ones(len(shape)) * 0.7, len(shape))
     cost, ref = ops.tk1_reg_cost_grad(x, g, shape, w, 0.37)
-    slots = torch.zeros(3, dtype=torch.float64, device="cuda")
+    slots = torch.zeros(4, dtype=torch.float64, device="cuda")
     out = ops.tk1_reg_objective(x, g, d, shape, w, 0.37, lo, hi,
                                 out=torch.empty_like(g), result=slots)
     got = slots.cpu().numpy()
@@ -915,6 +915,14 @@ def test_objective_pass_also_gives_the_line_search_its_scalars(nsol, dtype, shap
     gd = ops.dot(ref, d)
     assert abs(got[1] - gd) <= 1e-13 * float(ref.abs().double() @ d.abs().double())
     assert got[2] == DeviceBackend().projgr(x, ref, lo, hi)
+    # with the gradient of the iteration's start: the BFGS update's y and y'y
+    gold = torch.randn(n, device="cuda", dtype=td, generator=gen)
+    y = torch.empty_like(g)
+    ops.tk1_reg_objective(x, g, d, shape, w, 0.37, lo, hi, out=torch.empty_like(g),
+                          result=slots, gold=gold, ydiff=y)
+    y_ref, yy, _ = DeviceBackend().diff_dots(ref, gold)
+    assert torch.equal(y, y_ref)
+    assert abs(float(slots[3]) - yy) <= 1e-13 * yy
     # in place on g, no direction
     ops.tk1_reg_objective(x, g, None, shape, w, 0.37, lo, hi, out=g, result=slots)
     assert torch.equal(g, ref) and float(slots[1]) == 0.0

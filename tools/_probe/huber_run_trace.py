@@ -17,7 +17,7 @@ from nsol_amd import lbfgsb  # noqa: E402
 from nsol_amd.synthetic import synth_volume  # noqa: E402
 
 
-def factory(n):
+def factory(n, minimizer="L-BFGS-B", loss="huber"):
     shape = (n, n, n)
     lo = LO.LinearOperators3D()
     A, A_adj = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
@@ -34,14 +34,16 @@ def factory(n):
                                                  generator=gen)
     return lambda: admm.ADMMLinearSolver(
         A=A_, A_adj=Aa_, b=y, B=D_, B_adj=Da_, x0=y, dimension=3, alpha=0.01,
-        rho=0.1, iterations=10, iter_max=10, minimizer="L-BFGS-B",
-        data_loss="huber", x_scale=float(y.max()), dtype=np.float32)
+        rho=0.1, iterations=10, iter_max=10, minimizer=minimizer,
+        data_loss=loss, x_scale=float(y.max()), dtype=np.float32)
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     runs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    make = factory(n)
+    minimizer = sys.argv[3] if len(sys.argv) > 3 else "L-BFGS-B"
+    loss = sys.argv[4] if len(sys.argv) > 4 else "huber"
+    make = factory(n, minimizer, loss)
     infos = []
     orig = lbfgsb.minimize
 
