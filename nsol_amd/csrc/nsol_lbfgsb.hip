@@ -765,6 +765,12 @@ __global__ __launch_bounds__(kBlock) void k_gram2_final(const double *ws, int nb
 // staging, the reduced gradient (RG) and the workspace layout are k_masked_gram_dma's.
 // Products of widened floats are exact in double, so the sums differ from the VALU
 // form only in their (fixed) order.
+// measurement builds (tools/_probe/build_variant_lb.sh -DGRAM_ABLATE=n): 1 no products,
+// 2 no reduced gradient, 4 no staging.  At 512^3 and ten stored pairs (gram / gram + r, ms,
+// same box): 2.30 / 2.72 as built; staging alone 1.72 / 2.02; arithmetic alone 1.50 / 2.09.
+#ifndef GRAM_ABLATE
+#define GRAM_ABLATE 0
+#endif
 template <typename T, int TB, int NB, bool RG>
 __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_mfma(
     GramPtrs<T> P, int nvec, const int8_t *iw, int64_t n, double *ws,
@@ -854,11 +860,11 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_mfma(
   for (; t < ntiles; t += step) {
     const int64_t t2 = t + 2 * step;
     int nxt2 = cur + 2; if (nxt2 >= kGram2Bufs) nxt2 -= kGram2Bufs;
-    if (t2 < ntiles) stage(t2, nxt2);
+    if (t2 < ntiles && !(GRAM_ABLATE & 4)) stage(t2, nxt2);
     const unsigned char *bufp = gram_raw + cur * buf_bytes;
     const int64_t base = t * kTile;
     int stored = 0;                                    // (wave-uniform) stores of r issued
-    if constexpr (RG) {
+    if constexpr (RG && !(GRAM_ABLATE & 2)) {
       // one element of r per lane (k_wcomb's sum, same order: the rows beyond nvec hold
       // zeros and carry zero coefficients), by the last kRWaves waves on top of their
       // groups -- element-wise so that half the waves share the work (two waves with a
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_mfma(
         R.out[base + e] = accv;
       }
     }
-    {
+    if constexpr (!(GRAM_ABLATE & 1)) {
       constexpr int G = kGroups / kGram2Waves;             // groups of this wave per tile
       const unsigned char *mine = bufp + r4 * kPitch + (wave * 16 + vox) * (int)sizeof(T);
       const unsigned char *mk = bufp + mask_at + wave * 16 + vox;
@@ -926,7 +932,7 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_mfma(
             acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[bi], a[bj], acc[p], 0, 0, 0);
       }
     }
-    sync_keep((t2 < ntiles && full(t2)) ? my_pieces + stored : 0);
+    sync_keep((t2 < ntiles && full(t2) && !(GRAM_ABLATE & 4)) ? my_pieces + stored : 0);
     if (++cur == kGram2Bufs) cur = 0;
   }
   // the four voxel quarters of every entry, then the waves, in a fixed order
