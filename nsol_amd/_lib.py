@@ -84,6 +84,8 @@ def load():
     lib.nsol_hip_set_param_pdk.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_hip_set_param_lb.restype = c_int
     lib.nsol_hip_set_param_lb.argtypes = [ctypes.c_char_p, c_int]
+    lib.nsol_hip_set_param_sort.restype = c_int
+    lib.nsol_hip_set_param_sort.argtypes = [ctypes.c_char_p, c_int]
     lib.nsol_hip_set_param_pdp.restype = c_int
     lib.nsol_hip_set_param_pdp.argtypes = [ctypes.c_char_p, c_int]
     if lib.nsol_hip_abi_version() != 1:
@@ -109,7 +111,7 @@ PARAM_DEFAULTS = {
     "pdk_xcd_map": 1, "pdk_verbose": 0, "pdk_autotune": 1, "pdk_pf2": -1,
     "pdk_split": -1, "pdk_tail2": 1, "pdk_min_kvox": 1024, "pdk_tune_min_mvox": 16,
     "pdp_max_spin": 1 << 21, "pdp_mute_tile": -1,
-    "corr_ra": 8, "corr_xv": 1, "corr_blur3_lxb": 16, "corr_blur3_zchunk": 0, "corr_blur3_dma": 1, "corr_blur3_dma_rag": 1, "lb_gram_dma": 1, "lb_gram_mfma": 1,
+    "corr_ra": 8, "corr_xv": 1, "corr_blur3_lxb": 16, "corr_blur3_zchunk": 0, "corr_blur3_dma": 1, "corr_blur3_dma_rag": 1, "lb_gram_dma": 1, "lb_gram_mfma": 1, "sort_walk_by_key": 1,
 }
 _touched = set()
 
@@ -135,6 +137,8 @@ def set_param(name, value):
         fn = lib.nsol_hip_set_param_conv
     elif name.startswith("lb_"):
         fn = lib.nsol_hip_set_param_lb
+    elif name.startswith("sort_"):
+        fn = lib.nsol_hip_set_param_sort
     else:
         fn = lib.nsol_hip_set_param
     check(fn(name.encode(), int(value)), "set_param")

@@ -4,6 +4,7 @@
 // a plain library primitive); the result is deterministic: indices are sorted
 // first, then stably by key, so ties keep index order whatever order the
 // compaction kernel produced.
+#include <cstring>
 #include <hipcub/hipcub.hpp>
 
 #include "nsol_common.hpp"
@@ -227,11 +228,30 @@ __global__ void k_walk_out(int K, int col2, double f1, double f2, double dtm,
   }
 }
 
+// The 2 col columns of a stage (G -> Pcum, then H -> Ccum) lie one behind the other in
+// the table: ONE scan by key (key = position / K, the column) takes all of them -- the
+// walk of a window then issues 4 scans whatever col is, where one scan per column made
+// 4 col + 2 (84 tiny launches per window at ten stored pairs).
+struct ColumnOf {
+  int64_t K;
+  __host__ __device__ int operator()(int64_t pos) const { return (int)(pos / K); }
+};
+typedef hipcub::TransformInputIterator<int, ColumnOf, hipcub::CountingInputIterator<int64_t>>
+    ColumnKeys;
+
+int g_walk_by_key = 1;           // 0: one hipCUB scan per column (the A/B form)
+
 inline size_t scan_bytes(int K) {
   size_t b = 0;
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const double *)nullptr,
                                          (double *)nullptr, K);
-  return b;
+  // (the scan by key over all columns of a stage at the largest memory)
+  size_t bk = 0;
+  const ColumnKeys keys(hipcub::CountingInputIterator<int64_t>(0), ColumnOf{K > 0 ? K : 1});
+  (void)hipcub::DeviceScan::InclusiveSumByKey(nullptr, bk, keys, (const double *)nullptr,
+                                              (double *)nullptr,
+                                              (size_t)2 * kMaxCol * (size_t)(K > 0 ? K : 1));
+  return b > bk ? b : bk;
 }
 
 template <typename T>
@@ -263,10 +283,20 @@ int walk_impl(const T *tbk, const T *d, const T *x, const int64_t *idx, int K,
     const hipError_t r = hipcub::DeviceScan::InclusiveSum(tmp, tb, in, outp, K, st);
     if (ce == hipSuccess) ce = r;
   };
-  for (int j = 0; j < col2; ++j) scan(C.G + (int64_t)j * K, C.Pcum + (int64_t)j * K);
+  auto scan_columns = [&](const double *in, double *outp) {
+    if (g_walk_by_key && col2 > 1) {
+      const ColumnKeys keys(hipcub::CountingInputIterator<int64_t>(0), ColumnOf{K});
+      const hipError_t r = hipcub::DeviceScan::InclusiveSumByKey(
+          tmp, tb, keys, in, outp, (size_t)col2 * (size_t)K, hipcub::Equality(), st);
+      if (ce == hipSuccess) ce = r;
+    } else {
+      for (int j = 0; j < col2; ++j) scan(in + (int64_t)j * K, outp + (int64_t)j * K);
+    }
+  };
+  scan_columns(C.G, C.Pcum);
   if (col2 > 0) {
     hipLaunchKernelGGL(k_walk_h, g, b, 0, st, K, col2, params, C);
-    for (int j = 0; j < col2; ++j) scan(C.G + (int64_t)j * K, C.Ccum + (int64_t)j * K);
+    scan_columns(C.G, C.Ccum);
     hipLaunchKernelGGL(k_walk_quad, g, b, 0, st, K, col2, params, C);
   }
   scan(C.inc2, C.f2cum);
@@ -285,6 +315,12 @@ int walk_impl(const T *tbk, const T *d, const T *x, const int64_t *idx, int K,
 }  // namespace
 
 extern "C" {
+/* experiment knob of this file: "sort_walk_by_key" */
+int nsol_hip_set_param_sort(const char *name, int value) {
+  if (!name || strcmp(name, "sort_walk_by_key")) return NSOL_EINVAL;
+  g_walk_by_key = value;
+  return 0;
+}
 int64_t nsol_lb_walk_table_doubles(int count, int col) {
   return (int64_t)(8 + 8 * (int64_t)col) * (count > 0 ? count : 1);
 }

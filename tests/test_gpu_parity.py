@@ -820,6 +820,39 @@ def test_device_lbfgsb_tracks_scipy(nsol):
         assert rel_l2(x.cpu().numpy(), ref.x) < 1e-9
 
 
+def test_cauchy_walk_scans_all_columns_of_a_stage_at_once(nsol):
+    """The prefix-sum walk of the Cauchy search with ONE scan by key per stage
+    (nsol_sort.hip, sort_walk_by_key) against one hipCUB scan per column: the same
+    iterations and evaluations, iterates equal to the order of the sums."""
+    import torch
+    from nsol_amd import _lib, lbfgsb
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    rng = np.random.default_rng(11)
+    n = 3000
+    A = rng.standard_normal((n + 5, n)) / np.sqrt(n)
+    b = 3.0 * rng.standard_normal(n + 5)
+
+    def fg_dev(xd):
+        x = xd.cpu().numpy()
+        r = A @ x - b
+        z = r * r
+        return (float(np.sum(np.sqrt(1 + z) - 1)),
+                torch.from_numpy(A.T @ (r / np.sqrt(1 + z))).cuda())
+    x0 = torch.from_numpy(2.0 * rng.standard_normal(n) + 1.0).cuda()
+    out = []
+    for by_key in (1, 0):
+        _lib.set_param("sort_walk_by_key", by_key)
+        try:
+            for k in lbfgsb.STATS:
+                lbfgsb.STATS[k] = 0
+            x, info = lbfgsb.minimize(fg_dev, x0, 0.0, 1.0, DeviceBackend(), maxiter=14)
+            out.append((x.cpu().numpy(), info["nit"], info["nfev"], lbfgsb.STATS["crossed"]))
+        finally:
+            _lib.set_param("sort_walk_by_key", 1)
+    assert out[0][1:] == out[1][1:] and out[0][3] > 100
+    assert rel_l2(out[0][0], out[1][0]) < 1e-12
+
+
 @pytest.mark.parametrize("k", ["1d", "2d", "3d"])
 def test_admm_lbfgsb_huber_matches_reference_goldens(nsol, golden, k,
                                                      lbfgsb_form):
