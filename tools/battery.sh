@@ -46,4 +46,7 @@ python3 tools/summarize_pmc.py k_ $O/${TAG}_admm_pmc_fetch $O/${TAG}_admm_pmc_wr
 # ... and of the L-BFGS-B / Huber branch
 timeout -k 10 400 bash tools/profile_admm_pmc_huber.sh ${TAG}
 python3 tools/summarize_pmc.py k_ $O/${TAG}_huber_pmc_fetch $O/${TAG}_huber_pmc_write > $O/${TAG}_admm_lbfgsb_huber_pmc.jsonl
+# one Huber run's kernel list and the GPU's idle time in it
+bash tools/_probe/huber_run_trace.sh ${TAG} > /dev/null 2>&1
+(grep -E "^run|sum nit|cauchy" $O/${TAG}_huber_trace.log; python3 tools/_probe/trace_gaps.py $O/${TAG}_huber_trace/p_kernel_trace.csv 3 -v | tail -34) > $O/${TAG}_huber_run_trace.txt
 echo BATTERY_DONE

@@ -15,6 +15,10 @@ for d in admm_lsmr admm_lbfgsb pd_deconv blur3_stats; do f=$(find gpurun_out/${T
 mv profiles/${T}_admm_lbfgsb_kernel_stats.csv profiles/${T}_admm_lbfgsb_huber_kernel_stats.csv
 mv profiles/${T}_blur3_stats_kernel_stats.csv profiles/${T}_blur3_kernel_stats.csv
 grep '"metric"' gpurun_out/${T}_stats.log | tail -1 > profiles/${T}_bench_profiled.json
+if [ -f gpurun_out/${T}_huber_run_trace.txt ]; then
+  cp gpurun_out/${T}_huber_run_trace.txt profiles/${T}_huber_run_trace.txt
+  cp gpurun_out/${T}_huber_trace/p_kernel_stats.csv profiles/${T}_huber_run_kernel_stats.csv
+fi
 if [ -n "$OLD" ]; then
   git rm -q --cached profiles/${OLD}_* 2>/dev/null || true
   rm -f profiles/${OLD}_*
