@@ -824,6 +824,23 @@ int nsol_lb_subspace_step_f64(const double *const *w_host, const double *wcoef_h
                               const double *g, const int8_t *iwhere, int64_t n,
                               double scale, double lo, double hi, double *xn, double *d,
                               double *result, double *ws, void *stream);
+/* The same with r formed in the pass instead of read,
+ *   r = free ? rb3[0]*xcp + rb3[1]*x + rb3[2]*g + sum_j rcoef[j]*w[j] : 0
+ * (nsol_lb_wcomb_*'s sum term for term -- scipy's cmprlb), from the values the step
+ * holds anyway: nsol_lb_masked_gram_rgrad_* then runs with r_out = NULL.  rb3_host /
+ * rcoef_host: HOST arrays of 3 / nw doubles. */
+int nsol_lb_subspace_step_r_f32(const float *const *w_host, const double *wcoef_host, int nw,
+                                const double *rb3_host, const double *rcoef_host,
+                                const float *xcp, const float *x, const float *g,
+                                const int8_t *iwhere, int64_t n, double scale, double lo,
+                                double hi, float *xn, float *d, double *result, double *ws,
+                                void *stream);
+int nsol_lb_subspace_step_r_f64(const double *const *w_host, const double *wcoef_host, int nw,
+                                const double *rb3_host, const double *rcoef_host,
+                                const double *xcp, const double *x, const double *g,
+                                const int8_t *iwhere, int64_t n, double scale, double lo,
+                                double hi, double *xn, double *d, double *result, double *ws,
+                                void *stream);
 int64_t nsol_lb_gram_ws_doubles(void);
 int nsol_lb_masked_gram_f32(const float *const *vecs, int nvec, const int8_t *iwhere,
                             int64_t n, double *result, double *ws, void *stream);
@@ -843,7 +860,8 @@ int nsol_lb_masked_gram_f64(const double *const *vecs, int nvec, const int8_t *i
  * Returns -2 (nothing launched) where
  * the LDS-DMA staged kernel does not apply (n not a multiple of 16, unaligned
  * arrays, no room for the three extra rows): call nsol_lb_masked_gram_* and
- * nsol_lb_wcomb_* then. */
+ * nsol_lb_wcomb_* then.  r_out may be NULL (matrix and products only: the caller
+ * leaves r to nsol_lb_subspace_step_r_*). */
 int nsol_lb_masked_gram_rgrad_f32(const float *const *vecs, int nvec,
                                   const int8_t *iwhere, int64_t n, double *result,
                                   double *ws, const float *const *base3,

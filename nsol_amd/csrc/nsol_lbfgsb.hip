@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_dma(
     int nxt2 = cur + 2; if (nxt2 >= kGram2Bufs) nxt2 -= kGram2Bufs;
     if (t2 < ntiles) stage(t2, nxt2);
     int stored = 0;                                    // (wave-uniform) stores of r issued
-    if constexpr (RG) {
+    if (RG && R.out != nullptr) {
       // One 16-byte group of r per lane and trip (k_wcomb's sum, same order), by the
       // waves that own no pair block -- 15 block pairs x 64 shares leave the sixteenth
       // wave free at ten stored pairs.  (On the first lanes instead, two waves did this
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(kGram2Threads) void k_masked_gram_mfma(
     const unsigned char *bufp = gram_raw + cur * buf_bytes;
     const int64_t base = t * kTile;
     int stored = 0;                                    // (wave-uniform) stores of r issued
-    if constexpr (RG && !(GRAM_ABLATE & 2)) {
+    if (RG && !(GRAM_ABLATE & 2) && R.out != nullptr) {   // (R.out null: the caller forms r later)
       // one element of r per lane (k_wcomb's sum, same order: the rows beyond nvec hold
       // zeros and carry zero coefficients), by the last kRWaves waves on top of their
       // groups -- element-wise so that half the waves share the work (two waves with a
@@ -1066,7 +1066,7 @@ int masked_gram_dma_launch(const GramPtrs<T> &P, int nvec, const int8_t *iwhere,
   if (rg) {
     for (int k = 0; k < 3; ++k)
       if (!rg->base[k] || ((uintptr_t)rg->base[k] & 15u)) return -2;
-    if (!rg->out || ((uintptr_t)rg->out & 15u)) return -2;
+    if (rg->out && ((uintptr_t)rg->out & 15u)) return -2;
     if (g_gram_mfma) {
       const int rc = masked_gram_mfma_dispatch<T, true>(P, nvec, iwhere, n, result, ws, st, *rg);
       if (rc != -2) return rc;
@@ -1526,19 +1526,28 @@ inline T cast_bound(double b) {
 // the 2c + 3 sums come from one read of W (105 bytes per voxel at ten stored pairs
 // instead of 215).  The arithmetic per value is that of the four kernels, in the same
 // order; the sums are accumulated per lane in the order k_diff_dots / k_mdots use.
+// RIN: r is not read but formed here, r = free ? rb[0] xcp + rb[1] x + rb[2] g + sum_j
+// rcoef[j] W_j : 0 -- nsol_lb_wcomb_*'s sum (scipy's cmprlb) term for term in its order,
+// from the values the step holds anyway (the Gram pass then neither forms nor stores r,
+// and this pass does not read it).
 template <typename T>
 struct SubStep {
   const T *w[kDotsMax];
   T wcoef[kDotsMax];
   int nw;
 };
+template <typename T>
+struct SubStepR {
+  T rb[3];
+  T rcoef[kDotsMax];
+};
 
-template <typename T, int VEC, int NV>
+template <typename T, int VEC, int NV, bool RIN = false>
 __global__ __launch_bounds__(kBlock) void k_subspace_step(
     SubStep<T> C, const T *__restrict__ r, const T *__restrict__ xcp,
     const T *__restrict__ x, const T *__restrict__ g, const int8_t *iw, int64_t n,
     T scale, T lo, T hi, bool has_lo, bool has_hi, T *__restrict__ xn_out,
-    T *__restrict__ d_out, double *ws) {
+    T *__restrict__ d_out, double *ws, SubStepR<T> RC = SubStepR<T>()) {
   typedef T V __attribute__((ext_vector_type(VEC)));
   typedef int8_t M __attribute__((ext_vector_type(VEC)));
   double a[NV + 3];                          // hits, d'd, g'd, W_j'd
@@ -1551,12 +1560,26 @@ __global__ __launch_bounds__(kBlock) void k_subspace_step(
 #pragma unroll
     for (int k = 0; k < NV; ++k)
       wv[k] = k < C.nw ? reinterpret_cast<const V *>(C.w[k])[j] : V(T(0));
-    const V rv = reinterpret_cast<const V *>(r)[j];
     const V cv = reinterpret_cast<const V *>(xcp)[j];
     const V xv = reinterpret_cast<const V *>(x)[j];
     const V gv = reinterpret_cast<const V *>(g)[j];
     M m = M((int8_t)0);
     if (iw) m = reinterpret_cast<const M *>(iw)[j];
+    V rv;
+    if constexpr (RIN) {
+      rv = V(T(0));
+      rv += RC.rb[0] * cv;
+      rv += RC.rb[1] * xv;
+      rv += RC.rb[2] * gv;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        if (k < C.nw) rv += RC.rcoef[k] * wv[k];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (m[e] > 0) rv[e] = T(0);
+    } else {
+      rv = reinterpret_cast<const V *>(r)[j];
+    }
     V acc = V(T(0));
     acc += T(1) * rv;
 #pragma unroll
@@ -1601,9 +1624,11 @@ template <typename T>
 int subspace_step_impl(const T *const *w_host, const double *wcoef_host, int nw,
                        const T *r, const T *xcp, const T *x, const T *g,
                        const int8_t *iwhere, int64_t n, double scale, double lo, double hi,
-                       T *xn, T *d, double *result, double *ws, void *stream) {
-  if (n < 1 || nw < 1 || !w_host || !wcoef_host || !r || !xcp || !x || !g || !xn || !d ||
-      !result || !ws)
+                       T *xn, T *d, double *result, double *ws, void *stream,
+                       const double *rb3_host = nullptr, const double *rcoef_host = nullptr) {
+  // r == NULL: formed in the kernel from rb3_host / rcoef_host (both then required)
+  if (n < 1 || nw < 1 || !w_host || !wcoef_host || (!r && (!rb3_host || !rcoef_host)) ||
+      !xcp || !x || !g || !xn || !d || !result || !ws)
     return NSOL_EINVAL;
   if (nw > kDotsMax) return -2;
   constexpr int VW = 16 / sizeof(T);
@@ -1625,14 +1650,26 @@ int subspace_step_impl(const T *const *w_host, const double *wcoef_host, int nw,
     return -2;
   const int gr = rgrid(n / VW);
   const T tlo = cast_bound<T>(lo), thi = cast_bound<T>(hi);
-  if (nw > 12)
+  SubStepR<T> RC;
+  for (int k = 0; k < 3; ++k) RC.rb[k] = (!r) ? (T)rb3_host[k] : T(0);
+  for (int k = 0; k < kDotsMax; ++k) RC.rcoef[k] = (!r && k < nw) ? (T)rcoef_host[k] : T(0);
+  if (!r) {
+    if (nw > 12)
+      hipLaunchKernelGGL((k_subspace_step<T, VW, kDotsMax, true>), dim3(gr), dim3(kBlock), 0,
+                         as_stream(stream), C, r, xcp, x, g, iwhere, n, (T)scale, tlo, thi,
+                         lo > -INFINITY, hi < INFINITY, xn, d, ws, RC);
+    else
+      hipLaunchKernelGGL((k_subspace_step<T, VW, 12, true>), dim3(gr), dim3(kBlock), 0,
+                         as_stream(stream), C, r, xcp, x, g, iwhere, n, (T)scale, tlo, thi,
+                         lo > -INFINITY, hi < INFINITY, xn, d, ws, RC);
+  } else if (nw > 12)
     hipLaunchKernelGGL((k_subspace_step<T, VW, kDotsMax>), dim3(gr), dim3(kBlock), 0,
                        as_stream(stream), C, r, xcp, x, g, iwhere, n, (T)scale, tlo, thi,
-                       lo > -INFINITY, hi < INFINITY, xn, d, ws);
+                       lo > -INFINITY, hi < INFINITY, xn, d, ws, RC);
   else
     hipLaunchKernelGGL((k_subspace_step<T, VW, 12>), dim3(gr), dim3(kBlock), 0,
                        as_stream(stream), C, r, xcp, x, g, iwhere, n, (T)scale, tlo, thi,
-                       lo > -INFINITY, hi < INFINITY, xn, d, ws);
+                       lo > -INFINITY, hi < INFINITY, xn, d, ws, RC);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(kBlock), 0, as_stream(stream), ws, gr, nw + 3,
                      false, result);
   // result[nw + 3] = -(smallest feasible step ratio), -inf when no variable limits it
@@ -1646,7 +1683,7 @@ template <typename T>
 int gram_rgrad(const T *const *vecs, int nvec, const int8_t *iwhere, int64_t n,
                double *result, double *ws, const T *const *base3,
                const double *bcoef3, const double *wcoef, T *r_out, void *stream) {
-  if (!base3 || !bcoef3 || !wcoef || !r_out || nvec > kGram2MaxVec) return NSOL_EINVAL;
+  if (!base3 || !bcoef3 || !wcoef || nvec > kGram2MaxVec) return NSOL_EINVAL;
   GramRG<T> R;
   for (int k = 0; k < 3; ++k) { R.base[k] = base3[k]; R.bcoef[k] = (T)bcoef3[k]; }
   for (int k = 0; k < kGram2MaxVec; ++k) R.wcoef[k] = k < nvec ? (T)wcoef[k] : T(0);
@@ -1731,6 +1768,28 @@ int nsol_lb_subspace_step_f64(const double *const *w_host, const double *wcoef_h
                               double *result, double *ws, void *stream) {
   return subspace_step_impl<double>(w_host, wcoef_host, nw, r, xcp, x, g, iwhere, n, scale,
                                     lo, hi, xn, d, result, ws, stream);
+}
+int nsol_lb_subspace_step_r_f32(const float *const *w_host, const double *wcoef_host, int nw,
+                                const double *rb3_host, const double *rcoef_host,
+                                const float *xcp, const float *x, const float *g,
+                                const int8_t *iwhere, int64_t n, double scale, double lo,
+                                double hi, float *xn, float *d, double *result, double *ws,
+                                void *stream) {
+  if (!rb3_host || !rcoef_host) return NSOL_EINVAL;
+  return subspace_step_impl<float>(w_host, wcoef_host, nw, nullptr, xcp, x, g, iwhere, n,
+                                   scale, lo, hi, xn, d, result, ws, stream, rb3_host,
+                                   rcoef_host);
+}
+int nsol_lb_subspace_step_r_f64(const double *const *w_host, const double *wcoef_host, int nw,
+                                const double *rb3_host, const double *rcoef_host,
+                                const double *xcp, const double *x, const double *g,
+                                const int8_t *iwhere, int64_t n, double scale, double lo,
+                                double hi, double *xn, double *d, double *result, double *ws,
+                                void *stream) {
+  if (!rb3_host || !rcoef_host) return NSOL_EINVAL;
+  return subspace_step_impl<double>(w_host, wcoef_host, nw, nullptr, xcp, x, g, iwhere, n,
+                                    scale, lo, hi, xn, d, result, ws, stream, rb3_host,
+                                    rcoef_host);
 }
 int nsol_lb_masked_gram_rgrad_f32(const float *const *vecs, int nvec,
                                   const int8_t *iwhere, int64_t n, double *result,

@@ -33,6 +33,10 @@ FUSE_SUBSPACE_STEP = True
 # read back together where the backend offers it (cauchy_setup + W'd; the count of
 # free variables + the subspace matrix)
 MERGE_READBACKS = True
+# True: where the backend's subspace step can form the reduced gradient r itself
+# (subspace_step_forms_r), the Gram pass neither forms nor stores it and the step does
+# not read it; r becomes an array only on the rare path that needs one
+DEFER_REDUCED_GRADIENT = True
 # False: [Y S]'Z r by a pass of its own even when the Gram pass delivered it
 USE_GRAM_RHS = True
 BIG = 1.0e10
@@ -445,15 +449,19 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
                 coef_y = mc[:col]
                 coef_s = theta * mc[col:]
                 if hasattr(be, "masked_grams_rgrad"):
+                    kw = {}
+                    if DEFER_REDUCED_GRADIENT and FUSE_SUBSPACE_STEP and USE_GRAM_RHS and \
+                            getattr(be, "subspace_step_forms_r", False):
+                        kw["want_r"] = False
                     if late_count:
                         fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
-                                                      coef_s, coef_y, count=True)
+                                                      coef_s, coef_y, count=True, **kw)
                         if fused is not None:
                             nfree = fused[-1]
                             fused = fused[:-1]
                     else:
                         fused = be.masked_grams_rgrad(ws, wy, free, z, x, g, theta,
-                                                      coef_s, coef_y)
+                                                      coef_s, coef_y, **kw)
             if nfree < 0:
                 nfree = be.count_free(iwhere)
         if nfree != 0 and col != 0:       # (a late count may have found none free)
@@ -465,15 +473,22 @@ def minimize(fun_and_grad, x0, lo, hi, backend, maxiter=10, m=10,
             fac = form_k(cm, yzzy, szzs, szzy)
             if fac is None:
                 ok = False
+            rdef = None
             if ok and r is None:
                 if not cnstnd and col > 0:
                     r = be.scale(g, -1.0)
+                elif fused is not None and wtzr is not None:
+                    # (deferred: the subspace step forms it; an array only if asked for)
+                    rdef = (coef_y, coef_s,
+                            lambda: be.reduced_gradient(z0, x, g, theta, ws, wy, coef_s,
+                                                        coef_y, free))
+                    z0 = z
                 else:
                     r = be.reduced_gradient(z, x, g, theta, ws, wy, coef_s,
                                             coef_y, free)
             if ok:
                 z, step = _subsm(be, z, r, x, g, lo, hi, ws, wy, cm, fac, free,
-                                 wtzr if USE_GRAM_RHS else None)
+                                 wtzr if USE_GRAM_RHS else None, rdef)
             else:
                 # refresh the memory and restart the iteration
                 cm.reset()
@@ -806,15 +821,19 @@ def _cauchy(be, x, g, lo, hi, iwhere, ws, wy, cm, sbgnrm):
     return xcp, c, iwhere
 
 
-def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free, wtzr=None):
+def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free, wtzr=None, rdef=None):
     """Subspace minimisation over the free variables at the Cauchy point with
     the projection refinement; returns the new point.  wtzr: [Y S]'Z r when the
-    backend's Gram pass already produced it."""
+    backend's Gram pass already produced it.  rdef (r is None then): (coef_y,
+    coef_s, make_r) -- the W part of r for a backend whose subspace step forms r
+    itself, and a callable that returns r as an array for the paths that need one."""
     col, theta = cm.col, cm.theta
     wv = np.zeros(2 * col)
     if wtzr is not None:
         both = np.asarray(wtzr)
     else:
+        if r is None:
+            r = rdef[2]()
         both = np.asarray(be.dots(wy + ws, r, free))   # one pass, one read-back
     wv[:col] = both[:col]
     wv[col:] = theta * both[col:]
@@ -825,13 +844,19 @@ def _subsm(be, xcp, r, x, g, lo, hi, ws, wy, cm, fac, free, wtzr=None):
     # vectors with d that the BFGS update will ask for -- from ONE pass over them
     fused = None
     if FUSE_SUBSPACE_STEP and hasattr(be, "subspace_step"):
-        fused = be.subspace_step(r, ws, wy, wv[:col] / theta, wv[col:], theta,
-                                 free, xcp, x, g, lo, hi)
+        if r is None:
+            fused = be.subspace_step(None, ws, wy, wv[:col] / theta, wv[col:], theta,
+                                     free, xcp, x, g, lo, hi, rdef=rdef[:2])
+        else:
+            fused = be.subspace_step(r, ws, wy, wv[:col] / theta, wv[col:], theta,
+                                     free, xcp, x, g, lo, hi)
     if fused is not None:
         xnew, hit, dvec, dtd, gd, sd, yd, ratio = fused
         # (g'd of the projected point IS subsm's directional derivative dd_p)
         if not hit or gd <= 0.0:
             return xnew, (dvec, dtd, gd, sd, yd, ratio)
+    if r is None:
+        r = rdef[2]()
     d = be.subspace_direction(r, ws, wy, wv[:col] / theta, wv[col:], theta,
                               free)
     if fused is None:

@@ -162,8 +162,12 @@ class DeviceBackend(object):
         ss = np.triu(h[1]) + np.triu(h[1], 1).T
         return yy, ss, h[2]
 
+    # subspace_step can form r = Z(-theta (xcp - x) - g + W M c) itself (rdef=...): the
+    # Gram pass then runs with want_r=False and r never exists as an array
+    subspace_step_forms_r = True
+
     def masked_grams_rgrad(self, ws_list, wy_list, free, z, x, g, theta, coef_s,
-                           coef_y, count=False):
+                           coef_y, count=False, want_r=True):
         """masked_grams and reduced_gradient from ONE pass over the 2c vectors
         (nsol_lb_masked_gram_rgrad_*), with [Y S]'Z r (Y first) for the subspace
         right-hand side; None where that kernel does not apply.  count: the number
@@ -182,7 +186,7 @@ class DeviceBackend(object):
                                         dtype=torch.float64, device=like.device)
         npairs = nv * (nv + 1) // 2
         out = torch.empty(npairs + nv + 1, dtype=torch.float64, device=like.device)
-        r = torch.empty_like(like)
+        r = torch.empty_like(like) if want_r else None
         ptrs = (ctypes.c_void_p * nv)(*[v.data_ptr() for v in vecs])
         base = (ctypes.c_void_p * 3)(z.data_ptr(), x.data_ptr(), g.data_ptr())
         bco = np.array([-theta, theta, -1.0], dtype=np.float64)
@@ -420,7 +424,7 @@ class DeviceBackend(object):
                            list(cy) + list(cs))
 
     def subspace_step(self, r, ws_list, wy_list, cy, cs, theta, free, xcp, x, g,
-                      lo, hi):
+                      lo, hi, rdef=None):
         """subspace_direction + project_step + diff_dots(xn, x, g) + the products
         of every stored vector with d = xn - x, from one pass over the stored
         vectors.  Returns (xn, hit, d, d'd, g'd, S'd, Y'd, ratio) -- ratio: the
@@ -431,19 +435,30 @@ class DeviceBackend(object):
         if nw < 1:
             return None
         lib = _lib.load()
-        if self._gram_ws is None or self._gram_ws.device != r.device:
+        if self._gram_ws is None or self._gram_ws.device != xcp.device:
             self._gram_ws = torch.empty(int(lib.nsol_lb_gram_ws_doubles()),
-                                        dtype=torch.float64, device=r.device)
+                                        dtype=torch.float64, device=xcp.device)
         PW = ctypes.c_void_p * nw
         wp = PW(*[w.data_ptr() for w in vecs])
         wc = np.ascontiguousarray(list(cy) + list(cs), dtype=np.float64)
-        out = torch.empty(nw + 4, dtype=torch.float64, device=r.device)
+        out = torch.empty(nw + 4, dtype=torch.float64, device=xcp.device)
         xn = torch.empty_like(xcp)
         d = torch.empty_like(xcp)
-        rc = _fn("subspace_step", r)(
-            ctypes.cast(wp, ctypes.c_void_p), wc.ctypes.data, nw, _p(r), _p(xcp),
-            _p(x), _p(g), _p(free), r.numel(), 1.0 / theta, float(lo), float(hi),
-            _p(xn), _p(d), _p(out), _p(self._gram_ws), stream_ptr())
+        if r is None:
+            # rdef = (coef_y, coef_s) of r's W part; its base part is scipy cmprlb's
+            # -theta (xcp - x) - g  (what reduced_gradient / masked_grams_rgrad use)
+            rb = np.array([-theta, theta, -1.0], dtype=np.float64)
+            rw = np.ascontiguousarray(list(rdef[0]) + list(rdef[1]), dtype=np.float64)
+            rc = _fn("subspace_step_r", xcp)(
+                ctypes.cast(wp, ctypes.c_void_p), wc.ctypes.data, nw, rb.ctypes.data,
+                rw.ctypes.data, _p(xcp), _p(x), _p(g), _p(free), xcp.numel(),
+                1.0 / theta, float(lo), float(hi), _p(xn), _p(d), _p(out),
+                _p(self._gram_ws), stream_ptr())
+        else:
+            rc = _fn("subspace_step", r)(
+                ctypes.cast(wp, ctypes.c_void_p), wc.ctypes.data, nw, _p(r), _p(xcp),
+                _p(x), _p(g), _p(free), r.numel(), 1.0 / theta, float(lo), float(hi),
+                _p(xn), _p(d), _p(out), _p(self._gram_ws), stream_ptr())
         if rc == -2:
             return None
         self._check(rc, "subspace_step")

@@ -2361,6 +2361,25 @@ def test_subspace_step_in_one_pass(nsol, dtype, c, n, lo, hi):
     assert abs(gd - gd_ref) <= 1e-12 * max(abs(gd_ref), np.sqrt(dtd_ref))
     scale = np.abs(wtd_ref).max() + 1e-300
     assert np.abs(np.concatenate([sd, yd]) - wtd_ref).max() <= 1e-12 * scale
+    # r formed by the step itself from the Cauchy point, x, g and W (the Gram pass then
+    # leaves it out): the reduced gradient of nsol_lb_wcomb_*, bit for bit
+    if free is not None:
+        coef_s = list(np.linspace(-0.7, 0.9, c))
+        coef_y = list(np.linspace(0.3, -1.1, c))
+        r2 = be.reduced_gradient(xcp, x, g, theta, ws, wy, coef_s, coef_y, free)
+        want = be.subspace_step(r2, ws, wy, cy, cs, theta, free, xcp, x, g, lo, hi)
+        have = be.subspace_step(None, ws, wy, cy, cs, theta, free, xcp, x, g, lo, hi,
+                                rdef=(coef_y, coef_s))
+        assert torch.equal(want[0], have[0]) and torch.equal(want[2], have[2])
+        assert want[1] == have[1] and want[3] == have[3] and want[4] == have[4]
+        assert np.array_equal(want[5], have[5]) and np.array_equal(want[6], have[6])
+        grams = be.masked_grams_rgrad(ws, wy, free, xcp, x, g, theta, coef_s, coef_y)
+        lean = be.masked_grams_rgrad(ws, wy, free, xcp, x, g, theta, coef_s, coef_y,
+                                     want_r=False)
+        if grams is not None:
+            assert lean[3] is None
+            for a, b in zip(grams[:3] + (grams[4],), lean[:3] + (lean[4],)):
+                assert np.array_equal(a, b)
     # lengths / addresses off the 16-byte grid: the caller's separate passes
     m = n - 3
     cut = lambda v: v[:m].clone()
