@@ -232,6 +232,35 @@ int nsol_corr3_wrap_lanczos_b_f64(const double *t, const double *q0, const doubl
                                   double rho_ident, double *board, int step, double *coef,
                                   double *ws, int64_t ws_doubles, void *stream);
 
+/* The leaner pair of halves (same board, same coefficients, same results bit for bit):
+ * _a2: t = A y with sum t^2 and sum |grad y|^2 onto the board (the blur of
+ * nsol_corr3_wrap_norms_*) and coef[4..5] for the second half -- no q0;  _b2:
+ * y_new = ca A t + (c1 K'K y + c0 y + c2 y_prev) + cy y with sum y_new^2, the step's
+ * K'K y formed from a halo'd tile of y inside the kernel (y_prev may be NULL).  25 B per
+ * voxel and step instead of 33.  Return -2 as _a / _b do. */
+int nsol_corr3_wrap_lanczos_a2_f32(const float *y, float *t, int64_t nz, int64_t ny,
+                                   int64_t nx, const double *taps_z, const double *taps_y,
+                                   const double *taps_x, int ntaps, double rho_grad,
+                                   double rho_ident, double *board, int step, float *coef,
+                                   double *ws, int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_lanczos_a2_f64(const double *y, double *t, int64_t nz, int64_t ny,
+                                   int64_t nx, const double *taps_z, const double *taps_y,
+                                   const double *taps_x, int ntaps, double rho_grad,
+                                   double rho_ident, double *board, int step, double *coef,
+                                   double *ws, int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_lanczos_b2_f32(const float *t, const float *y, const float *y_prev,
+                                   float *y_new, int64_t nz, int64_t ny, int64_t nx,
+                                   const double *taps_z, const double *taps_y,
+                                   const double *taps_x, int ntaps, double rho_grad,
+                                   double rho_ident, double *board, int step, float *coef,
+                                   double *ws, int64_t ws_doubles, void *stream);
+int nsol_corr3_wrap_lanczos_b2_f64(const double *t, const double *y, const double *y_prev,
+                                   double *y_new, int64_t nz, int64_t ny, int64_t nx,
+                                   const double *taps_z, const double *taps_y,
+                                   const double *taps_x, int ntaps, double rho_grad,
+                                   double rho_ident, double *board, int step, double *coef,
+                                   double *ws, int64_t ws_doubles, void *stream);
+
 /* The blur with the data term of the robust-loss objective as its epilogue
  * (tikhonov_linear_solver.py:201-208: `residual = A(x) - b`, `loss(residual^2)`,
  * `A_adj(gradient_loss * residual)`): g = rho'(r^2) r for r = A x - b and

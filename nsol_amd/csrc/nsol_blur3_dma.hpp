@@ -114,6 +114,27 @@ int blur3_loss_epilogue(const double *x, const double *b, double *g, int64_t nz,
                         int64_t nx, const Taps<double> &tz, const Taps<double> &ty,
                         const Taps<double> &tx, int ntaps, int loss, double s2, double gm,
                         double *result, double *part, int64_t part_doubles, hipStream_t st);
+// The leaner pair: half A is the EPI 2 blur (blur3_dma_run, epi 2: t = A y, its two sums in
+// result[0..1]) closed by blur3_lanczos_a2_close; half B (epi 6) forms the step's
+// c1 K'K y + c0 y + c2 y_prev itself: y_new = ca A t + that + cy y with sum y_new^2.
+__attribute__((visibility("hidden")))
+int blur3_lanczos_b2(const float *t, const float *y, const float *y_prev, float *y_new,
+                     int64_t nz, int64_t ny, int64_t nx, const Taps<float> &tz,
+                     const Taps<float> &ty, const Taps<float> &tx, int ntaps, double rho_g,
+                     double rho_i, double *board, int step, float *coef, double *part,
+                     int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_b2(const double *t, const double *y, const double *y_prev, double *y_new,
+                     int64_t nz, int64_t ny, int64_t nx, const Taps<double> &tz,
+                     const Taps<double> &ty, const Taps<double> &tx, int ntaps, double rho_g,
+                     double rho_i, double *board, int step, double *coef, double *part,
+                     int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_a2_close(const double *sums2, double *board, int step, double rho_g,
+                           double rho_i, float *coef, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_a2_close(const double *sums2, double *board, int step, double rho_g,
+                           double rho_i, double *coef, hipStream_t st);
 __attribute__((visibility("hidden")))
 int blur3_lanczos_init(double *board, float *coef, double rho_g, double rho_i, hipStream_t st);
 __attribute__((visibility("hidden")))
@@ -238,6 +259,16 @@ __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
 // ONE tile per array: a lane moves its values of this plane to registers first and the
 // next plane's piece is requested into the same tile (a wave only ever reads what its own
 // piece brought).
+//
+// EPI == 6: the second half of a Lanczos step WITH the step's K'K y (so that the first half
+// is EPI 2 and no q0 ever goes to memory: 25 B per voxel and step instead of 33):
+//   y_new = ca A t + (c1 K'K y + c0 y + c2 y_prev) + cy y,  sum y_new^2
+// with aux1 = y, aux2 = y_prev (may be null).  Plane j + 1 of y travels into ONE tile WITH
+// a one-vector / one-row halo while output plane j is worked on; a lane takes its own
+// vector and the in-plane part of K'K y of that plane from it at the start of a phase (the
+// values of EPI 3, in its order) and keeps y of the two planes before in registers for the
+// z part.  The neighbours come from other waves' pieces, so a barrier separates those reads
+// from the request for the next plane into the same tile (two tiles would not fit the LDS).
 //
 // EPI == 5: the data term of the robust-loss objective (tikhonov_linear_solver.py:
 // 201-208) as the epilogue of A x: with b = aux1 staged like EPI 1's old io tile, the
@@ -579,7 +610,31 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   T k0 = T(0), k1 = T(0), k2 = T(0);
   if constexpr (EPI == 3) { k0 = coef[0]; k1 = coef[1]; k2 = coef[2]; }   // c1, c0, c2
   if constexpr (EPI == 4) { k0 = coef[4]; k1 = coef[5]; }                   // ca, cy
-  const bool has_prev = EPI == 3 && aux1 != nullptr;
+  T k3 = T(0), k4 = T(0);
+  if constexpr (EPI == 6) {                                                 // c1, c0, c2, ca, cy
+    k0 = coef[0]; k1 = coef[1]; k2 = coef[2]; k3 = coef[4]; k4 = coef[5];
+  }
+  const bool has_prev = (EPI == 3 && aux1 != nullptr) || (EPI == 6 && aux2 != nullptr);
+  // (EPI 6) the halo'd tile of y: (tyr + 2) rows of lxb + 2 vectors behind the own-position
+  // tile; piece k = wave + j * NW of it (two at most) from a clamped position
+  constexpr int hrl = lxb + 2;
+  constexpr int halo_vecs = (tyr + 2) * hrl;
+  constexpr int hpieces = (halo_vecs + 63) >> 6;
+  static_assert(EPI != 6 || hpieces <= 2 * NW, "halo tile: two pieces per wave");
+  uint32_t yh_off[2] = {0, 0};
+  if constexpr (EPI == 6) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int i = (wave + j * NW) * 64 + lane;
+      if (i >= halo_vecs) i = 0;
+      int64_t yy = y0 + i / hrl - 1;
+      yy = yy < 0 ? 0 : (yy >= ny ? ny - 1 : yy);
+      int xx = bx * lxb + i % hrl - 1;
+      xx = xx < 0 ? 0 : (xx >= nxv ? nxv - 1 : xx);
+      yh_off[j] = (uint32_t)(yy * nx + (int64_t)xx * VEC);
+    }
+  }
+  V ym1 = splat<V, T>(T(0)), y0c = splat<V, T>(T(0)), lap0 = splat<V, T>(T(0));
   auto put = [&](int64_t z, V val, int ob) {
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + z * plane, 0, plane_bytes,
                                                         0x00020000);
@@ -680,6 +735,21 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
                                                    (size_t)wave * 64),
         16, 0, 0);
   };
+  // (EPI 6) plane z of y (clamped into the volume) with its halo -> behind the own tile
+  auto stage_yh = [&](int64_t z) {
+    if (z < 0) z = 0;
+    if (z >= nz) z = nz - 1;
+    const T *pl = aux1 + z * plane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = wave + j * NW;
+      if (k < hpieces)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(pl + yh_off[j]),
+            (__attribute__((address_space(3))) void *)(obuf + (size_t)tile_vecs + (size_t)k * 64),
+            16, 0, 0);
+    }
+  };
   // a 16-byte store every wave issues (offset kNoLane: dropped by the hardware)
   auto store_at = [&](T *dst, int64_t z, uint32_t off, V val) {
     if (z < 0) z = 0;
@@ -760,6 +830,77 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         soff = own_off;
       }
       store_at(out, zbeg + (st - 2 * R), soff, val);
+      const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
+      phase_end((more ? my_stage_ops : 0) + 1);
+      return;
+    }
+    if constexpr (EPI == 6) {
+      // ---- second half with K'K y: output plane j = st - 2R; the halo'd tile holds
+      //      plane j + 1 of y (requested in the phase before, from phase 2R - 3 on)
+      const int j = st - 2 * R;
+      const bool have = j + 1 >= -1;                // (uniform; j + 1 <= len always)
+      V yp1 = splat<V, T>(T(0)), lap1 = splat<V, T>(T(0)), ypv = splat<V, T>(T(0));
+      if (have) {
+        const V *o = obuf + (size_t)tile_vecs + (size_t)(row + 1) * hrl + (lx + 1);
+        yp1 = o[0];
+        const int64_t zc = zbeg + (j + 1);
+        if (j + 1 >= 0 && zc < zend) {              // in-plane part of K'K y, plane j + 1
+          // (EPI 3's values; the 0 / 1 factors of the volume's edges as lane masks, which
+          // live in scalar registers: a * 1 - b = a - b, a * 0 - b = -b for finite a)
+          const bool e_r = xv + 1 < nxv, e_d = y0 + row + 1 < ny, e_l = xv > 0,
+                     e_u = y0 + row > 0;
+          const V down = o[hrl], up = o[-hrl];
+          const T right0 = reinterpret_cast<const T *>(o + 1)[0],
+                  left3 = reinterpret_cast<const T *>(o)[-1];
+          const V dy = e_d ? down - yp1 : -yp1;
+          const V dpy = e_u ? yp1 - up : splat<V, T>(T(0));
+          T dx[VEC];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k)
+            dx[k] = (k + 1 < VEC) ? yp1[(k + 1) % VEC] - yp1[k]
+                                  : (e_r ? right0 - yp1[k] : -yp1[k]);
+          const T dl = e_l ? yp1[0] - left3 : T(0);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const T l = (k > 0) ? dx[(k + VEC - 1) % VEC] : dl;
+            lap1[k] = (l - dx[k]) + (dpy[k] - dy[k]);
+          }
+        }
+      }
+      if (storing && has_prev) ypv = obuf[(size_t)row * lxb + lx];
+      // every wave has taken what it needs from the two tiles: only then may the next
+      // plane be requested into them
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (st >= 2 * R - 3 && st + 1 < nsteps) stage_yh(zbeg + (j + 2));
+      if (has_prev && st + 1 >= 2 * R && st + 1 < nsteps)
+        stage_tile(aux2, zbeg + (j + 1), 0);
+      if (more) stage(next_plane(), r_cur);         // plane st + 3
+      // q0 of the output plane now, the window moved on: four vectors fewer are live
+      // through the passes below (the kernel sits at the 128 registers of 16 waves)
+      V q0v = splat<V, T>(T(0));
+      if (storing) {
+        const int64_t zc = zbeg + j;
+        const T zm = (zc + 1 < nz) ? T(1) : T(0);
+        const T zlm = zc > 0 ? T(1) : T(0);
+        const V dz = __builtin_elementwise_fma(yp1, splat<V, T>(zm), -y0c);
+        const V dpz = (y0c - ym1) * splat<V, T>(zlm);
+        const V lap = lap0 + (dpz - dz);
+        q0v = splat<V, T>(k0) * lap + splat<V, T>(k1) * y0c;
+        if (has_prev) q0v = q0v + splat<V, T>(k2) * ypv;    // (uniform)
+      }
+      if (have) { ym1 = y0c; y0c = yp1; lap0 = lap1; }      // (ym1: y of plane j from here on)
+      if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+      V val = yz_value();
+      uint32_t soff = kNoLane;
+      if (storing) {
+        val = (splat<V, T>(k3) * val + q0v) + splat<V, T>(k4) * ym1;
+        if (owner) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) sacc = fma1(val[e], val[e], sacc);
+        }
+        soff = own_off;
+      }
+      store_at(out, zbeg + j, soff, val);
       const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
       phase_end((more ? my_stage_ops : 0) + 1);
       return;
@@ -989,6 +1130,22 @@ __global__ __launch_bounds__(kBlock) void k_blur3_lanczos_final(
   }
 }
 
+// The first half taken by the EPI 2 kernel (its two sums already reduced): what
+// k_blur3_lanczos_final does for which == 1, from sums2 = { sum t^2, sum |grad y|^2 }.
+template <typename T>
+__global__ void k_blur3_lanczos_from_sums(const double *sums2, double *board, int j,
+                                          double rho_g, double rho_i, T *coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double r0 = sums2[0], r1 = sums2[1];
+  board[3 * j + 1] = r0;
+  board[3 * j + 2] = r1;
+  const double nb2 = board[3 * j];
+  const double alpha = (r0 + rho_g * r1) / nb2 + rho_i;
+  const double beta = sqrt(nb2);
+  coef[4] = (T)(1.0 / beta);
+  coef[5] = (T)(-alpha / beta);
+}
+
 template <typename T>
 struct LanczosArgs {
   const T *aux1, *aux2;
@@ -1017,8 +1174,11 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   // own-position tiles staged beside the raw tiles: EPI 1 two (old io, double buffered),
   // EPI 3 two (y_prev, double buffered), EPI 4 two (q0 and y, one buffer each)
   constexpr int otiles = EPI == 1 ? 2 : (EPI == 3 ? 2 : (EPI == 4 ? 2 : (EPI == 5 ? 2 : 0)));
-  constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl +
-                           (size_t)otiles * dtyr * dl) * 16;
+  // (EPI 6: one own-position tile and the halo'd tile of y, whole 1-KiB pieces)
+  constexpr size_t ovecs = EPI == 6 ? (size_t)dtyr * dl +
+                                          (((size_t)(dtyr + 2) * (dl + 2) + 63) / 64) * 64
+                                    : (size_t)otiles * dtyr * dl;
+  constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl + ovecs) * 16;
   constexpr size_t lds_patch = 3 * (size_t)((frows * 4 + 63) / 64) * 16 * 16;   // (RAG)
   if constexpr (lds0 > 160 * 1024 || ((EPI == 2 || EPI == 3) && sizeof(T) == 8 && NT >= 15) ||
                 (EPI >= 3 && (NT < 5 || NT >= 15 || (sizeof(T) == 8 && NT >= 11)))) {
@@ -1197,6 +1357,21 @@ int blur3_loss_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
     const LanczosArgs<T> lz{b, nullptr, nullptr, nullptr, nullptr, 0, 0.0, 0.0};             \
     return blur3_loss_dispatch<T>(x, g, nz, ny, nx, tz, ty, tx, ntaps, lz, loss, s2, gm,     \
                                   result, part, part_doubles, st);                           \
+  }                                                                                          \
+  int blur3_lanczos_b2(const T *t, const T *y, const T *y_prev, T *y_new, int64_t nz,        \
+                       int64_t ny, int64_t nx, const Taps<T> &tz, const Taps<T> &ty,         \
+                       const Taps<T> &tx, int ntaps, double rho_g, double rho_i,             \
+                       double *board, int step, T *coef, double *part, int64_t part_doubles, \
+                       hipStream_t st) {                                                     \
+    const LanczosArgs<T> lz{y, y_prev, nullptr, coef, board, step, rho_g, rho_i};            \
+    return blur3_lanczos_dispatch<T, 6>(t, y_new, nz, ny, nx, tz, ty, tx, ntaps, lz, part,   \
+                                        part_doubles, st);                                   \
+  }                                                                                          \
+  int blur3_lanczos_a2_close(const double *sums2, double *board, int step, double rho_g,     \
+                             double rho_i, T *coef, hipStream_t st) {                        \
+    hipLaunchKernelGGL(k_blur3_lanczos_from_sums<T>, dim3(1), dim3(64), 0, st, sums2, board, \
+                       step, rho_g, rho_i, coef);                                            \
+    return launch_status();                                                                  \
   }                                                                                          \
   int blur3_lanczos_init(double *board, T *coef, double rho_g, double rho_i,                 \
                          hipStream_t st) {                                                   \

@@ -777,6 +777,47 @@ int loss_epilogue_impl(const T *x, const T *b, T *g, int64_t nz, int64_t ny, int
                              1.345, result, ws, ws_doubles, as_stream(stream));
 }
 
+// nsol_corr3_wrap_lanczos_a2_* / _b2_*: the leaner pair of halves -- A is the blur with
+// its two sums (EPI 2) landing on the board and closed by a one-thread kernel, B forms the
+// step's K'K y itself (EPI 6): no q0 array, 25 B per voxel and step instead of 33
+template <typename T>
+int lanczos_a2_impl(const T *y, T *t, int64_t nz, int64_t ny, int64_t nx,
+                    const double *tz_host, const double *ty_host, const double *tx_host,
+                    int ntaps, double rho_grad, double rho_ident, double *board, int step,
+                    T *coef, double *ws, int64_t ws_doubles, void *stream) {
+  if (!y || !t || y == t || !tz_host || !ty_host || !tx_host || !board || !coef || !ws ||
+      step < 0 || nz < 1 || ny < 1 || nx < 1)
+    return NSOL_EINVAL;
+  Taps<T> tz, ty, tx;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  constexpr int VEC = 16 / sizeof(T);
+  if (nx % VEC != 0 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(t)) & 15u))
+    return -2;                                     // (as the other halves: no ragged form)
+  // (unit spacing: the squared weights of the difference sums are 1; the sums land on
+  // board[3 step + 1], [3 step + 2])
+  const int rc = blur3_dma_run(y, t, nz, ny, nx, tz, ty, tx, ntaps, 2, 1.0, 1.0, 1.0,
+                               board + 3 * (int64_t)step + 1, ws, ws_doubles,
+                               as_stream(stream));
+  if (rc != 0) return rc;
+  return blur3_lanczos_a2_close(board + 3 * (int64_t)step + 1, board, step, rho_grad,
+                                rho_ident, coef, as_stream(stream));
+}
+
+template <typename T>
+int lanczos_b2_impl(const T *t, const T *y, const T *y_prev, T *y_new, int64_t nz, int64_t ny,
+                    int64_t nx, const double *tz_host, const double *ty_host,
+                    const double *tx_host, int ntaps, double rho_grad, double rho_ident,
+                    double *board, int step, T *coef, double *ws, int64_t ws_doubles,
+                    void *stream) {
+  if (!t || !y || !y_new || y_new == t || y_new == y || y_new == y_prev || !tz_host ||
+      !ty_host || !tx_host || !board || !coef || !ws || step < 0 || nz < 1 || ny < 1 || nx < 1)
+    return NSOL_EINVAL;
+  Taps<T> tz, ty, tx;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  return blur3_lanczos_b2(t, y, y_prev, y_new, nz, ny, nx, tz, ty, tx, ntaps, rho_grad,
+                          rho_ident, board, step, coef, ws, ws_doubles, as_stream(stream));
+}
+
 template <typename T, int VEC, int NT>
 int launch_blur3(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                  const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, bool symmetric,
@@ -1011,6 +1052,23 @@ int nsol_corr3_wrap_norms_f64(const double *x, double *out, int64_t nz, int64_t 
     return lanczos_b_impl<T>(t, q0, y, y_new, nz, ny, nx, taps_z, taps_y, taps_x, ntaps,  \
                              rho_grad, rho_ident, board, step, coef, ws, ws_doubles,      \
                              stream);                                                     \
+  }                                                                                       \
+  int nsol_corr3_wrap_lanczos_a2_##SUF(                                                   \
+      const T *y, T *t, int64_t nz, int64_t ny, int64_t nx, const double *taps_z,         \
+      const double *taps_y, const double *taps_x, int ntaps, double rho_grad,             \
+      double rho_ident, double *board, int step, T *coef, double *ws, int64_t ws_doubles, \
+      void *stream) {                                                                     \
+    return lanczos_a2_impl<T>(y, t, nz, ny, nx, taps_z, taps_y, taps_x, ntaps, rho_grad,  \
+                              rho_ident, board, step, coef, ws, ws_doubles, stream);      \
+  }                                                                                       \
+  int nsol_corr3_wrap_lanczos_b2_##SUF(                                                   \
+      const T *t, const T *y, const T *y_prev, T *y_new, int64_t nz, int64_t ny,          \
+      int64_t nx, const double *taps_z, const double *taps_y, const double *taps_x,       \
+      int ntaps, double rho_grad, double rho_ident, double *board, int step, T *coef,     \
+      double *ws, int64_t ws_doubles, void *stream) {                                     \
+    return lanczos_b2_impl<T>(t, y, y_prev, y_new, nz, ny, nx, taps_z, taps_y, taps_x,    \
+                              ntaps, rho_grad, rho_ident, board, step, coef, ws,          \
+                              ws_doubles, stream);                                        \
   }
 NSOL_LANCZOS_DEF(float, f32)
 NSOL_LANCZOS_DEF(double, f64)

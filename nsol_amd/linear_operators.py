@@ -229,11 +229,22 @@ class ConvolutionOperator(DeviceOperator):
             return None
         tz, ty, tx = (self._passes[0][1], self._passes[1][1], self._passes[2][1])
 
+        lean = bool(ops.LEAN_LANCZOS_HALVES)
+        held = {}
+
         def half_a(y, y_prev, t, q0, lb, step):
+            if lean:
+                # (q0 is not formed: the second half takes y_prev itself)
+                held["y_prev"] = y_prev
+                return ops.corr3_lanczos_a2(y, t, in_shape, tz, ty, tx, lb, step)
             return ops.corr3_lanczos_a(y, y_prev, t, q0, in_shape, tz, ty, tx, lb, step)
 
         def half_b(t, q0, y, y_new, lb, step):
+            if lean:
+                return ops.corr3_lanczos_b2(t, y, held.get("y_prev"), y_new, in_shape, tz,
+                                            ty, tx, lb, step)
             return ops.corr3_lanczos_b(t, q0, y, y_new, in_shape, tz, ty, tx, lb, step)
+        half_a.lean = lean
         return half_a, half_b
 
     def apply_loss(self, x, b, in_shape, loss, f_scale, result):

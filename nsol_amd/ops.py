@@ -261,6 +261,53 @@ def corr3_lanczos_a(y, y_prev, t, q0, shape, taps_z, taps_y, taps_x, lb, step):
     return True
 
 
+# True: the halves of a Lanczos step as nsol_corr3_wrap_lanczos_a2 / _b2 (no q0 array:
+# the second half forms the step's K'K y itself; 25 B per voxel and step instead of 33)
+LEAN_LANCZOS_HALVES = True
+
+
+def corr3_lanczos_a2(y, t, shape, taps_z, taps_y, taps_x, lb, step):
+    """First half, lean form: t = blur(y), its two sums onto the board, the second
+    half's coefficients.  False when the kernel does not apply (nothing launched)."""
+    _same(y, t)
+    ndim, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(v, dtype=np.float64)
+                  for v in (taps_z, taps_y, taps_x))
+    if ndim != 3 or nz * ny * nx != y.numel() or not (tz.size == ty.size == tx.size):
+        return False
+    ws, _ = _workspace(y.device)
+    rc = _fn("corr3_wrap_lanczos_a2", y)(
+        _p(y), _p(t), nz, ny, nx, tz.ctypes.data, ty.ctypes.data, tx.ctypes.data,
+        int(tz.size), lb.rho_grad, lb.rho_ident, _p(lb.board), int(step), _p(lb.coef),
+        _p(ws), int(ws.numel()), stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_corr3_wrap_lanczos_a2")
+    return True
+
+
+def corr3_lanczos_b2(t, y, y_prev, y_new, shape, taps_z, taps_y, taps_x, lb, step):
+    """Second half, lean form: y_new = ca blur(t) + (c1 K'K y + c0 y + c2 y_prev) + cy y
+    with |y_new|^2 onto the board (y_prev may be None)."""
+    _same(t, y, y_new)
+    if y_prev is not None:
+        _same(y, y_prev)
+    ndim, nz, ny, nx = dims3(shape)
+    tz, ty, tx = (np.ascontiguousarray(v, dtype=np.float64)
+                  for v in (taps_z, taps_y, taps_x))
+    if ndim != 3 or nz * ny * nx != y.numel() or not (tz.size == ty.size == tx.size):
+        return False
+    ws, _ = _workspace(y.device)
+    rc = _fn("corr3_wrap_lanczos_b2", y)(
+        _p(t), _p(y), _p(y_prev), _p(y_new), nz, ny, nx, tz.ctypes.data, ty.ctypes.data,
+        tx.ctypes.data, int(tz.size), lb.rho_grad, lb.rho_ident, _p(lb.board), int(step),
+        _p(lb.coef), _p(ws), int(ws.numel()), stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_corr3_wrap_lanczos_b2")
+    return True
+
+
 def corr3_wrap_loss(x, b, shape, taps_z, taps_y, taps_x, loss, f_scale, result):
     """rho'(r^2) r for r = blur(x) - b with 1/2 sum rho(r^2) in result[0] (the caller's
     device slot), from the blur itself; None when that kernel does not apply (nothing

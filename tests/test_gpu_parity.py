@@ -651,19 +651,24 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
     ((130, 200, 264), 4.0, np.float32), ((512, 512, 512), 4.0, np.float32),
     ((30, 36, 64), 1.5, np.float64), ((20, 20, 32), 1.0, np.float64)])
 @pytest.mark.parametrize("ident", [False, True])
-def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype, ident):
-    """nsol_corr3_wrap_lanczos_a / _b: both halves of a Lanczos step on A'A + rho B'B
-    inside the one-pass blur.  Against their parts, bit for bit: t and the two sums as
-    nsol_corr3_wrap_norms_* leaves them; q0 as nsol_tk1_lanczos_* (c_g = 0) forms it;
-    y_new as nsol_lincomb3_* of the plain blur; the coefficients the device derives from
-    the sums against the same formulas on the host."""
+@pytest.mark.parametrize("lean", [True, False])
+def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype, ident,
+                                                      lean, monkeypatch):
+    """nsol_corr3_wrap_lanczos_a / _b (and the lean pair _a2 / _b2, whose second half
+    forms the step's K'K y itself and which never stores q0): both halves of a Lanczos
+    step on A'A + rho B'B inside the one-pass blur.  Against their parts, bit for bit: t
+    and the two sums as nsol_corr3_wrap_norms_* leaves them; q0 as nsol_tk1_lanczos_*
+    (c_g = 0) forms it; y_new as nsol_lincomb3_* of the plain blur; the coefficients the
+    device derives from the sums against the same formulas on the host."""
     import torch
     from nsol_amd import ops
+    monkeypatch.setattr(ops, "LEAN_LANCZOS_HALVES", lean)
     lo = _lo(3)
     A, _ = lo.get_gaussian_blurring_operators(np.diag([sigma2] * 3))
     halves = A.lanczos_halves(shape)
     assert halves is not None
     half_a, half_b = halves
+    assert half_a.lean == lean
     n = int(np.prod(shape))
     td = torch.float32 if dtype == np.float32 else torch.float64
     gen = torch.Generator(device="cuda").manual_seed(11)
@@ -697,6 +702,8 @@ def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype
         assert board[3 * step + 1] == float(sums[0]) and board[3 * step + 2] == float(sums[1])
         q0_ref = torch.empty_like(y)
         ops.tk1_lanczos(y, torch.zeros_like(y), prev, shape, w, c1, 0.0, c0, c2, out=q0_ref)
+        if lean:
+            q0 = q0_ref                       # (never stored: the second half forms it)
         assert torch.equal(q0, q0_ref), (shape, step, ident)
         # the coefficients of the second half
         alfa = (board[3 * step + 1] + rg * board[3 * step + 2]) / nb2 + ri
