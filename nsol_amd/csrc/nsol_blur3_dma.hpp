@@ -844,7 +844,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         const V *o = obuf + (size_t)tile_vecs + (size_t)(row + 1) * hrl + (lx + 1);
         yp1 = o[0];
         const int64_t zc = zbeg + (j + 1);
-        if (j + 1 >= 0 && zc < zend) {              // in-plane part of K'K y, plane j + 1
+        if (j + 1 >= 0 && zc < zend && k0 != T(0)) {   // in-plane part of K'K y, plane j + 1
+                                                    // (k0 = 0: B = identity, no K'K term)
           // (EPI 3's values; the 0 / 1 factors of the volume's edges as lane masks, which
           // live in scalar registers: a * 1 - b = a - b, a * 0 - b = -b for finite a)
           const bool e_r = xv + 1 < nxv, e_d = y0 + row + 1 < ny, e_l = xv > 0,

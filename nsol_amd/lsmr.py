@@ -248,7 +248,10 @@ USE_BLUR_NORMS = True
 # ... and the whole Lanczos update: two kernels per step (nsol_corr3_wrap_lanczos_a / _b)
 # instead of blur, blur and nsol_tk1_lanczos_*; the step's scalars stay on the device
 USE_BLUR_LANCZOS = True
-LANCZOS_IDENTITY = False
+# ... also with B = identity (primal-dual deconvolution's prox): with the lean halves
+# (ops.LEAN_LANCZOS_HALVES) 82 against 76.6 PD iterations/s at 512^3; with q0 stored it was
+# no faster than blur, blur and the element-wise update
+LANCZOS_IDENTITY = True
 _LAG = 2                     # steps the host's recurrences trail the enqueued kernels
 LAST_FORM = [None]           # (diagnostics: "lanczos-in-blur" / "lanczos" / None)
 LAST_NE_COND = [None]        # (diagnostics: the estimate of the last run)
@@ -396,10 +399,9 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
             r += b_bot_scale ** 2 * ops.dot(b_bot, b_bot)
         return r
     halves = getattr(A_axpby, "lanczos", None) if USE_BLUR_LANCZOS else None
-    # (B = identity: the kernels take it -- rho_ident -- but the element-wise update
-    # of that mode is cheap enough that three kernels are as fast: primal-dual
-    # deconvolution at 512^3 0.132 s per run against 0.134 s; LANCZOS_IDENTITY = True
-    # to route it through the blur anyway)
+    # (B = identity: the kernels take it -- rho_ident; with q0 stored the three-kernel
+    # form was as fast, with the lean halves primal-dual deconvolution at 512^3 runs
+    # 0.122 s per ten iterations against 0.131 s; LANCZOS_IDENTITY = False for the A/B)
     if halves is not None and (grad_mode or (LANCZOS_IDENTITY and
                                               bmode == ops.B_IDENTITY)) and \
             (not grad_mode or (tuple(w) == (1.0, 1.0, 1.0) and

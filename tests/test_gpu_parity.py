@@ -1568,22 +1568,20 @@ def test_normal_equations_lsmr_at_the_edge_of_its_guard(nsol, golden, bname, wna
                                     iter_max=iters, dtype=dtype)
         s.run()
         assert L.LAST_NE_COND[0] is not None, "the normal-equations form did not run"
-        # (13 taps, unit spacing, B = gradient: both halves of every step inside the
-        # blur; B = identity keeps its element-wise update unless asked)
-        # (float64 at 13 taps would spill in the first half: three kernels there)
-        assert L.LAST_FORM[0] == ("lanczos-in-blur" if bname == "grad" and
-                                  dtype == np.float32 else "lanczos")
+        # (13 taps, unit spacing, B = gradient or identity: both halves of every step
+        # inside the blur; float64 at 13 taps would spill there: three kernels)
+        assert L.LAST_FORM[0] == ("lanczos-in-blur" if dtype == np.float32 else "lanczos")
         if bname == "ident" and dtype == np.float32:
-            L.LANCZOS_IDENTITY = True
+            L.LANCZOS_IDENTITY = False          # (the element-wise update of that mode)
             try:
                 s2 = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=B, B_adj=Ba, b=y, x0=y,
                                              alpha=weight, x_scale=float(y.max()),
                                              iter_max=iters, dtype=dtype)
                 s2.run()
             finally:
-                L.LANCZOS_IDENTITY = False
-            assert L.LAST_FORM[0] == "lanczos-in-blur"
-            assert rel_l2(s2.get_x(), ref, "identity through the blur") < tol
+                L.LANCZOS_IDENTITY = True
+            assert L.LAST_FORM[0] == "lanczos"
+            assert rel_l2(s2.get_x(), ref, "identity with its element-wise update") < tol
         assert rel_l2(s.get_x(), ref,
                       "%s %s %d %s cond %.3g" % (bname, wname, iters,
                                                  np.dtype(dtype).name,
