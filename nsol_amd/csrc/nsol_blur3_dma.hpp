@@ -1182,11 +1182,12 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl + ovecs) * 16;
   constexpr size_t lds_patch = 3 * (size_t)((frows * 4 + 63) / 64) * 16 * 16;   // (RAG)
   if constexpr (lds0 > 160 * 1024 || ((EPI == 2 || EPI == 3) && sizeof(T) == 8 && NT >= 15) ||
-                (EPI >= 3 && (NT < 5 || NT >= 15 || (sizeof(T) == 8 && NT >= 11)))) {
+                (EPI >= 3 && (NT < 5 || NT >= 15 ||
+                              (sizeof(T) == 8 && NT >= (EPI == 6 ? 13 : 11))))) {
     static_assert(EPI != 0, "LDS-DMA blur tile does not fit");
     // (no room for the io tiles; the difference sums of 15 / 17 taps in double -- and the
-    // first Lanczos half at 15 / 17 taps, in double from 11 taps on -- would need more than
-    // the 128 registers of a 16-wave workgroup)
+    // first Lanczos half at 15 / 17 taps, in double from 11 taps on (the lean second half:
+    // from 13 on) -- would need more than the 128 registers of a 16-wave workgroup)
     return -2;
   } else {
   if (dtyr < 2 * R) return -2;

@@ -710,9 +710,10 @@ int corr3_axpby_impl(const T *x, T *io, int64_t nz, int64_t ny, int64_t nx,
 // that form does not apply (the caller then runs blur, blur and nsol_tk1_lanczos_*)
 template <typename T>
 bool lanczos_taps(const double *tz_host, const double *ty_host, const double *tx_host,
-                  int ntaps, Taps<T> *tz, Taps<T> *ty, Taps<T> *tx) {
-  // (13 taps in float, 9 in double: beyond, the first half would spill -- nsol_blur3_dma.hpp)
-  if ((ntaps & 1) == 0 || ntaps < 5 || ntaps > (sizeof(T) == 4 ? 13 : 9) || !g_blur3_dma ||
+                  int ntaps, Taps<T> *tz, Taps<T> *ty, Taps<T> *tx, int max_double = 9) {
+  // (13 taps in float, 9 in double -- 11 for the lean pair: beyond, a half would spill --
+  // nsol_blur3_dma.hpp)
+  if ((ntaps & 1) == 0 || ntaps < 5 || ntaps > (sizeof(T) == 4 ? 13 : max_double) || !g_blur3_dma ||
       g_blur3_lxb != kDmaLxb)
     return false;
   for (int t = 0; t < kMaxTaps; ++t) {
@@ -789,7 +790,7 @@ int lanczos_a2_impl(const T *y, T *t, int64_t nz, int64_t ny, int64_t nx,
       step < 0 || nz < 1 || ny < 1 || nx < 1)
     return NSOL_EINVAL;
   Taps<T> tz, ty, tx;
-  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx, 11)) return -2;
   constexpr int VEC = 16 / sizeof(T);
   if (nx % VEC != 0 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(t)) & 15u))
     return -2;                                     // (as the other halves: no ragged form)
@@ -813,7 +814,7 @@ int lanczos_b2_impl(const T *t, const T *y, const T *y_prev, T *y_new, int64_t n
       !ty_host || !tx_host || !board || !coef || !ws || step < 0 || nz < 1 || ny < 1 || nx < 1)
     return NSOL_EINVAL;
   Taps<T> tz, ty, tx;
-  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx)) return -2;
+  if (!lanczos_taps<T>(tz_host, ty_host, tx_host, ntaps, &tz, &ty, &tx, 11)) return -2;
   return blur3_lanczos_b2(t, y, y_prev, y_new, nz, ny, nx, tz, ty, tx, ntaps, rho_grad,
                           rho_ident, board, step, coef, ws, ws_doubles, as_stream(stream));
 }

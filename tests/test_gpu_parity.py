@@ -649,7 +649,8 @@ def test_admm_lsmr_matches_reference_goldens(nsol, golden, k, lsmr_form):
     ((40, 48, 64), 4.0, np.float32), ((33, 70, 128), 4.0, np.float32),
     ((64, 64, 64), 1.0, np.float32), ((24, 40, 96), 2.0, np.float32),
     ((130, 200, 264), 4.0, np.float32), ((512, 512, 512), 4.0, np.float32),
-    ((30, 36, 64), 1.5, np.float64), ((20, 20, 32), 1.0, np.float64)])
+    ((30, 36, 64), 1.5, np.float64), ((20, 20, 32), 1.0, np.float64),
+    ((28, 36, 64), 2.6, np.float64)])
 @pytest.mark.parametrize("ident", [False, True])
 @pytest.mark.parametrize("lean", [True, False])
 def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype, ident,
@@ -665,6 +666,8 @@ def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype
     monkeypatch.setattr(ops, "LEAN_LANCZOS_HALVES", lean)
     lo = _lo(3)
     A, _ = lo.get_gaussian_blurring_operators(np.diag([sigma2] * 3))
+    if dtype == np.float64 and len(A._passes[0][1]) > (11 if lean else 9):
+        pytest.skip("float64: the halves with q0 up to 9 taps, the lean pair up to 11")
     halves = A.lanczos_halves(shape)
     assert halves is not None
     half_a, half_b = halves

@@ -141,12 +141,17 @@ def test_one_pass_blur_instantiations_do_not_spill(tmp_path_factory):
         hot = [int(p) for n, p in zip(names, scratch)
                if "k_blur3_dmaI%sLi13ELi16E" % t in n]
         # (plain, epilogue, sums) x (isotropic or not) x (ragged or not); float: + the
-        # two halves of a Lanczos step and the loss epilogue x (isotropic or not)
-        assert len(hot) == (18 if t[0] == "f" else 12) and not any(hot), (src, hot)
+        # two halves of a Lanczos step, the lean second half and the loss epilogue x
+        # (isotropic or not)
+        assert len(hot) == (20 if t[0] == "f" else 12) and not any(hot), (src, hot)
         # the Lanczos halves at every tap count they are built for (5 .. 13, double 5 .. 9)
         lz = {n: int(p) for n, p in zip(names, scratch)
               if re.search(r"k_blur3_dmaI%sLi\d+ELi16ELb[01]ELi[34]ELb0E" % t, n)}
         assert len(lz) == (5 if t[0] == "f" else 3) * 2 * 2 and not any(lz.values()), (src, lz)
+        # the lean second half (EPI 6): float 5 .. 13 taps, double 5 .. 11
+        l6 = {n: int(p) for n, p in zip(names, scratch)
+              if re.search(r"k_blur3_dmaI%sLi\d+ELi16ELb[01]ELi6ELb0E" % t, n)}
+        assert len(l6) == (5 if t[0] == "f" else 4) * 2 and not any(l6.values()), (src, l6)
         # the loss epilogue (EPI 5) at the same tap counts
         ls = {n: int(p) for n, p in zip(names, scratch)
               if re.search(r"k_blur3_dmaI%sLi\d+ELi16ELb[01]ELi5ELb0E" % t, n)}
