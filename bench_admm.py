@@ -45,7 +45,10 @@ BYTES = {"k_blur3_dma": 8, "k_lsmr_u": 40, "k_lsmr_v": 24, "k_lsmr_hx": 28,
          "k_blur3_dma_norms": 8,
          # ... or both halves of the Lanczos step inside the blur: (y, y_prev) -> (t, q0)
          # and (t, q0, y) -> y_new
-         "k_blur3_lanczos_a": 16, "k_blur3_lanczos_b": 16}
+         "k_blur3_lanczos_a": 16, "k_blur3_lanczos_b": 16,
+         # ... or the lean pair: the first half is the blur with both sums (8), the
+         # second (t, y, y_prev) -> y_new forms the step's K'K y itself
+         "k_blur3_lanczos_b2": 16}
 SETUP_BYTES = 156
 
 
@@ -53,6 +56,7 @@ SETUP_BYTES = 156
 PMC_NAMES = {"k_tk1_lanczos": "k_tk1_reg<float, 4, 4, false, 2>",
              "k_blur3_lanczos_a": "k_blur3_dma<float, 4, 13, 16, true, 3, false>",
              "k_blur3_lanczos_b": "k_blur3_dma<float, 4, 13, 16, true, 4, false>",
+             "k_blur3_lanczos_b2": "k_blur3_dma<float, 4, 13, 16, true, 6, false>",
              "k_blur3_dma_norms": "k_blur3_dma<float, 4, 13, 16, true, 2, false>",
              "k_blur3_dma": "k_blur3_dma<float, 4, 13, 16, true, 0, false>",
              "k_blur3_dma_epi": "k_blur3_dma<float, 4, 13, 16, true, 1, false>",
@@ -114,8 +118,10 @@ def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
         # per Lanczos step: t = A y (12), sum |grad y|^2 (4), A^T t (8), the three-term
         # update with sa^2 grad^T grad y (16); the right-hand side A^T b + sa B^T c
         # once (8 + 24); x from the iter_max stored vectors; the outer step as before
-        # (blur_norms: t = A y with both sums in 8)
-        return iter_max * (32 if blur_norms else 40) + 32 + 4 * (iter_max + 1) + \
+        # (blur_norms: t = A y with both sums in 8; "lean": the second half reads t, y,
+        # y_prev and writes y_new -- 24 per step, no q0)
+        per_step = 24 if blur_norms == "lean" else (32 if blur_norms else 40)
+        return iter_max * per_step + 32 + 4 * (iter_max + 1) + \
             SETUP_BYTES - 64 - (40 if prescaled_rhs else 0)
     per_it = (100 if blur_epilogue else 108) - (28 if deferred_x else 0)
     return iter_max * per_it + (4 * (iter_max + 2) if deferred_x else 0) + \
@@ -173,6 +179,8 @@ def time_kernels(shape, reps=20):
     lib_la = lambda: ops.corr3_lanczos_a(v, h, blur_out, q0, shape, taps, taps, taps, lb, 1)
     lib_lb = lambda: ops.corr3_lanczos_b(blur_out, q0, v, x_out, shape, taps, taps, taps,
                                          lb, 1)
+    lib_lb2 = lambda: ops.corr3_lanczos_b2(blur_out, v, h, x_out, shape, taps, taps, taps,
+                                           lb, 1)
     for _ in range(30):        # (clocks up before the first timed kernel)
         lib_blur()
     for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
@@ -180,7 +188,8 @@ def time_kernels(shape, reps=20):
                      ("k_admm_vw", lib_vw), ("k_wcomb", lib_x),
                      ("k_blur3_dma_epi", lib_epi), ("k_tk1_norm", lib_reg),
                      ("k_tk1_lanczos", lib_lz), ("k_blur3_dma_norms", lib_norms),
-                     ("k_blur3_lanczos_a", lib_la), ("k_blur3_lanczos_b", lib_lb)):
+                     ("k_blur3_lanczos_a", lib_la), ("k_blur3_lanczos_b", lib_lb),
+                     ("k_blur3_lanczos_b2", lib_lb2)):
         for _ in range(3):
             fn()
         e0, e1 = ev.create(), ev.create()
@@ -463,13 +472,16 @@ def main():
         blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS)
         in_blur = normal and bool(lsmr_mod.USE_BLUR_LANCZOS) and \
             lsmr_mod.LAST_FORM[0] == "lanczos-in-blur"
+        lean = in_blur and bool(ops.LEAN_LANCZOS_HALVES)
         if in_blur:
-            per_it = {"k_blur3_lanczos_a": args.iter_max,
-                      "k_blur3_lanczos_b": args.iter_max, "k_blur3_dma": 0,
-                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_blur3_dma_norms": 0,
+            per_it = {"k_blur3_lanczos_a": 0 if lean else args.iter_max,
+                      "k_blur3_lanczos_b": 0 if lean else args.iter_max,
+                      "k_blur3_lanczos_b2": args.iter_max if lean else 0,
+                      "k_blur3_dma_norms": args.iter_max if lean else 0, "k_blur3_dma": 0,
+                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0,
                       "k_tk1_lanczos": 0, "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0,
                       "k_admm_vw": 1, "k_wcomb": 1}
-            blur_norms = True
+            blur_norms = "lean" if lean else True
         elif normal:
             per_it = {"k_blur3_dma": args.iter_max + 1,
                       "k_blur3_dma_epi": 0 if blur_norms else args.iter_max,
@@ -477,6 +489,7 @@ def main():
                       "k_blur3_dma_norms": args.iter_max if blur_norms else 0,
                       "k_tk1_lanczos": args.iter_max,
                       "k_blur3_lanczos_a": 0, "k_blur3_lanczos_b": 0,
+                      "k_blur3_lanczos_b2": 0,
                       "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0, "k_admm_vw": 1,
                       "k_wcomb": 1}
         else:
@@ -486,7 +499,7 @@ def main():
                       "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0,
                       "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_tk1_lanczos": 0,
                       "k_blur3_dma_norms": 0, "k_blur3_lanczos_a": 0,
-                      "k_blur3_lanczos_b": 0}
+                      "k_blur3_lanczos_b": 0, "k_blur3_lanczos_b2": 0}
         for k, c in per_it.items():
             kern[k]["launches_per_admm_iteration"] = c
             kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]
