@@ -347,8 +347,10 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                 A_axpby=None, atb=None, x_bounds=None, b_bot_scale=1.0,
-                normb2=None):
+                normb2=None, top_norm2=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
+    top_norm2: a callable that returns |b_top|^2 (like atb: the same in every solve of an
+    outer loop around one b).
     b_top is only read, b_bot too.  atb: a callable that returns A^T b_top (a caller
     that solves around the same b again and again keeps it).  x_bounds: see lsmr_fused.
     Returns (x, istop, itn).
@@ -394,7 +396,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         # (right-hand side [b_top; b_bot_scale * b_bot]; the caller's figure if it has one)
         if normb2 is not None:
             return normb2
-        r = ops.dot(b_top, b_top)
+        r = top_norm2() if top_norm2 is not None else ops.dot(b_top, b_top)
         if b_bot is not None and bmode != ops.B_NONE:
             r += b_bot_scale ** 2 * ops.dot(b_bot, b_bot)
         return r
@@ -602,7 +604,7 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
-               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None,
+               atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None, top_norm2=None,
                own_b=True, atb=None, x_bounds=None, b_bot_scale=1.0,
                allow_normal=True):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
@@ -634,7 +636,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
                                     x_like, maxiter, A_axpby=A_axpby, atb=atb,
                                     x_bounds=x_bounds, b_bot_scale=b_bot_scale,
-                                    normb2=normb2)
+                                    normb2=normb2, top_norm2=top_norm2)
         if x is not None:
             return x, istop, itn
         # (the weight is below the guard or the condition estimate came out too high:

@@ -71,6 +71,21 @@ def _adjoint_of_data(key_op, A_adj, b):
     return val
 
 
+_bnorm_cache = []
+
+
+def _norm2_of_data(b):
+    """|b|^2, kept like A^T b."""
+    key = (b.data_ptr(), int(b._version), b.numel(), str(b.dtype))
+    for k, ref, val in _bnorm_cache:
+        if k == key and ref is b:
+            return val
+    val = ops.dot(b, b)
+    _bnorm_cache.append((key, b, val))
+    del _bnorm_cache[:-2]
+    return val
+
+
 class TikhonovLinearSolver(LinearSolver):
 
     def __init__(self, A, A_adj, b, B, B_adj, x0, alpha=0.01, b_reg=0,
@@ -199,6 +214,7 @@ class TikhonovLinearSolver(LinearSolver):
                                  own_b=False,
                                  atb=lambda: _adjoint_of_data(self._A_adj, fused[1],
                                                               b_top),
+                                 top_norm2=lambda: _norm2_of_data(b_top),
                                  x_bounds=self._bounds,
                                  b_bot_scale=self._lower_scale)
             self._lsmr_stop = (istop, itn)     # (SciPy's istop, iterations taken)
