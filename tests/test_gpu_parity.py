@@ -1001,6 +1001,47 @@ def test_blur_takes_the_loss_as_its_epilogue(nsol, dtype, lossname, shape, sigma
     assert abs(float(slot[0]) - cost) <= 1e-13 * abs(cost)
 
 
+def test_objective_kernels_at_512_cubed_match_their_parts(nsol):
+    """BASELINE config 4's size: the data term as the blur's epilogue and the
+    regulariser's pass with the line search's scalars against the separate kernels
+    (blur, loss; stencil, dot, projected gradient, difference) -- gradients bit for bit,
+    sums to the order of their additions."""
+    import torch
+    import nsol_amd.linear_operators as LO
+    from nsol_amd import ops
+    from nsol_amd.lbfgsb_device import DeviceBackend
+    shape = (512, 512, 512)
+    n = 512 ** 3
+    lo = LO.LinearOperators3D()
+    A, _ = lo.get_gaussian_blurring_operators(np.diag([4.0] * 3))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(n, device="cuda", generator=gen)
+    b = torch.rand(n, device="cuda", generator=gen)
+    slot = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g = A.apply_loss(x, b, shape, "huber", 0.1, slot)
+    assert g is not None
+    cost, g_ref = ops.loss_cost_grad(A(x.view(*shape)).reshape(-1), "huber", 0.1, minus=b)
+    assert torch.equal(g, g_ref)
+    assert abs(float(slot[0]) - cost) <= 1e-12 * abs(cost)
+    del g_ref
+    d = torch.randn(n, device="cuda", generator=gen)
+    gold = torch.randn(n, device="cuda", generator=gen)
+    w = ops.inv_spacing(np.ones(3), 3)
+    c2, ref = ops.tk1_reg_cost_grad(x, g, shape, w, 0.1)
+    slots = torch.zeros(4, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(g)
+    out = ops.tk1_reg_objective(x, g, d, shape, w, 0.1, 0.0, np.inf,
+                                out=torch.empty_like(g), result=slots, gold=gold, ydiff=y)
+    got = slots.cpu().numpy()
+    assert torch.equal(out, ref) and got[0] == c2
+    be = DeviceBackend()
+    assert got[2] == be.projgr(x, ref, 0.0, np.inf)
+    gd = ops.dot(ref, d)
+    assert abs(got[1] - gd) <= 1e-10 * float(np.sqrt(ops.dot(ref, ref) * ops.dot(d, d)))
+    y_ref, yy, _ = be.diff_dots(ref, gold)
+    assert torch.equal(y, y_ref) and abs(got[3] - yy) <= 1e-12 * yy
+
+
 def test_blur_epilogue_leaves_the_heavy_losses_to_the_loss_kernel(nsol):
     import torch
     import nsol_amd.linear_operators as LO
