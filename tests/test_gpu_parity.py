@@ -1042,6 +1042,53 @@ def test_objective_kernels_at_512_cubed_match_their_parts(nsol):
     assert torch.equal(y, y_ref) and abs(got[3] - yy) <= 1e-12 * yy
 
 
+def test_config4_forms_at_512_cubed_leave_the_result_alone(nsol, monkeypatch):
+    """BASELINE config 4 at its size (2 ADMM x 3 inner iterations): the LSMR branch with
+    the lean Lanczos halves and with q0 stored, the Huber branch with and without the
+    objective handed from solve to solve -- the same x bit for bit."""
+    import torch
+    import nsol_amd.linear_operators as LO
+    import nsol_amd.admm_linear_solver as admm
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.lsmr as lsmr_mod
+    from nsol_amd import ops
+    from nsol_amd.synthetic import synth_volume
+    n = 512
+    shape, Z = (n, n, n), (3 * n, n, n)
+    lo = LO.LinearOperators3D()
+    A, A_adj = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
+    grad, grad_adj = lo.get_gradient_operators()
+    clean = torch.from_numpy(synth_volume(n, 0, "clean", np.float32)).cuda()
+    y = A(clean).flatten()
+    del clean
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    y = y + 0.02 * float(y.max()) * torch.randn(y.shape, device="cuda", generator=gen)
+
+    def run(**kw):
+        s = admm.ADMMLinearSolver(
+            A=lambda x: A(x.reshape(*shape)).flatten(),
+            A_adj=lambda x: A_adj(x.reshape(*shape)).flatten(), b=y,
+            B=lambda x: grad(x.reshape(*shape)).flatten(),
+            B_adj=lambda x: grad_adj(x.reshape(*Z)).flatten(), x0=y, dimension=3,
+            alpha=0.01, rho=0.1, iterations=2, iter_max=3, x_scale=float(y.max()),
+            dtype=np.float32, **kw)
+        s.run()
+        return s.get_x_device().clone()
+    got = []
+    for lean in (True, False):
+        monkeypatch.setattr(ops, "LEAN_LANCZOS_HALVES", lean)
+        got.append(run())
+        assert lsmr_mod.LAST_FORM[0] == "lanczos-in-blur"
+    assert torch.equal(got[0], got[1])
+    assert bool(torch.isfinite(got[0]).all())
+    got = []
+    for reuse in (True, False):
+        monkeypatch.setattr(tk, "REUSE_OBJECTIVE_AT_X0", reuse)
+        got.append(run(minimizer="L-BFGS-B", data_loss="huber"))
+    assert torch.equal(got[0], got[1])
+    assert bool(torch.isfinite(got[0]).all())
+
+
 def test_blur_epilogue_leaves_the_heavy_losses_to_the_loss_kernel(nsol):
     import torch
     import nsol_amd.linear_operators as LO
