@@ -7,5 +7,6 @@ import.  All arithmetic runs in hand-written HIP kernels (libnsol_hip.so, C ABI
 in include/nsol_hip.h); there is no CPU fallback.
 """
 from .device import set_default_dtype, get_default_dtype  # noqa: F401
+from ._caches import invalidate_caches  # noqa: F401
 
 __version__ = "0.1.0"

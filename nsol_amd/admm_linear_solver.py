@@ -55,6 +55,7 @@ class ADMMLinearSolver(LinearSolver):
 
         x = self._x0_device().clone()
         self._warm = None
+        self._inner_log = []
         n = x.numel()
         B = BridgedCallable(self._B, self._dtype)
         desc = trace_operator(self._B, n)
@@ -127,6 +128,11 @@ class ADMMLinearSolver(LinearSolver):
         self._x = x
 
     _warm = None
+    _inner_log = ()
+
+    def get_inner_log(self):
+        """One record per inner solve of the last run (see _solve_tikhonov_least_squares)."""
+        return list(self._inner_log)
 
     def _solve_tikhonov_least_squares(self, x, b_reg, prescaled=None):
         # admm :220-237: data_loss_scale and bounds are NOT forwarded
@@ -144,6 +150,14 @@ class ADMMLinearSolver(LinearSolver):
         tikhonov._warm_start = self._warm
         tikhonov.run()
         self._warm = tikhonov._warm_result
+        # what the inner solve decided (LSMR: SciPy's istop and the iterations taken;
+        # L-BFGS-B: accepted iterations, evaluations, the task it ended on) -- two
+        # precisions of one problem are compared through these
+        info = getattr(tikhonov, "_minimize_info", None)
+        self._inner_log.append(
+            ("lsmr",) + tuple(getattr(tikhonov, "_lsmr_stop", (None, None)))
+            if info is None else
+            ("minimize", info.get("nit"), info.get("nfev"), info.get("task")))
         return tikhonov._x
 
     def _prox_g(self, t, tau, dimension):

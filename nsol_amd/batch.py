@@ -2,7 +2,8 @@
 
 The reference has no notion of a batch or of several devices; one volume is one
 independent solve, so the shard rule is: volume i -> rank i % world_size, no
-per-iteration communication, and ONE gather of the results at the end
+per-iteration communication, and ONE gather of the results at the end (a rank's
+results as one buffer)
 (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
 tests).
 """
@@ -60,22 +61,23 @@ def solve_batch(solve_one, n_items, group=None, dst=0):
     stage_host = on_gpu and dist.get_backend(group) == "gloo"
     device = torch.device("cuda", torch.cuda.current_device()) \
         if on_gpu and not stage_host else torch.device("cpu")
+    # ONE gather: a rank's results travel as one buffer of `rounds` slots (a rank that
+    # owns fewer volumes -- n_items not a multiple of world_size -- leaves its last
+    # slot unused), and the root hands out views of what arrived, in item order.
     rounds = (n_items + world - 1) // world
-    out = [None] * n_items
-    for r in range(rounds):
-        if r < len(local):
-            send = local[r].contiguous().view(-1)
-            if stage_host:
-                send = send.cpu()  # rehearsal without RCCL: stage through host
-        else:      # no item in this (ragged) round: a dummy of the agreed shape
-            send = torch.zeros(numel, dtype=dtype, device=device)
-        if rank == dst:
-            bucket = [torch.empty_like(send) for _ in range(world)]
-            dist.gather(send, gather_list=bucket, dst=dst, group=group)
-            for src in range(world):
-                i = r * world + src
-                if i < n_items:
-                    out[i] = bucket[src]
-        else:
-            dist.gather(send, gather_list=None, dst=dst, group=group)
-    return out if rank == dst else None
+    if len(local) == rounds == 1:
+        send = local[0].contiguous().view(-1)
+        if stage_host:
+            send = send.cpu()      # rehearsal without RCCL: stage through host
+    else:
+        alloc = torch.zeros if len(local) < rounds else torch.empty
+        send = alloc(rounds * numel, dtype=dtype, device=device)
+        for r, t in enumerate(local):
+            send[r * numel:(r + 1) * numel].copy_(t.contiguous().view(-1))
+    if rank != dst:
+        dist.gather(send, gather_list=None, dst=dst, group=group)
+        return None
+    bucket = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, gather_list=bucket, dst=dst, group=group)
+    return [bucket[i % world][(i // world) * numel:(i // world + 1) * numel]
+            for i in range(n_items)]

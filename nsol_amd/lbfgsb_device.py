@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, _timing, ops
 from .device import suffix, stream_ptr
 
 
@@ -19,7 +19,9 @@ WINDOW_STRETCH = 1.5       # (config 4's Huber run: 52 -> 30 windows, same itera
 
 
 def _fn(name, t):
-    return getattr(_lib.load(), "nsol_lb_%s_%s" % (name, suffix(t)))
+    fn = getattr(_lib.load(), "nsol_lb_%s_%s" % (name, suffix(t)))
+    kt = _timing.active()              # (measurement only: bench.py / bench_admm.py)
+    return fn if kt is None else kt.wrap("lb_" + name, fn)
 
 
 def _p(t):

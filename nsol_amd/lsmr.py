@@ -307,7 +307,7 @@ class MinresCoefficients(object):
         self.w = (e - oldeps * w1 - delta * self.w2) / gamma
         self.x = self.x + phi * self.w
 
-    def lsmr_tests(self, normb2):
+    def lsmr_tests(self, normb2, eps=2.220446049250313e-16):
         """The quantities SciPy's LSMR tests after iteration k = itn
         (scipy lsmr.py:416-449), from the Lanczos / MINRES scalars.  With
         x_k = V_k z (orthonormal v_j), Abar = [A; sa B], M = Abar'Abar,
@@ -318,7 +318,8 @@ class MinresCoefficients(object):
             ||r_k||^2     = ||b||^2 - 2 beta_1 z_1 + z' T_k z     (normr^2)
             ||x_k||       = ||z||
         Returns (test1, test2, t1) = (normr / normb, normar / (normA normr),
-        test1 / (1 + normA normx / normb))."""
+        test1 / (1 + normA normx / normb)); eps: the rounding unit of the vectors the
+        scalars were summed over."""
         k = self.itn
         z = self.x[:k]
         a = np.asarray(self.alfas[:k])
@@ -326,7 +327,16 @@ class MinresCoefficients(object):
         if k > 1:
             quad += 2.0 * float(np.dot(np.asarray(self.betas[:k - 1]),
                                        z[:-1] * z[1:]))
-        normr2 = normb2 - 2.0 * self.beta1 * float(z[0]) + quad
+        cross = 2.0 * self.beta1 * float(z[0])
+        normr2 = normb2 - cross + quad
+        # normr^2 is formed by cancellation from sums over vectors of rounding unit
+        # `eps` (the Lanczos relation behind it holds to about that): a value within
+        # rounding of its terms says nothing -- not even its sign.  SciPy's own
+        # estimate stays positive through its recurrences and it would iterate on
+        # (atol = btol = 0), so such a residual is reported as unknown (NaN: none of
+        # the tests below fires on it) instead of as an exact zero (istop 1).
+        if abs(normr2) <= 64.0 * eps * (normb2 + abs(cross) + abs(quad)):
+            return float("nan"), float("nan"), float("nan")
         normr = math.sqrt(normr2) if normr2 > 0 else 0.0
         normb = math.sqrt(normb2)
         normA = math.sqrt(float(np.sum(a)))
@@ -428,7 +438,7 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     normb2 = rhs_norm2()
 
     def scipy_stop(co):
-        return _scipy_stop(co, normb2)
+        return _scipy_stop(co, normb2, float(torch.finfo(x_like.dtype).eps))
     LAST_FORM[0] = "lanczos"
     ys, betas = [g], [beta1]
     co = MinresCoefficients(maxiter + 1, beta1)
@@ -499,10 +509,11 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     return x, istop, k
 
 
-def _scipy_stop(co, normb2):
+def _scipy_stop(co, normb2, eps=2.220446049250313e-16):
     """istop of scipy lsmr.py:432-449 after iteration co.itn (0: go on), atol = btol =
-    0: the tests on machine precision (4, 5) and on exact zeros (1, 2)."""
-    test1, test2, t1 = co.lsmr_tests(normb2)
+    0: the tests on machine precision (4, 5) and on exact zeros (1, 2).  eps: see
+    MinresCoefficients.lsmr_tests."""
+    test1, test2, t1 = co.lsmr_tests(normb2, eps)
     stop = 0
     if 1 + test2 <= 1:
         stop = 5
@@ -535,7 +546,9 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
     half_a, half_b = halves
     lb.init()
     ys = [g]
-    t, q0 = torch.empty_like(x_like), torch.empty_like(x_like)
+    # (the lean halves keep no q0 array: the second half forms the step's K'K y itself)
+    t = torch.empty_like(x_like)
+    q0 = None if getattr(half_a, "lean", False) else torch.empty_like(x_like)
     fetchers = ops.scalar_fetchers(x_like.device, 4, _LAG + 1)
     state = {"co": None, "betas": None, "istop": 7, "normb2": None, "verdict": None}
 
@@ -556,7 +569,7 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
         alfa = (tt + lb.rho_grad * gg) / nb2 + lb.rho_ident
         beta_next = math.sqrt(nb2n) if nb2n > 0 else 0.0
         co.step(alfa, beta_next)
-        stop = _scipy_stop(co, state["normb2"])
+        stop = _scipy_stop(co, state["normb2"], float(torch.finfo(x_like.dtype).eps))
         if j + 1 < maxiter:
             if stop == 0 and (beta_next == 0 or not math.isfinite(beta_next)):
                 stop = 2                                  # Krylov space exhausted
@@ -588,6 +601,10 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
     while not stopped and done < last:
         stopped = digest(done, fetchers[done % (_LAG + 1)].wait())
         done += 1
+    # (an early stop leaves copies of later steps' sums in flight on the side stream:
+    # they read lb.board, which is freed with this frame -- let them finish first)
+    for j in range(done, last):
+        fetchers[j % (_LAG + 1)].wait()
     if state["verdict"] == "zero":
         return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
     if state["verdict"] == "weak":
@@ -601,6 +618,35 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
     x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)],
                          bounds=x_bounds)
     return x, state["istop"], k
+
+
+def _operators_in_float64(A, A_adj, x_like):
+    """(A, A_adj) for a float32 solve that is promoted to float64, or None when the
+    caller's operators cannot follow: a foreign NumPy callable behind a float32
+    BridgedCallable is bridged in float64 instead; a device operator is asked once
+    (a zero vector through A and A_adj) whether it answers float64 with float64 --
+    one bound to float32 tensors (dense taps uploaded in float32, a caller's own
+    float32 kernel) does not, and the solve then stays in float32."""
+    import torch
+    from .bridge import BridgedCallable, _is_gpu_failure
+
+    def widen(f):
+        return BridgedCallable(f.fn, np.float64) if isinstance(f, BridgedCallable) else f
+    A64, At64 = widen(A), widen(A_adj)
+    n = x_like.numel()
+    try:
+        r = A64(torch.zeros(n, dtype=torch.float64, device=x_like.device))
+        if not (isinstance(r, torch.Tensor) and r.is_cuda and r.dtype == torch.float64):
+            return None
+        r = At64(r.contiguous().view(-1))
+        if not (isinstance(r, torch.Tensor) and r.is_cuda and
+                r.dtype == torch.float64 and r.numel() == n):
+            return None
+    except (TypeError, AttributeError, ValueError, RuntimeError) as e:
+        if _is_gpu_failure(e):
+            raise
+        return None
+    return A64, At64
 
 
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
@@ -622,13 +668,16 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     caller's array is then only read: the normal-equations form folds the factor into a
     coefficient, the bidiagonalisation scales into a copy)."""
     import torch
+    wide = None
     if bmode == ops.B_NONE and PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 \
             and maxiter > PROMOTE_FROM_ITERATIONS:
         # (no regulariser at all: the same, more so)
+        wide = _operators_in_float64(A, A_adj, x_like)
+    if wide is not None:
         LAST_PROMOTED[0] = True
         x64, istop, itn = lsmr_fused(
-            A, A_adj, b_top.double(), None, bmode, shape, w, sa, x_like.double(), maxiter,
-            atol=atol, btol=btol, conlim=conlim, A_axpby=A_axpby, own_b=True,
+            wide[0], wide[1], b_top.double(), None, bmode, shape, w, sa, x_like.double(),
+            maxiter, atol=atol, btol=btol, conlim=conlim, A_axpby=A_axpby, own_b=True,
             x_bounds=x_bounds)
         return x64.to(x_like.dtype), istop, itn
     if atol == 0.0 and btol == 0.0 and allow_normal and \
@@ -643,13 +692,16 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         # nothing was consumed)
         if PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 and \
                 maxiter > PROMOTE_FROM_ITERATIONS:
+            wide = _operators_in_float64(A, A_adj, x_like)
+        if wide is not None:
             # float32 vectors cannot hold the 1e-5 contract there, in EITHER form
             # (see PROMOTE_WEAK_REGULARISERS): this solve runs in float64, and as the
             # bidiagonalisation -- SciPy's own recurrence: in this regime an iterate
             # depends on the form at the 1e-6 level even in float64
             LAST_PROMOTED[0] = True
             x64, istop, itn = lsmr_fused(
-                A, A_adj, b_top.double(), None if b_bot is None else b_bot.double(),
+                wide[0], wide[1], b_top.double(),
+                None if b_bot is None else b_bot.double(),
                 bmode, shape, w, sa, x_like.double(), maxiter, atol=atol, btol=btol,
                 conlim=conlim, A_axpby=A_axpby, normb2=None, own_b=True, atb=None,
                 x_bounds=x_bounds, b_bot_scale=b_bot_scale, allow_normal=False)

@@ -7,7 +7,7 @@ torch stream.  No arithmetic is done by torch itself.
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, _timing
 from .device import suffix, stream_ptr, empty_like
 
 MODES = {"constant": 0, "wrap": 1, "nearest": 2, "reflect": 3, "mirror": 4}
@@ -16,7 +16,9 @@ PD_REG_TV, PD_REG_HUBER, PD_DATA_L2, PD_DATA_L1 = 0, 1, 0, 2
 
 
 def _fn(name, t):
-    return getattr(_lib.load(), "nsol_%s_%s" % (name, suffix(t)))
+    fn = getattr(_lib.load(), "nsol_%s_%s" % (name, suffix(t)))
+    kt = _timing.active()              # (measurement only: bench.py / bench_admm.py)
+    return fn if kt is None else kt.wrap(name, fn)
 
 
 def _p(t):
@@ -27,6 +29,22 @@ def _chk(t):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
         raise TypeError("expected a contiguous HIP device tensor")
     return t
+
+
+_bump = torch.autograd.graph.increment_version
+
+
+def _wrote(first, *more):
+    """The kernels write through raw pointers, which torch cannot see: count the
+    write on the tensors' version counters (views share their base's).  That counter
+    is what the caches of b / x_scale, A^T b and |b|^2 are keyed on
+    (nsol_amd/_caches.py).  Returns its first argument."""
+    if first is not None:
+        _bump(first)
+    for t in more:
+        if t is not None:
+            _bump(t)
+    return first
 
 
 def _same(x, *others):
@@ -75,7 +93,7 @@ def grad(x, shape, w, out=None):
         out = empty_like(x, ndim * x.numel())
     _lib.check(_fn("grad", x)(_p(x), _p(out), ndim, nz, ny, nx, w[0], w[1],
                               w[2], stream_ptr()), "nsol_grad")
-    return out
+    return _wrote(out)
 
 
 def grad_adj(p, shape, w, out=None):
@@ -85,7 +103,7 @@ def grad_adj(p, shape, w, out=None):
         out = empty_like(p, nz * ny * nx)
     _lib.check(_fn("grad_adj", p)(_p(p), _p(out), ndim, nz, ny, nx, w[0], w[1],
                                   w[2], stream_ptr()), "nsol_grad_adj")
-    return out
+    return _wrote(out)
 
 
 def grad_adj_axpy(p, x, tau, shape, w, out=None):
@@ -103,7 +121,7 @@ def grad_adj_axpy(p, x, tau, shape, w, out=None):
     _lib.check(_fn("grad_adj_axpy", p)(_p(p), _p(x), _p(out), ndim, nz, ny, nx,
                                        w[0], w[1], w[2], float(tau),
                                        stream_ptr()), "nsol_grad_adj_axpy")
-    return out
+    return _wrote(out)
 
 
 def extrapolate(a, b, theta, out=None):
@@ -113,7 +131,7 @@ def extrapolate(a, b, theta, out=None):
         out = empty_like(a)
     _lib.check(_fn("extrapolate", a)(_p(out), _p(a), _p(b), float(theta),
                                      a.numel(), stream_ptr()), "nsol_extrapolate")
-    return out
+    return _wrote(out)
 
 
 def diff_axis(x, shape, direction, adjoint, w):
@@ -123,7 +141,7 @@ def diff_axis(x, shape, direction, adjoint, w):
     _lib.check(_fn("diff_axis", x)(_p(x), _p(out), int(direction),
                                    int(bool(adjoint)), nz, ny, nx, float(w),
                                    stream_ptr()), "nsol_diff_axis")
-    return out
+    return _wrote(out)
 
 
 def corr_axis(x, shape, axis3, taps, centre, mode, out=None):
@@ -137,7 +155,7 @@ def corr_axis(x, shape, axis3, taps, centre, mode, out=None):
         _p(x), _p(out), int(axis3), nz, ny, nx, taps.ctypes.data,
         int(taps.size), int(centre), MODES[mode], stream_ptr()),
         "nsol_corr_axis")
-    return out
+    return _wrote(out)
 
 
 def corr3_wrap(x, shape, taps_z, taps_y, taps_x, out=None):
@@ -157,7 +175,7 @@ def corr3_wrap(x, shape, taps_z, taps_y, taps_x, out=None):
     if rc == -2:
         return None
     _lib.check(rc, "nsol_corr3_wrap")
-    return out
+    return _wrote(out)
 
 
 def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True,
@@ -183,6 +201,7 @@ def corr3_wrap_axpby(x, io, shape, taps_z, taps_y, taps_x, ca, cb, sync=True,
     if rc == -2:
         return None
     _lib.check(rc, "nsol_corr3_wrap_axpby")
+    _wrote(io)
     return float(res.item()) if sync else res
 
 
@@ -211,6 +230,7 @@ def corr3_wrap_norms(x, out, shape, taps_z, taps_y, taps_x, w, result):
     if rc == -2:
         return None
     _lib.check(rc, "nsol_corr3_wrap_norms")
+    _wrote(out)
     return result
 
 
@@ -258,6 +278,7 @@ def corr3_lanczos_a(y, y_prev, t, q0, shape, taps_z, taps_y, taps_x, lb, step):
     if rc == -2:
         return False
     _lib.check(rc, "nsol_corr3_wrap_lanczos_a")
+    _wrote(t, q0)
     return True
 
 
@@ -283,6 +304,7 @@ def corr3_lanczos_a2(y, t, shape, taps_z, taps_y, taps_x, lb, step):
     if rc == -2:
         return False
     _lib.check(rc, "nsol_corr3_wrap_lanczos_a2")
+    _wrote(t)
     return True
 
 
@@ -305,6 +327,7 @@ def corr3_lanczos_b2(t, y, y_prev, y_new, shape, taps_z, taps_y, taps_x, lb, ste
     if rc == -2:
         return False
     _lib.check(rc, "nsol_corr3_wrap_lanczos_b2")
+    _wrote(y_new)
     return True
 
 
@@ -346,6 +369,7 @@ def corr3_lanczos_b(t, q0, y, y_new, shape, taps_z, taps_y, taps_x, lb, step):
     if rc == -2:
         return False
     _lib.check(rc, "nsol_corr3_wrap_lanczos_b")
+    _wrote(y_new)
     return True
 
 
@@ -358,7 +382,7 @@ def corr_dense(x, shape, taps_dev, kshape3, centre3, mode):
         _p(x), _p(out), nz, ny, nx, _p(taps_dev), kshape3[0], kshape3[1],
         kshape3[2], centre3[0], centre3[1], centre3[2], MODES[mode],
         stream_ptr()), "nsol_corr_dense")
-    return out
+    return _wrote(out)
 
 
 # --------------------------------------------------------- element-wise ----
@@ -370,7 +394,7 @@ def lincomb2(a, x, b, y, out=None):
         _same(x, out)
     _lib.check(_fn("lincomb2", x)(_p(out), float(a), _p(x), float(b), _p(y),
                                   x.numel(), stream_ptr()), "nsol_lincomb2")
-    return out
+    return _wrote(out)
 
 
 def lincomb3(a, x, b, y, c, z, out=None):
@@ -382,7 +406,7 @@ def lincomb3(a, x, b, y, c, z, out=None):
     _lib.check(_fn("lincomb3", x)(_p(out), float(a), _p(x), float(b), _p(y),
                                   float(c), _p(z), x.numel(), stream_ptr()),
                "nsol_lincomb3")
-    return out
+    return _wrote(out)
 
 
 def lincomb_many(vecs, coefs, out=None, bounds=None):
@@ -406,13 +430,16 @@ def lincomb_many(vecs, coefs, out=None, bounds=None):
             _lib.check(_fn("lincomb_clip", x)(
                 _p(out), x.numel(), len(vecs), ctypes.cast(ptrs, ctypes.c_void_p),
                 co.ctypes.data, lo, hi, stream_ptr()), "nsol_lincomb_clip")
-            return out
+            return _wrote(out)
         return clip(lincomb_many(vecs, coefs, out=out), bounds[0], bounds[1], out=out)
     fn = getattr(_lib.load(), "nsol_lb_wcomb_%s" % suffix(x))
+    kt = _timing.active()
+    if kt is not None:
+        fn = kt.wrap("lb_wcomb", fn)
     _lib.check(fn(_p(out), x.numel(), None, 1.0, 0, None, None, len(vecs),
                   ctypes.cast(ptrs, ctypes.c_void_p), co.ctypes.data,
                   stream_ptr()), "nsol_lb_wcomb")
-    return out
+    return _wrote(out)
 
 
 def scale(x, a, divide=False, out=None):
@@ -421,7 +448,7 @@ def scale(x, a, divide=False, out=None):
         out = empty_like(x)
     _lib.check(_fn("scale", x)(_p(out), _p(x), float(a), int(bool(divide)),
                                x.numel(), stream_ptr()), "nsol_scale")
-    return out
+    return _wrote(out)
 
 
 def _clip_bounds(x, lo, hi):
@@ -440,7 +467,7 @@ def clip(x, lo, hi, out=None):
     lo, hi = _clip_bounds(x, lo, hi)
     _lib.check(_fn("clip", x)(_p(out), _p(x), lo, hi, x.numel(),
                               stream_ptr()), "nsol_clip")
-    return out
+    return _wrote(out)
 
 
 def prox_dual_clamp(x, den=1.0, out=None):
@@ -450,7 +477,7 @@ def prox_dual_clamp(x, den=1.0, out=None):
     _lib.check(_fn("prox_dual_clamp", x)(_p(out), _p(x), float(den),
                                          x.numel(), stream_ptr()),
                "nsol_prox_dual_clamp")
-    return out
+    return _wrote(out)
 
 
 def prox_ell2(x, bt, tau, out=None):
@@ -459,7 +486,7 @@ def prox_ell2(x, bt, tau, out=None):
         out = empty_like(x)
     _lib.check(_fn("prox_ell2", x)(_p(out), _p(x), _p(bt), float(tau),
                                    x.numel(), stream_ptr()), "nsol_prox_ell2")
-    return out
+    return _wrote(out)
 
 
 def prox_ell1(x, bt, tau, out=None):
@@ -468,7 +495,7 @@ def prox_ell1(x, bt, tau, out=None):
         out = empty_like(x)
     _lib.check(_fn("prox_ell1", x)(_p(out), _p(x), _p(bt), float(tau),
                                    x.numel(), stream_ptr()), "nsol_prox_ell1")
-    return out
+    return _wrote(out)
 
 
 # ------------------------------------------------------------ reductions ----
@@ -518,7 +545,7 @@ def loss_cost_grad(r, loss, f_scale, want_grad=True, out=None, minus=None,
         _lib.check(_fn("loss_residual_cost_grad", r)(
             _p(r), _p(minus), _p(g), r.numel(), LOSSES[loss], float(f_scale),
             _p(res), _p(ws), stream_ptr()), "nsol_loss_residual_cost_grad")
-    return (res if result is not None else float(res.item())), g
+    return (res if result is not None else float(res.item())), _wrote(g)
 
 
 def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None, result=None):
@@ -535,7 +562,7 @@ def tk1_reg_cost_grad(x, g, shape, w, alpha, out=None, result=None):
     _lib.check(_fn("tk1_reg_cost_grad", x)(
         _p(x), _p(g), _p(out), ndim, nz, ny, nx, w[0], w[1], w[2], float(alpha),
         _p(res), _p(ws), stream_ptr()), "nsol_tk1_reg_cost_grad")
-    return (res if result is not None else float(res.item())), out
+    return (res if result is not None else float(res.item())), _wrote(out)
 
 
 _ws3 = {}
@@ -561,7 +588,7 @@ def tk1_reg_objective(x, g, d, shape, w, alpha, lo, hi, out, result, gold=None,
         _p(x), _p(g), _p(out), _p(d), _p(gold), _p(ydiff), ndim, nz, ny, nx, w[0], w[1],
         w[2], float(alpha), float(lo), float(hi), _p(result), _p(_ws3[key]),
         stream_ptr()), "nsol_tk1_reg_objective")
-    return out
+    return _wrote(out, ydiff)
 
 
 def tk1_grad_norm(x, shape, w, result=None):
@@ -591,6 +618,7 @@ def tk1_lanczos(x, g, z, shape, w, alpha, c_g, c_x, c_z, out, result=None):
         _p(x), _p(g), _p(z), _p(out), ndim, nz, ny, nx, w[0], w[1], w[2],
         float(alpha), float(c_g), float(c_x), float(c_z), _p(res), _p(ws),
         stream_ptr()), "nsol_tk1_lanczos")
+    _wrote(out)
     return res if result is not None else float(res.item())
 
 
@@ -673,6 +701,7 @@ def pd_dual_step(xbar, p_in, p_out, shape, w, sigma, hden):
     _lib.check(_fn("pd_dual_step", xbar)(
         _p(xbar), _p(p_in), _p(p_out), ndim, nz, ny, nx, w[0], w[1], w[2],
         float(sigma), float(hden), stream_ptr()), "nsol_pd_dual_step")
+    _wrote(p_out)
 
 
 def pd_primal_step(p, x, xbar, bt, shape, w, tau, tl, theta, flags):
@@ -681,6 +710,7 @@ def pd_primal_step(p, x, xbar, bt, shape, w, tau, tl, theta, flags):
         _p(p), _p(x), _p(xbar), _p(bt), ndim, nz, ny, nx, w[0], w[1], w[2],
         float(tau), float(tl), float(theta), int(flags), stream_ptr()),
         "nsol_pd_primal_step")
+    _wrote(x, xbar)
 
 
 def pd_fused_iter(xbar_in, xbar_out, x, bt, p_in, p_out, shape, w, sigma,
@@ -691,6 +721,7 @@ def pd_fused_iter(xbar_in, xbar_out, x, bt, p_in, p_out, shape, w, sigma,
         nz, ny, nx, w[0], w[1], w[2], float(sigma), float(hden), float(tau),
         float(tl), float(theta), int(flags), stream_ptr()),
         "nsol_pd_fused_iter")
+    _wrote(xbar_out, x, p_out)
 
 
 def pd_fused2_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
@@ -708,6 +739,7 @@ def pd_fused2_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
     if rc == -2:
         return False
     _lib.check(rc, "nsol_pd_fused2_iter")
+    _wrote(xbar_out, x_out, p_out)
     return True
 
 
@@ -729,6 +761,7 @@ def pd_fusedk_iter(xbar_in, xbar_out, x_in, x_out, bt, p_in, p_out, shape, w,
     if rc == -2:
         return False
     _lib.check(rc, "nsol_pd_fusedk_iter")
+    _wrote(xbar_out, x_out, p_out)
     return True
 
 
@@ -832,6 +865,7 @@ def _repeat_with_a_launch_per_iteration(r):
         r.tau.ctypes.data, r.theta.ctypes.data, n_it, int(bool(r.p_is_zero)),
         float(r.gamma_huber), int(r.flags) | PD_RUN_X_MAY_SWAP,
         ctypes.addressof(slot), stream_ptr()), "nsol_pd_run")
+    _wrote(xb_out, x_out, p_out)
     if not (slot.value & 1):              # final xbar / p in the scratch pair
         xb_out.copy_(xb0)
         p_out.copy_(p0)
@@ -914,6 +948,7 @@ def pd_persist_run(xbar, x, bt, p, shape, w, lmbda, sigma, tau, theta, p_is_zero
     if rc == -2:
         return False
     _lib.check(rc, "nsol_pd_persist_run")
+    _wrote(*dst)
     ws.record_stream(torch.cuda.current_stream())      # freed once the run is done
     _pending_runs.append(PersistRun(
         slot, stream_ptr(), (xbar, x, p), dst, bt, tuple(shape), tuple(w), lmbda,
@@ -944,6 +979,10 @@ def row_pitch(shape, like):
         return 0
     vec = 16 // like.element_size()
     nx = int(shape[2])
+    if nx < 2 * vec:
+        # (the pitched one-iteration kernel -- a run's odd trailing iteration -- needs
+        # two vectors per row, nsol_pd.hip fused_iter_impl: such rows stay contiguous)
+        return 0
     return 0 if nx % vec == 0 else (nx + vec - 1) // vec * vec
 
 
@@ -952,7 +991,7 @@ def to_pitched(t, shape, pitch, comps=1, fill=0.0):
     nz, ny, nx = (int(v) for v in shape)
     out = torch.full((comps * nz * ny * pitch,), fill, dtype=t.dtype, device=t.device)
     out.view(comps * nz, ny, pitch)[:, :, :nx].copy_(t.view(comps * nz, ny, nx))
-    return out
+    return _wrote(out)
 
 
 def from_pitched(t, shape, pitch, comps=1):
@@ -991,6 +1030,7 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
             float(gamma_huber),
             int(flags) | (PD_RUN_X_MAY_SWAP if swap_ok and x_alt is not None else 0),
             ctypes.addressof(slot), stream_ptr()), "nsol_pd_run_pitched")
+        _wrote(xbar0, xbar1, x, x_alt, p0, p1)
         if slot.value & 2:
             x.data, x_alt.data = x_alt.data, x.data
         return int(slot.value) & 1
@@ -1027,6 +1067,7 @@ def pd_run(xbar0, xbar1, x, bt, p0, p1, shape, w, lmbda, sigma, tau, theta,
         int(bool(p_is_zero)), float(gamma_huber),
         int(flags) | (PD_RUN_X_MAY_SWAP if swap_ok and x_alt is not None else 0),
         ctypes.addressof(slot), stream_ptr()), "nsol_pd_run")
+    _wrote(xbar0, xbar1, x, x_alt, p0, p1)
     if slot.value & 2:
         x.data, x_alt.data = x_alt.data, x.data
     return int(slot.value) & 1
@@ -1043,11 +1084,13 @@ def admm_vw_update(x, v, w_, c, rhs, shape, w, thr, rhs_scale, want_norm=False):
             _p(x), _p(v), _p(w_), _p(c), _p(rhs), ndim, nz, ny, nx, w[0], w[1],
             w[2], float(thr), float(rhs_scale), _p(res), _p(ws), stream_ptr()),
             "nsol_admm_vw_update_norm")
+        _wrote(v, w_, rhs)
         return float(res.item())
     _lib.check(_fn("admm_vw_update", x)(
         _p(x), _p(v), _p(w_), _p(c), _p(rhs), ndim, nz, ny, nx, w[0], w[1],
         w[2], float(thr), float(rhs_scale), stream_ptr()),
         "nsol_admm_vw_update")
+    _wrote(v, w_, rhs)
 
 
 def vector_shrink(t, ndim, thr, out=None):
@@ -1057,7 +1100,7 @@ def vector_shrink(t, ndim, thr, out=None):
     _lib.check(_fn("vector_shrink", t)(_p(t), _p(out), int(ndim),
                                        t.numel() // int(ndim), float(thr),
                                        stream_ptr()), "nsol_vector_shrink")
-    return out
+    return _wrote(out)
 
 
 # ----------------------------------------------------------------- LSMR ----
@@ -1114,6 +1157,7 @@ def lsmr_u_update(Av, v, u_top, u_bot, bmode, shape, w, c_av, c_bv, c_u,
         _p(Av_ptr), _p(v), _p(u_top), _p(u_bot), int(bmode), ndim, nz, ny, nx,
         w[0], w[1], w[2], float(c_av), float(c_bv), float(c_u), _p(res),
         _p(ws), stream_ptr()), "nsol_lsmr_u_update")
+    _wrote(u_top, u_bot)
     return float(res.item()) if sync else res
 
 
@@ -1139,11 +1183,13 @@ def lsmr_v_update(Atu, u_bot, v, bmode, shape, w, c_atu, c_btu, c_v,
             _p(Atu), _p(u_bot), _p(v), _p(out), int(bmode), ndim, nz, ny, nx,
             w[0], w[1], w[2], float(c_atu), float(c_btu), float(c_v), _p(res),
             _p(ws), stream_ptr()), "nsol_lsmr_v_update_to")
+        _wrote(out)
         return float(res.item()) if sync else res
     _lib.check(_fn("lsmr_v_update", Atu)(
         _p(Atu), _p(u_bot), _p(v), int(bmode), ndim, nz, ny, nx, w[0], w[1],
         w[2], float(c_atu), float(c_btu), float(c_v), _p(res), _p(ws),
         stream_ptr()), "nsol_lsmr_v_update")
+    _wrote(v)
     return float(res.item()) if sync else res
 
 
@@ -1156,4 +1202,5 @@ def lsmr_hx_update(hbar, x, h, v, c_hbar, c_x, c_h, c_v, sync=True):
         _p(hbar), _p(x), _p(h), _p(v), x.numel(), float(c_hbar), float(c_x),
         float(c_h), float(c_v), _p(res), _p(ws), stream_ptr()),
         "nsol_lsmr_hx_update")
+    _wrote(hbar, x, h)
     return float(res.item()) if sync else res

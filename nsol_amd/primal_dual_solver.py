@@ -188,11 +188,16 @@ class PrimalDualSolver(Solver):
             pq = [torch.zeros(plan["dim"] * np_, dtype=x.dtype, device=x.device),
                   torch.empty(plan["dim"] * np_, dtype=x.dtype, device=x.device)]
             btq = ops.to_pitched(bt, shape, pitch)
-            ops.pd_run(xbq[0], xbq[1], xq, btq, pq[0], pq[1], shape, plan["w"], lmbda,
-                       sig, ta, th, True, plan["gamma"], plan["flags"],
-                       x_alt=torch.zeros_like(xq), swap_ok=True, pitch=pitch)
-            self._x = ops.from_pitched(xq, shape, pitch)
-            return
+            try:
+                ops.pd_run(xbq[0], xbq[1], xq, btq, pq[0], pq[1], shape, plan["w"],
+                           lmbda, sig, ta, th, True, plan["gamma"], plan["flags"],
+                           x_alt=torch.zeros_like(xq), swap_ok=True, pitch=pitch)
+                self._x = ops.from_pitched(xq, shape, pitch)
+                return
+            except ValueError:
+                # the pitched entry declined (NSOL_EINVAL: the ragged-row form is
+                # switched off, knob pd_rag): the contiguous arrays are untouched
+                del xq, xbq, pq, btq
         if self._observer is None and not self._verbose:
             # scratch for the two-iterations-per-pass kernel (x ping-pong)
             x_alt = torch.empty_like(x) if self._iterations > 1 else None

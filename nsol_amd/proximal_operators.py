@@ -7,16 +7,19 @@ libnsol_hip.so.
 """
 import numpy as np
 
-from . import ops
+from . import _caches, ops
 from .device import is_device_tensor, to_device, to_numpy
 from .symbolic import Sym, TraceAbort, TauSym
 
 
-# small cache of b/x_scale on the device, keyed by the identity of the host
-# array the caller's lambda closes over (run_denoising.py:109-131 pass x0=b on
-# every call) AND by a fingerprint of its contents, so that an array the caller
-# changed in place between runs is uploaded again instead of served stale.
+# b / x_scale on the device for host arrays, keyed by the identity of the array the
+# caller's lambda closes over (run_denoising.py:109-131 pass x0=b on every call) AND
+# by a fingerprint of its contents, so that an array the caller changed in place
+# between runs is uploaded again instead of served stale.
 _bt_cache = []
+_caches._registered.append(_bt_cache)
+# the same for device tensors: nsol_amd/_caches.py says when an entry may be served
+_bt_dev_cache = _caches.DataCache(4)
 
 
 def _fingerprint(arr):
@@ -49,22 +52,19 @@ def scaled_data_on_device(x0, x_scale, like):
 
 
 def scaled_tensor(src, x_scale, dtype):
-    """src / x_scale for a device tensor, remembered while src is unchanged
-    (torch counts the in-place writes to a tensor's storage: `_version`) -- a
-    data term b or a start x0 that a caller's lambda hands over on every call
-    (prox_linear_least_squares inside a primal-dual loop builds a Tikhonov
-    solver per iteration) is divided once, not once per call."""
+    """src / x_scale for a device tensor, remembered while src is unchanged (the
+    reference divides on every call, proximal_operators.py:117-120) -- a data term b
+    or a start x0 that a caller's lambda hands over on every call
+    (prox_linear_least_squares inside a primal-dual loop builds a Tikhonov solver per
+    iteration) is divided once, not once per call."""
     flat = src.to(dtype).contiguous().view(-1)
     if flat.data_ptr() != src.data_ptr():      # converted / compacted: a temporary
         return ops.scale(flat, float(x_scale), divide=True)
-    key = (src.data_ptr(), src.numel(), str(dtype), src.device.index,
-           int(src._version), float(x_scale))
-    for k, ref, val in _bt_cache:
-        if k == key and ref.data_ptr() == key[0]:
-            return val
-    val = ops.scale(flat, float(x_scale), divide=True)
-    _bt_cache.append((key, src, val))       # (src kept alive: its address is the key)
-    del _bt_cache[:-4]
+    extra = float(x_scale)
+    val = _bt_dev_cache.lookup((src,), extra)
+    if val is None:
+        val = _bt_dev_cache.store((src,), extra,
+                                  ops.scale(flat, extra, divide=True))
     return val
 
 

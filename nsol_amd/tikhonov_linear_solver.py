@@ -17,7 +17,7 @@ import numpy as np
 import scipy.optimize
 import scipy.sparse.linalg
 
-from . import ops
+from . import _caches, ops
 from .bridge import BridgedCallable
 from .definitions import EPS
 from .device import is_device_tensor, to_device, to_numpy
@@ -53,36 +53,30 @@ USE_OBJECTIVE_EXTRAS = True
 USE_LOSS_EPILOGUE = True
 
 
-# A^T b for the (operator, data) pairs seen last: an outer loop (ADMM, primal-dual
-# with prox_linear_least_squares) builds one solver per iteration around the same b
-_atb_cache = []
+# A^T b and |b|^2 for the (operator, data) pairs seen last: an outer loop (ADMM,
+# primal-dual with prox_linear_least_squares) builds one solver per iteration around
+# the same b.  nsol_amd/_caches.py says when a remembered value may be served.
+_atb_cache = _caches.DataCache(2)
+_bnorm_cache = _caches.DataCache(2)
 
 
 def _adjoint_of_data(key_op, A_adj, b):
-    key = (id(key_op), b.data_ptr(), int(b._version), b.numel(), str(b.dtype))
-    for k, refs, val in _atb_cache:
-        if k == key and refs[0] is key_op:
-            return val
+    # the operator enters by identity: the entry holds it (a callable, not a volume)
+    hit = _atb_cache.lookup((b,), id(key_op))
+    if hit is not None and hit[0] is key_op:
+        return hit[1]
     val = A_adj(b)
     if val.untyped_storage().data_ptr() == b.untyped_storage().data_ptr():
         val = val.clone()                   # (an operator that hands back its argument)
-    _atb_cache.append((key, (key_op, b), val))
-    del _atb_cache[:-2]
+    _atb_cache.store((b,), id(key_op), (key_op, val))
     return val
-
-
-_bnorm_cache = []
 
 
 def _norm2_of_data(b):
     """|b|^2, kept like A^T b."""
-    key = (b.data_ptr(), int(b._version), b.numel(), str(b.dtype))
-    for k, ref, val in _bnorm_cache:
-        if k == key and ref is b:
-            return val
-    val = ops.dot(b, b)
-    _bnorm_cache.append((key, b, val))
-    del _bnorm_cache[:-2]
+    val = _bnorm_cache.lookup((b,))
+    if val is None:
+        val = _bnorm_cache.store((b,), None, ops.dot(b, b))
     return val
 
 
@@ -452,6 +446,8 @@ class TikhonovLinearSolver(LinearSolver):
             self._minimizer == "L-BFGS-B" and USE_DEVICE_LBFGSB and \
             is_device_tensor(x0) and warm["x"].data_ptr() == x0.data_ptr() and \
             warm["x"].numel() == x0.numel() and warm["x"].dtype == x0.dtype and \
+            warm["x"].untyped_storage() is x0.untyped_storage() and \
+            int(x0._version) == warm["version"] and \
             self._bounds is not None and \
             warm["bounds"] == (float(self._bounds[0]), float(self._bounds[1])) and \
             self._warm_key is not None and warm["key"] == self._objective_key()
@@ -499,7 +495,10 @@ class TikhonovLinearSolver(LinearSolver):
             self._minimize_info = info
             self._warm_result = None
             if info.get("jac") is not None:
-                self._warm_result = {"x": x, "f": info["fun"], "g": info["jac"],
+                # (x as it is now: a write to it that torch or nsol_amd.ops can see
+                # -- its version counter -- withdraws the hand-over)
+                self._warm_result = {"x": x, "version": int(x._version),
+                                     "f": info["fun"], "g": info["jac"],
                                      "pg": info.get("pg"),
                                      "bounds": (float(lo), float(hi)),
                                      "key": self._objective_key(),

@@ -1701,6 +1701,116 @@ def test_config4_at_contract_depth_matches_the_reference(nsol, golden, branch, d
                   "%s %s" % (branch, np.dtype(dtype).name)) < tol
 
 
+def _cfg4_problem(n):
+    """BASELINE config 4's workload as bench.py / bench_admm.py build it
+    (synth_volume(n, 0, 'clean') blurred with sigma = 2, + 2 % Gaussian noise), rounded
+    to float32 once so that both precisions are handed the very same numbers."""
+    import torch
+    from nsol_amd.synthetic import synth_volume
+    A, Aa, D, Da = _cfg4_ops(n)
+    clean = torch.from_numpy(synth_volume(n, 0, "clean", np.float64)).cuda().view(-1)
+    y = A(clean)
+    del clean
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    y = y + 0.02 * float(y.max()) * torch.randn(y.shape, device="cuda",
+                                                 dtype=torch.float64, generator=gen)
+    return (A, Aa, D, Da), y.float()
+
+
+@pytest.mark.parametrize("n,branch", [(128, "lsmr"), (128, "lbfgsb_huber"),
+                                      (256, "lsmr"), (256, "lbfgsb_huber"),
+                                      (512, "lsmr"), (512, "lbfgsb_huber")])
+def test_config4_float32_holds_the_contract_at_scale(nsol, n, branch):
+    """BASELINE config 4 as stated (rho = 0.1, alpha = 0.01, sigma = 2, 10 ADMM x 10
+    inner iterations; admm_linear_solver.py:165-218, tikhonov_linear_solver.py:146-158
+    and :197-220) in float32 -- what bench.py times -- against the package's own
+    float64 path on the same input, which test_config4_at_contract_depth_... pins to
+    the reference at 40^3 (<= 1e-8).  L-BFGS-B takes discrete decisions (line search,
+    breakpoints, free set) on sums over up to 1.3e8 elements: the decisions of the two
+    precisions (iterations and evaluations of every inner solve) are logged beside the
+    error."""
+    import torch
+    import nsol_amd.admm_linear_solver as admm
+    (A, Aa, D, Da), y32 = _cfg4_problem(n)
+    xs = float(y32.max())
+    kw = {} if branch == "lsmr" else dict(minimizer="L-BFGS-B", data_loss="huber",
+                                          data_loss_scale=1)
+    got, logs = {}, {}
+    for dtype in (np.float64, np.float32):
+        y = y32.double() if dtype == np.float64 else y32
+        s = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y, dimension=3,
+                                  alpha=0.01, rho=0.1, iterations=10, iter_max=10,
+                                  x_scale=xs, dtype=dtype, **kw)
+        s.run()
+        got[dtype] = s.get_x_device().double()
+        logs[dtype] = s.get_inner_log()
+        assert len(logs[dtype]) == 10
+        del s, y
+        torch.cuda.empty_cache()
+    assert bool(torch.isfinite(got[np.float32]).all())
+    differ = [i for i, (a, b) in enumerate(zip(logs[np.float64], logs[np.float32]))
+              if a[:3] != b[:3]]
+    note = "%d^3 %s; inner solves deciding differently: %s" % (
+        n, branch, ", ".join("%d: f64 %r f32 %r" % (i, logs[np.float64][i][1:3],
+                                                     logs[np.float32][i][1:3])
+                             for i in differ) or "none")
+    ref = got[np.float64].cpu().numpy()
+    assert rel_l2(got[np.float32].cpu().numpy(), ref, note) < F32_TOL, note
+
+
+def _tk_lsmr(b, x_scale, n=32):
+    import nsol_amd.tikhonov_linear_solver as tk
+    A, Aa, D, Da = _cfg4_ops(n)
+    s = tk.TikhonovLinearSolver(A=A, A_adj=Aa, B=D, B_adj=Da, b=b, x0=b, alpha=0.1,
+                                x_scale=x_scale, iter_max=10, dtype=np.float32)
+    s.run()
+    return s.get_x_device().clone()
+
+
+@pytest.mark.parametrize("x_scale", [1.0, 37.5])
+def test_data_caches_follow_writes_torch_cannot_see(nsol, x_scale):
+    """b / x_scale, A^T b and |b|^2 are remembered from solver to solver (an outer loop
+    builds one per iteration around the same b); the reference recomputes them on every
+    call (proximal_operators.py:117-120).  A caller that refills its resident b
+    (a) through nsol_amd.ops -- a ctypes launch on data_ptr(), which ops counts on the
+    tensor's version -- or (b) through a launch of its own followed by
+    nsol_amd.invalidate_caches(), gets the result a fresh process would."""
+    import torch
+    import nsol_amd
+    from nsol_amd import _lib, ops
+    from nsol_amd.device import stream_ptr
+    n = 32
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    ys = [50.0 + 10.0 * torch.randn(n ** 3, device="cuda", generator=gen)
+          for _ in range(3)]
+    fresh = []
+    for y in ys:                            # what a fresh process computes
+        nsol_amd.invalidate_caches()
+        fresh.append(_tk_lsmr(y.clone(), x_scale))
+    assert not torch.equal(fresh[0], fresh[1]) and not torch.equal(fresh[1], fresh[2])
+    nsol_amd.invalidate_caches()
+    b = ys[0].clone()
+    assert torch.equal(_tk_lsmr(b, x_scale), fresh[0])
+    assert torch.equal(_tk_lsmr(b, x_scale), fresh[0])      # (served from the caches)
+    # (a) refilled through the package's own front end
+    v = b._version
+    ops.scale(ys[1], 1.0, out=b)
+    assert b._version > v
+    assert torch.equal(_tk_lsmr(b, x_scale), fresh[1])
+    # (b) refilled by a foreign launch: the C ABI directly on the address
+    _lib.check(_lib.load().nsol_scale_f32(b.data_ptr(), ys[2].data_ptr(), 1.0, 0,
+                                          b.numel(), stream_ptr()), "nsol_scale")
+    nsol_amd.invalidate_caches()
+    assert torch.equal(_tk_lsmr(b, x_scale), fresh[2])
+    # an entry dies with the memory it was derived from: nothing keeps b alive
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.proximal_operators as po
+    del b
+    for c in (tk._atb_cache, tk._bnorm_cache, po._bt_dev_cache):
+        for _, refs, _ in c.entries:
+            assert all(r() is not None for r in refs)
+
+
 @pytest.mark.parametrize("bname", ["grad", "ident"])
 def test_lsmr_stops_where_scipys_does_when_the_krylov_space_runs_out(nsol, bname):
     """A 9-sample signal and iter_max = 15: SciPy's LSMR (atol = btol = 0) ends on
@@ -1777,6 +1887,57 @@ def test_weak_regularisers_in_float32_run_their_lsmr_in_float64(nsol, golden, bn
         errs[promote] = rel_l2(s.get_x(), ref, "%s %s promoted %d" % (bname, wname, promote))
     assert errs[True] < F32_TOL
     assert errs[True] < errs[False]
+
+
+@pytest.mark.parametrize("alpha", [0.0, 1e-3])
+def test_promoted_lsmr_takes_foreign_and_float32_bound_operators(nsol, alpha):
+    """A float32 Tikhonov solve without (or with a weak) regulariser and more than ten
+    iterations runs its LSMR in float64 (lsmr.PROMOTE_WEAK_REGULARISERS).  The caller's
+    operators have to follow: a NumPy-only callable is bridged in float64 and the
+    solve meets the float64 result; a device operator that only speaks float32 keeps
+    the solve in float32 -- neither raises (tikhonov_linear_solver.py:146-158 accepts
+    any callable)."""
+    import torch
+    import nsol_amd.tikhonov_linear_solver as tk
+    import nsol_amd.lsmr as L
+    from oracle import nsol_oracle as orc
+    n = 24
+    rng = np.random.default_rng(8)
+    y = 60.0 + 20.0 * rng.standard_normal(n ** 3)
+    xs = float(y.max())
+    _, _, Ao, _ = orc.flat_operators((n, n, n), None, np.diag([1.0, 1.0, 1.0]))
+    A_np = lambda x: Ao(np.asarray(x, dtype=np.float64))
+    A, Aa, D, Da = _cfg4_ops(n)          # (nsol_amd's: on the device, any dtype)
+
+    def run(ops4, dtype):
+        a, aa, d, da = ops4
+        s = tk.TikhonovLinearSolver(A=a, A_adj=aa, B=d, B_adj=da, b=y, x0=y,
+                                    alpha=alpha, x_scale=xs, iter_max=20, dtype=dtype)
+        s.run()
+        return s.get_x()
+    # NumPy-only callables: float64 run as the yardstick, float32 promoted
+    ref = run((A_np, A_np, D, Da), np.float64)
+    L.LAST_PROMOTED[0] = False
+    got = run((A_np, A_np, D, Da), np.float32)
+    assert L.LAST_PROMOTED[0]
+    assert rel_l2(got, ref, "numpy operators, alpha %g" % alpha) < F32_TOL
+    # a device operator bound to float32: the solve stays in float32 and runs
+    def only32(f):
+        def g(v):
+            if v.dtype != torch.float32:
+                raise TypeError("float32 only")
+            return f(v)
+        return g
+    L.LAST_PROMOTED[0] = False
+    got32 = run((only32(A), only32(Aa), D, Da), np.float32)
+    assert not L.LAST_PROMOTED[0]
+    # (what the float32 recurrence gives: the same bits as with the promotion off)
+    L.PROMOTE_WEAK_REGULARISERS = False
+    try:
+        assert np.array_equal(got32, run((A, Aa, D, Da), np.float32))
+    finally:
+        L.PROMOTE_WEAK_REGULARISERS = True
+    assert np.isfinite(got32).all()
 
 
 def test_foreign_numpy_callables_take_the_host_bridge(nsol, golden):
@@ -2688,6 +2849,7 @@ def test_solver_keeps_ragged_volumes_at_a_pitch(nsol):
     vectors: the run goes through nsol_pd_run_pitched_* and returns what the contiguous
     run returns, bit for bit."""
     import nsol_amd.primal_dual_solver as pd
+    from nsol_amd import _lib
     shape = (70, 131, 127)
     obs = 60.0 + 25.0 * np.random.default_rng(4).standard_normal(shape)
     outs = []
@@ -2701,18 +2863,48 @@ def test_solver_keeps_ragged_volumes_at_a_pitch(nsol):
         assert s.get_execution() == "fused"
         outs.append(s.get_x())
     assert np.array_equal(outs[0], outs[1])
+    # with the ragged-row kernels switched off the pitched entry declines a run that
+    # ends on a single iteration (25 = 8 x 3 + 1): the solver falls back to the
+    # contiguous layout instead of raising
+    _lib.set_param("pd_rag", 0)
+    s = _pd_solver(obs, "TV", "L1", 0.6, 25, 16.0, "ALG2", np.float32)
+    s.run()
+    assert np.isfinite(s.get_x()).all()
 
 
-@pytest.mark.parametrize("plan", [(12, 2, 103), (8, 3, 64), (12, 2, 64)])
-def test_timed_plans_at_512_are_bit_identical(nsol, plan):
+def test_short_rows_stay_contiguous(nsol):
+    """1024 x 1024 x 5: more than 2^20 voxels, rows shorter than two 16-byte vectors --
+    no pitched layout (ops.row_pitch), the contiguous ragged kernels run; against the
+    oracle after a run that ends on a single iteration."""
+    import torch
+    from nsol_amd import ops
+    from oracle import nsol_oracle as orc
+    shape = (1024, 1024, 5)
+    assert ops.row_pitch(shape, torch.empty(1, dtype=torch.float32)) == 0
+    assert ops.row_pitch((4, 4, 7), torch.empty(1, dtype=torch.float32)) == 0
+    assert ops.row_pitch((4, 4, 9), torch.empty(1, dtype=torch.float32)) == 12
+    assert ops.row_pitch((4, 4, 3), torch.empty(1, dtype=torch.float64)) == 0
+    obs = 60.0 + 25.0 * np.random.default_rng(6).standard_normal(shape)
+    s = _pd_solver(obs, "TV", "L2", 0.05, 4, 16.0, "ALG2", np.float32)
+    s.run()
+    assert s.get_execution() == "fused"
+    ref = orc.primal_dual_denoise(obs.flatten(), shape, "TV", "L2", 0.05, 4, 16.0, "ALG2")
+    assert rel_l2(s.get_x(), ref) < F32_TOL
+
+
+@pytest.mark.parametrize("plan,data", [((12, 2, 103), "L2"), ((8, 3, 64), "L2"),
+                                       ((12, 2, 64), "L2"), ((12, 2, 103), "L1")])
+def test_timed_plans_at_512_are_bit_identical(nsol, plan, data):
     """The configuration bench.py times (the tuner settles on 12 waves x 2 tiles
     x z-chunk 103 at 512^3: five z-chunk seams) and an 8-wave plan, pinned, over
     12 iterations (four depth-3 launches): x, xbar and p bit-identical to twelve
-    launches of the one-iteration kernel (primal_dual_solver.py:242-256)."""
+    launches of the one-iteration kernel (primal_dual_solver.py:242-256).  The timed
+    plan also with the l1 data term (proximal_operators.py:95-98): BASELINE config 5's
+    kernel flags at its size."""
     import torch
     from nsol_amd import ops
     shape = (512, 512, 512)
-    flags = ops.PD_REG_TV | ops.PD_DATA_L2
+    flags = ops.PD_REG_TV | (ops.PD_DATA_L2 if data == "L2" else ops.PD_DATA_L1)
     w = (1.0, 1.0, 1.0)
     ref = _run_pd_raw(shape, np.float32, 12, flags, enable2=0, w=w)
     before = ops.pd_fusedk_launches(3)

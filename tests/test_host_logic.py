@@ -612,3 +612,77 @@ def test_minres_coefficients_reproduce_lsmr_iterates():
             ref = sla.lsmr(Ahat, bhat, atol=0.0, btol=0.0, conlim=0.0, maxiter=j + 1)[0]
             assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref), (rho, j)
         assert co.itn == K and co.gmax / co.gmin < 1e3
+
+
+def test_data_cache_serves_only_what_is_provably_unchanged():
+    """nsol_amd/_caches.py: an entry is tied to the storage it was derived from (weak
+    reference: dropped when the memory is freed, never keeping it alive) and to torch's
+    version counter, which ops._wrote bumps for every kernel write; anything else is
+    the caller's to announce with nsol_amd.invalidate_caches()."""
+    import gc
+    import torch
+    import nsol_amd
+    from nsol_amd import _caches, ops
+    c = _caches.DataCache(2)
+    b = torch.arange(8, dtype=torch.float32)
+    assert c.lookup((b,), 2.0) is None
+    val = c.store((b,), 2.0, "b/2")
+    assert c.lookup((b,), 2.0) is val
+    assert c.lookup((b.view(2, 4).view(-1),), 2.0) is val   # a view of the same memory
+    assert c.lookup((b,), 3.0) is None                      # another x_scale
+    assert c.lookup((b[1:],), 2.0) is None                  # another window
+    b.add_(1.0)                                             # torch sees this write
+    assert c.lookup((b,), 2.0) is None
+    c.store((b,), 2.0, "new")
+    ops._wrote(b)                                           # a kernel wrote through data_ptr()
+    assert c.lookup((b,), 2.0) is None
+    c.store((b,), 2.0, "newer")
+    assert c.lookup((b,), 2.0) == "newer"
+    nsol_amd.invalidate_caches()
+    assert c.entries == [] and c.lookup((b,), 2.0) is None
+    # freed memory takes its entries along, and the cache never holds it
+    import weakref
+    c.store((b,), 2.0, "x")
+    alive = weakref.ref(b.untyped_storage())
+    del b
+    gc.collect()
+    assert alive() is None and c.entries == []
+    # only the newest `keep` entries stay
+    ts = [torch.zeros(4) for _ in range(3)]
+    for i, t in enumerate(ts):
+        c.store((t,), None, i)
+    assert len(c.entries) == 2 and c.lookup((ts[0],)) is None and c.lookup((ts[2],)) == 2
+
+
+def test_a_residual_lost_to_cancellation_is_unknown_not_zero():
+    """MinresCoefficients.lsmr_tests forms |r_k|^2 = |b|^2 - 2 beta_1 z_1 + z'T z by
+    cancellation.  On a consistent system with scalars summed over float32 vectors the
+    true value (<= 1e-9 |b|^2 here) is below the rounding of its terms and may come
+    out <= 0: SciPy (lsmr.py:416-449, atol = btol = 0) keeps a positive estimate and
+    iterates on, so the restated tests must not report istop 1 there."""
+    from nsol_amd.lsmr import MinresCoefficients, _scipy_stop
+    rng = np.random.default_rng(2)
+    n = 7
+    Ab = (np.eye(n) + 0.1 * rng.standard_normal((n, n))).astype(np.float32)
+    b = (Ab @ rng.standard_normal(n).astype(np.float32)).astype(np.float32)
+    M, g = (Ab.T @ Ab).astype(np.float32), (Ab.T @ b).astype(np.float32)
+    beta1 = float(np.linalg.norm(g))
+    v, vprev, beta = g / np.float32(beta1), np.zeros(n, np.float32), beta1
+    co = MinresCoefficients(12, beta1)
+    eps32 = float(np.finfo(np.float32).eps)
+    normb2 = float(b @ b)
+    seen_unknown = False
+    for k in range(1, n + 1):
+        y = (M @ v).astype(np.float32)
+        alfa = float(v @ y)
+        y = (y - np.float32(alfa) * v - np.float32(beta) * vprev * (k > 1)).astype(np.float32)
+        beta_new = float(np.linalg.norm(y))
+        co.step(alfa, beta_new)
+        t32 = co.lsmr_tests(normb2, eps32)
+        if np.isnan(t32[0]):
+            seen_unknown = True
+            assert _scipy_stop(co, normb2, eps32) == 0          # iterate on, as SciPy does
+            # (what the same scalars say without the guard is not to be trusted)
+            assert co.lsmr_tests(normb2)[0] < 1e-2
+        vprev, v, beta = v, y / np.float32(beta_new), beta_new
+    assert seen_unknown
