@@ -120,63 +120,40 @@ def cpu_baseline_c(sample_n, iters):
     return iters / dt, c_oracle.threads()
 
 
-def config4_line(n, runs=3):
+def config4_line(n, runs=3, cpu_sample=64):
     """BASELINE config 4 (sigma = 2 deconvolution, ADMMLinearSolver alpha = 0.01,
-    rho = 0.1, 10 ADMM x 10 LSMR iterations, float32) timed in THIS process so that
-    a driver-run number exists for it; bench_admm.py is the full instrument (its
-    roofline, both branches, the CPU beside it).  Median wall time of `runs` runs
-    after one that carries the one-time set-up."""
-    import torch
-    import nsol_amd.linear_operators as LO
-    import nsol_amd.admm_linear_solver as admm
-    import nsol_amd.lsmr as lsmr_mod
-    from nsol_amd.synthetic import synth_volume
-    shape, Z = (n, n, n), (3 * n, n, n)
-    lo = LO.LinearOperators3D()
-    A, A_adj = lo.get_gaussian_blurring_operators(np.diag([4.0, 4.0, 4.0]))
-    grad, grad_adj = lo.get_gradient_operators()
-    clean = torch.from_numpy(synth_volume(n, 0, "clean", np.float32)).cuda()
-    y = A(clean).flatten()
-    del clean
-    gen = torch.Generator(device="cuda").manual_seed(1)
-    y = y + 0.02 * float(y.max()) * torch.randn(y.shape, device="cuda", generator=gen)
-    ops_ = dict(A=lambda x: A(x.reshape(*shape)).flatten(),
-                A_adj=lambda x: A_adj(x.reshape(*shape)).flatten(),
-                B=lambda x: grad(x.reshape(*shape)).flatten(),
-                B_adj=lambda x: grad_adj(x.reshape(*Z)).flatten())
+    rho = 0.1, 10 ADMM x 10 inner iterations, float32) measured in THIS process so that
+    the driver's line carries it: both branches (LSMR / linear loss; L-BFGS-B / Huber
+    loss), each with seconds per run (median of `runs` runs after one that carries the
+    one-time set-up), its `roofline` (the dominant kernel's duration INSIDE a run:
+    event pairs around every C-ABI entry, bench_admm.kernels_in_run) and its
+    `cpu_baseline` (one ADMM iteration of the reference-style CPU path at cpu_sample^3,
+    extrapolated per voxel).  bench_admm.py prints the same record on its own."""
+    import bench_admm
+    rec = bench_admm.measure(n, 10, 10, "lsmr", "linear", runs + 1, cpu_sample)
+    hub = bench_admm.measure(n, 10, 10, "L-BFGS-B", "huber", runs + 1, cpu_sample)
 
-    def timed(**kw):
-        ts = []
-        for _ in range(runs + 1):
-            s = admm.ADMMLinearSolver(b=y, x0=y, dimension=3, alpha=0.01, rho=0.1,
-                                      iterations=10, iter_max=10,
-                                      x_scale=float(y.max()), dtype=np.float32,
-                                      **ops_, **kw)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            s.run()
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - t0)
-        return s, ts
-    s, times = timed()
-    finite = bool(torch.isfinite(s.get_x_device()).all().item())
-    med = median(times[1:])
-    # the robust-loss branch of the same configuration (GPU-resident L-BFGS-B)
-    sh, th = timed(minimizer="L-BFGS-B", data_loss="huber")
-    huber = {"minimizer": "L-BFGS-B", "data_loss": "huber",
-             "seconds_per_run": median(th[1:]), "value": 10.0 / median(th[1:]),
-             "unit": "ADMM iterations/s", "runs_s": th[1:], "first_run_s": th[0],
-             "result_finite": bool(torch.isfinite(sh.get_x_device()).all().item())}
-    del sh
-    return {"metric": "ADMM iterations/sec on %d^3 fp32 TV deconvolution" % n,
-            "workload": "BASELINE config 4: synth_volume(%d, 0, 'clean') blurred "
-                        "sigma = 2 + 2 %% noise; ADMMLinearSolver alpha=0.01 rho=0.1, "
-                        "10 ADMM x 10 LSMR iterations (minimizer lsmr, linear loss)" % n,
-            "value": 10.0 / med, "unit": "ADMM iterations/s", "seconds_per_run": med,
-            "runs_s": times[1:], "first_run_s": times[0],
-            "execution": s.get_execution(), "lsmr_step": lsmr_mod.LAST_FORM[0],
-            "result_finite": finite, "huber_branch": huber,
-            "see": "bench_admm.py (roofline and cpu_baseline of both branches)"}
+    def brief(r):
+        # (the per-entry table stays, without its min / max columns)
+        roof = dict(r["roofline"])
+        roof["kernels"] = {k: {f: v[f] for f in ("kernel", "launches_per_run",
+                                                 "avg_launch_ms", "ms_per_run",
+                                                 "bytes_per_voxel", "frac")
+                               if f in v}
+                           for k, v in roof["kernels"].items()}
+        return {"metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                "seconds_per_run": r["seconds_per_run"], "runs_s": r["runs"][1:],
+                "first_run_s": r["runs"][0], "workload": r["config"]["workload"],
+                "minimizer": r["config"]["minimizer"],
+                "data_loss": r["config"]["data_loss"],
+                "execution": r["config"]["execution"],
+                "lsmr_step": r["config"]["lsmr_form"],
+                "inner_solves": r["config"]["inner_solves"],
+                "result_finite": r["finite"], "roofline": roof,
+                "cpu_baseline": r.get("cpu_baseline")}
+    out = brief(rec)
+    out["huber_branch"] = brief(hub)
+    return out
 
 
 # ------------------------------------------------------------------ launcher
@@ -765,7 +742,8 @@ def main(argv=None):
             del p[:], xbar[:], inputs[:]
             torch.cuda.empty_cache()
             try:
-                out["config4"] = config4_line(n)
+                out["config4"] = config4_line(
+                    n, cpu_sample=0 if args.no_cpu_baseline else 64)
             except Exception as e:                  # never at the headline's expense
                 out["config4"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -128,80 +128,70 @@ def bytes_moved_per_admm_iteration(iter_max, blur_epilogue, prescaled_rhs,
         SETUP_BYTES - (40 if prescaled_rhs else 0)
 
 
-def time_kernels(shape, reps=20):
-    """Average launch duration of each kernel of the LSMR branch on vectors of
-    the run's size (HIP events on the launch stream, 3 warm-up launches)."""
+# C-ABI entries as nsol_amd/_timing.py names them -> (kernel key for BYTES / PMC_NAMES,
+# algorithmic bytes per voxel; a callable takes the entry's tag = number of vectors)
+ENTRIES = {
+    "corr3_wrap": ("k_blur3_dma", 8),
+    "corr3_wrap_axpby": ("k_blur3_dma_epi", 12),
+    "corr3_wrap_norms": ("k_blur3_dma_norms", 8),
+    "corr3_wrap_lanczos_a": ("k_blur3_lanczos_a", 16),
+    "corr3_wrap_lanczos_b": ("k_blur3_lanczos_b", 16),
+    "corr3_wrap_lanczos_a2": ("k_blur3_dma_norms", 8),
+    "corr3_wrap_lanczos_b2": ("k_blur3_lanczos_b2", 16),
+    "corr3_wrap_loss": ("k_blur3_loss", 12),
+    "tk1_grad_norm": ("k_tk1_norm", 4),
+    "tk1_lanczos": ("k_tk1_lanczos", 16),
+    "tk1_reg_cost_grad": ("k_tk1_cost_grad", 12),
+    # reads x, g (in place), d, the old gradient; writes the gradient and its difference
+    "tk1_reg_objective": ("k_tk1_objective", 24),
+    "lsmr_u_update": ("k_lsmr_u", 40),
+    "lsmr_v_update": ("k_lsmr_v", 24), "lsmr_v_update_to": ("k_lsmr_v", 24),
+    "lsmr_hx_update": ("k_lsmr_hx", 28),
+    "admm_vw_update": ("k_admm_vw", 40), "admm_vw_update_norm": ("k_admm_vw", 40),
+    "lincomb_clip": ("k_wcomb", lambda k: 4 * (k + 1)),
+    "lb_wcomb": ("k_wcomb", lambda k: 4 * (k + 2) + 1),
+    "lb_mdots": ("k_mdots", lambda k: 4 * (k + 1) + 1),
+    "lb_masked_gram_rgrad": ("k_masked_gram_mfma", lambda k: 4 * (k + 4) + 1),
+    "lb_subspace_step": ("k_subspace_step", lambda k: 4 * (k + 4) + 1 + 8),
+    "lb_subspace_step_r": ("k_subspace_step", lambda k: 4 * (k + 3) + 1 + 8),
+    "lb_cauchy_setup": ("k_cauchy_setup", 18),
+    "lb_cauchy_finish": ("k_cauchy_finish", 16),
+    "lb_projgr": ("k_projgr", 8),
+    "dot": ("k_dot", 8), "scale": ("k_map", 8), "clip": ("k_map", 8),
+    "lincomb2": ("k_map", 12), "grad": ("k_grad", 16),
+}
+# the integer argument that says how many vectors an entry runs over
+ENTRY_TAGS = {"lincomb_clip": 2, "lb_wcomb": 7, "lb_mdots": 1, "lb_masked_gram_rgrad": 1,
+              "lb_subspace_step": 2, "lb_subspace_step_r": 2}
+
+
+def kernels_in_run(run_once, nvox):
+    """Durations of the C-ABI entries INSIDE one run of the solver (event pairs around
+    every entry, nsol_amd/_timing.py): cold caches, real neighbours, the clocks of the
+    moment -- what rocprofv3 sees for the same run, not a replay on idle operands.
+    Returns (table by entry, wall seconds of that run)."""
     import torch
-    from nsol_amd import ops
-    n = int(np.prod(shape))
-    dev = torch.device("cuda", torch.cuda.current_device())
-    gen = torch.Generator(device=dev).manual_seed(5)
-    r = lambda m: torch.rand(m, device=dev, generator=gen)
-    v, ut, Av, h, hbar, x = r(n), r(n), r(n), r(n), r(n), r(n)
-    ub, vv, ww, rhs = r(3 * n), r(3 * n), r(3 * n), r(3 * n)
-    w = (1.0, 1.0, 1.0)
-    ev = HipEvents()
-    stream = torch.cuda.current_stream().cuda_stream
-    # the wrappers read their reduction result back (.item()); the launches are
-    # timed between events, the read-back falls outside
-    lib_u = lambda: ops.lsmr_u_update(Av, v, ut, ub, ops.B_GRAD, shape, w,
-                                      0.5, 0.1, -0.5, sync=False)
-    lib_v = lambda: ops.lsmr_v_update(Av, ub, v, ops.B_GRAD, shape, w, 0.5,
-                                      0.1, -0.5, sync=False)
-    lib_hx = lambda: ops.lsmr_hx_update(hbar, x, h, v, -0.3, 0.2, -0.4, 0.5,
-                                        sync=False)
-    lib_vw = lambda: ops.admm_vw_update(x, None, ww, None, rhs, shape, w, 0.1,
-                                        1.0)
-    import nsol_amd.kernels as K
-    taps = K.Kernels1D().get_gaussian(4.0)           # sigma = 2: 13 taps per axis
-    blur_out = torch.empty_like(v)
-    lib_blur = lambda: ops.corr3_wrap(v, shape, taps, taps, taps, out=blur_out)
-    out = {}
-    vts = [v, ut, Av, h, hbar, x, blur_out, r(n), r(n), r(n), r(n)]
-    x_out = torch.empty_like(v)
-    lib_x = lambda: ops.lincomb_many(vts, [0.1 * (k + 1) for k in range(11)],
-                                     out=x_out)
-    BYTES["k_wcomb"] = 4 * (11 + 1)
-    slot = torch.zeros(1, dtype=torch.float64, device=dev)
-    lib_epi = lambda: ops.corr3_wrap_axpby(v, blur_out, shape, taps, taps, taps, 1.0,
-                                           0.0, result=slot)
-    lib_reg = lambda: ops.tk1_grad_norm(v, shape, w, result=slot)
-    slot2 = torch.zeros(2, dtype=torch.float64, device=dev)
-    lib_norms = lambda: ops.corr3_wrap_norms(v, blur_out, shape, taps, taps, taps, w,
-                                             slot2)
-    lib_lz = lambda: ops.tk1_lanczos(h, Av, hbar, shape, w, 0.1, 0.5, -0.3, -0.2,
-                                     out=x_out, result=slot)
-    lb = ops.LanczosBoard(v, 4, 0.1, 0.0)
-    lb.board[0:1] = 1.0
-    lb.board[3:4] = 1.0
-    lb.init()
-    q0 = torch.empty_like(v)
-    lib_la = lambda: ops.corr3_lanczos_a(v, h, blur_out, q0, shape, taps, taps, taps, lb, 1)
-    lib_lb = lambda: ops.corr3_lanczos_b(blur_out, q0, v, x_out, shape, taps, taps, taps,
-                                         lb, 1)
-    lib_lb2 = lambda: ops.corr3_lanczos_b2(blur_out, v, h, x_out, shape, taps, taps, taps,
-                                           lb, 1)
-    for _ in range(30):        # (clocks up before the first timed kernel)
-        lib_blur()
-    for name, fn in (("k_blur3_dma", lib_blur), ("k_lsmr_u", lib_u),
-                     ("k_lsmr_v", lib_v), ("k_lsmr_hx", lib_hx),
-                     ("k_admm_vw", lib_vw), ("k_wcomb", lib_x),
-                     ("k_blur3_dma_epi", lib_epi), ("k_tk1_norm", lib_reg),
-                     ("k_tk1_lanczos", lib_lz), ("k_blur3_dma_norms", lib_norms),
-                     ("k_blur3_lanczos_a", lib_la), ("k_blur3_lanczos_b", lib_lb),
-                     ("k_blur3_lanczos_b2", lib_lb2)):
-        for _ in range(3):
-            fn()
-        e0, e1 = ev.create(), ev.create()
-        ev.record(e0, stream)
-        for _ in range(reps):
-            fn()
-        ev.record(e1, stream)
-        ms = ev.elapsed_ms(e0, e1) / reps
-        gbps = BYTES[name] * n / (ms * 1e-3) / 1e9
-        out[name] = {"bytes_per_voxel": BYTES[name], "avg_launch_ms": ms,
-                     "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
-    return out
+    from nsol_amd import _timing
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with _timing.KernelTimer(ENTRY_TAGS) as kt:
+        run_once()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    table = {}
+    for name, s in kt.summary().items():
+        base, _, tag = name.partition("#")
+        kern, bpv = ENTRIES.get(base, (None, None))
+        if callable(bpv):
+            bpv = bpv(int(tag))
+        rec = {"kernel": kern, "launches_per_run": s["launches"],
+               "avg_launch_ms": s["avg_ms"], "min_ms": s["min_ms"], "max_ms": s["max_ms"],
+               "ms_per_run": s["total_ms"], "bytes_per_voxel": bpv}
+        if bpv is not None:
+            gbps = bpv * nvox / (s["avg_ms"] * 1e-3) / 1e9
+            rec["achieved_GBps"], rec["frac"] = gbps, gbps / HBM_PEAK_GBPS
+        table[name] = rec
+    return table, wall
 
 
 def cpu_baseline(sample_n, iter_max):
@@ -243,82 +233,6 @@ def cpu_baseline_lbfgsb(sample_n, iter_max):
              minimizer="L-BFGS-B", data_loss="huber", rho=0.1, iterations=1,
              x_scale=float(y.max()))
     return 1.0 / (time.time() - t0)
-
-
-# algorithmic bytes per voxel of the limited-memory products at c stored pairs
-# (float32 vectors, one mask byte): W' v, W c + base vectors, the subspace matrix
-# with the reduced gradient formed in the same pass
-def lb_bytes(c):
-    return {"k_mdots": 4 * (2 * c + 1) + 1, "k_wcomb": 4 * (2 * c + 2) + 1,
-            "k_masked_gram_mfma": 4 * (2 * c + 4) + 1,
-            # the 2c vectors, r, xcp, x, g and the mask read; xn and d written
-            "k_subspace_step": 4 * (2 * c + 4) + 1 + 8}
-
-
-def time_kernels_lbfgsb(shape, c=10, reps=6):
-    """Average launch duration of the O(m n) kernels of the GPU-resident L-BFGS-B
-    with a full memory (c stored pairs) on vectors of the run's size."""
-    import torch
-    from nsol_amd.lbfgsb_device import DeviceBackend
-    n = int(np.prod(shape))
-    n -= n % 16
-    dev = torch.device("cuda", torch.cuda.current_device())
-    gen = torch.Generator(device=dev).manual_seed(5)
-    r = lambda: torch.rand(n, device=dev, generator=gen)
-    be = DeviceBackend()
-    ws, wy = [r() for _ in range(c)], [r() for _ in range(c)]
-    x, g, z = r(), r() - 0.5, r()
-    free = (torch.rand(n, device=dev, generator=gen) < 0.2).to(torch.int8)
-    coef = list(np.linspace(0.1, 1.0, c))
-    fns = {"k_mdots": lambda: be.dots(wy + ws, x, free),
-           "k_wcomb": lambda: be.subspace_direction(z, ws, wy, coef, coef, 0.7, free),
-           "k_masked_gram_mfma": lambda: be.masked_grams_rgrad(
-               ws, wy, free, z, x, g, 0.7, coef, coef),
-           "k_subspace_step": lambda: be.subspace_step(
-               z, ws, wy, coef, coef, 0.7, free, x, x, g, 0.0, float("inf"))}
-    ev = HipEvents()
-    stream = torch.cuda.current_stream().cuda_stream
-    out = {}
-    for name, fn in fns.items():
-        fn()
-        e0, e1 = ev.create(), ev.create()
-        torch.cuda.synchronize()
-        ev.record(e0, stream)
-        for _ in range(reps):
-            fn()                       # (each reads its reduction back: in-order)
-        ev.record(e1, stream)
-        ms = ev.elapsed_ms(e0, e1) / reps
-        bpv = lb_bytes(c)[name]
-        gbps = bpv * n / (ms * 1e-3) / 1e9
-        out[name] = {"bytes_per_voxel": bpv, "stored_pairs": c, "avg_launch_ms": ms,
-                     "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
-    return out
-
-
-def count_lbfgsb_calls(run):
-    """Calls of the O(m n) products during one (untimed) run."""
-    from nsol_amd.lbfgsb_device import DeviceBackend
-    counts = {"k_mdots": 0, "k_wcomb": 0, "k_masked_gram_mfma": 0, "k_subspace_step": 0}
-    orig = {k: getattr(DeviceBackend, k) for k in
-            ("dots", "_wcomb", "masked_grams_rgrad", "subspace_step",
-             "cauchy_setup_dots")}
-
-    def wrap(name, key):
-        def f(self, *a, **kw):
-            counts[key] += 1
-            return orig[name](self, *a, **kw)
-        return f
-    DeviceBackend.dots = wrap("dots", "k_mdots")
-    DeviceBackend._wcomb = wrap("_wcomb", "k_wcomb")
-    DeviceBackend.masked_grams_rgrad = wrap("masked_grams_rgrad", "k_masked_gram_mfma")
-    DeviceBackend.subspace_step = wrap("subspace_step", "k_subspace_step")
-    DeviceBackend.cauchy_setup_dots = wrap("cauchy_setup_dots", "k_mdots")
-    try:
-        run()
-    finally:
-        for k, v in orig.items():
-            setattr(DeviceBackend, k, v)
-    return counts
 
 
 def main():
@@ -398,7 +312,29 @@ def main():
         if not hasattr(m, name):
             raise SystemExit("no switch %s" % path)
         setattr(m, name, type(getattr(m, name))(int(v)))
-    n = args.size
+    out = measure(args.size, args.iterations, args.iter_max, args.minimizer,
+                  args.data_loss, args.repeat,
+                  cpu_sample=0 if args.no_cpu_baseline else args.cpu_sample)
+    out["config"].update({
+        "knobs": args.param, "blur_epilogue": not args.no_blur_epilogue,
+        "prescaled_rhs": not args.no_prescaled_rhs,
+        "lsmr_x": "carried" if args.carried_x else "assembled at the end"})
+    print(json.dumps(out))
+
+
+def measure(n, iterations=10, iter_max=10, minimizer="lsmr", data_loss="linear",
+            repeat=5, cpu_sample=64):
+    """One JSON-able record for BASELINE config 4 at edge length n: `repeat` untimed-by-
+    events runs (median wall time = seconds_per_run), ONE more run with every C-ABI
+    entry bracketed by events (the `roofline`: per-kernel durations as they are inside
+    the solve), and the CPU path on a cpu_sample^3 volume (0: skipped).  bench.py puts
+    this record into the driver's line as `config4`."""
+    import torch
+    import nsol_amd.linear_operators as LO
+    import nsol_amd.admm_linear_solver as admm
+    import nsol_amd.lsmr as lsmr_mod
+    from nsol_amd import ops
+    from nsol_amd.synthetic import synth_volume
     shape = (n, n, n)
     nvox = n ** 3
     lo = LO.LinearOperators3D()
@@ -412,6 +348,7 @@ def main():
 
     clean = torch.from_numpy(synth_volume(n, 0, "clean", np.float32)).cuda()
     y = A(clean).flatten()
+    del clean
     gen = torch.Generator(device="cuda").manual_seed(1)
     y = y + 0.02 * float(y.max()) * torch.randn(y.shape, device="cuda",
                                                  generator=gen)
@@ -421,10 +358,10 @@ def main():
     def solver():
         return admm.ADMMLinearSolver(
             A=A_1D, A_adj=A_adj_1D, b=y, B=D_1D, B_adj=D_adj_1D, x0=y,
-            dimension=3, alpha=0.01, rho=0.1, iterations=args.iterations,
-            iter_max=args.iter_max, minimizer=args.minimizer,
-            data_loss=args.data_loss, x_scale=x_scale, dtype=np.float32)
-    for _ in range(max(1, args.repeat)):
+            dimension=3, alpha=0.01, rho=0.1, iterations=iterations,
+            iter_max=iter_max, minimizer=minimizer,
+            data_loss=data_loss, x_scale=x_scale, dtype=np.float32)
+    for _ in range(max(1, repeat)):
         s = solver()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -436,122 +373,74 @@ def main():
                         ops.norm2(y)))
     finite = bool(torch.isfinite(x).all().item())
     execution = s.get_execution()
+    inner = s.get_inner_log()
     del s, x
-    med = sorted(times)[len(times) // 2]
+    # (the first run carries the one-time set-up when there is more than one)
+    med = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    kern, timed_wall = kernels_in_run(lambda: solver().run(), nvox)
+    known = {k: v for k, v in kern.items() if v["bytes_per_voxel"] is not None}
+    dom = max(known, key=lambda k: known[k]["ms_per_run"])
+    dkey = kern[dom]["kernel"]
+    traffic, traffic_source = profiled_traffic(dkey, n)
+    kernel_ms = sum(v["ms_per_run"] for v in kern.values())
     out = {
         "metric": "ADMM iterations/sec on %d^3 fp32 TV deconvolution" % n,
-        "value": args.iterations / med, "unit": "ADMM iterations/s",
-        "n_gpus": 1, "steps": args.iterations, "warmup": 0,
-        "ms_per_step": med / args.iterations * 1e3,
+        "value": iterations / med, "unit": "ADMM iterations/s",
+        "n_gpus": 1, "steps": iterations, "warmup": 0,
+        "ms_per_step": med / iterations * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "seconds_per_run": med, "runs": times,
-        "statistic": "median of %d runs (the first includes one-time set-up)"
-                     % len(times),
+        "statistic": "median of the runs after the first (which carries the one-time "
+                     "set-up)" if len(times) > 1 else "one run",
         "config": {"workload": "synth_volume(%d,0,'clean') blurred sigma=2 "
                                "(13 taps per axis, periodic) + 2%% noise; "
                                "ADMMLinearSolver alpha=0.01 rho=0.1 "
                                "dimension=3 (BASELINE config 4)" % n,
-                   "iterations": args.iterations, "iter_max": args.iter_max,
-                   "minimizer": args.minimizer, "data_loss": args.data_loss,
-                   "knobs": args.param, "blur_epilogue": not args.no_blur_epilogue,
-                   "prescaled_rhs": not args.no_prescaled_rhs,
-                   "lsmr_x": "carried" if args.carried_x else "assembled at the end",
-                   "lsmr_form": "bidiagonalisation" if (args.bidiag or args.carried_x)
-                   else "Lanczos on the normal equations",
-                   "lanczos_step": __import__("nsol_amd.lsmr", fromlist=["x"]).LAST_FORM[0],
-                   "execution": execution},
-        "rel_change_vs_input": rel_change, "finite": finite}
-    if args.minimizer == "lsmr":
-        kern = time_kernels(shape)
-        import nsol_amd.lsmr as lsmr_mod
-        deferred = bool(lsmr_mod.DEFER_X)
-        normal = bool(lsmr_mod.USE_NORMAL_EQUATIONS) and deferred and \
-            0.1 >= lsmr_mod.NE_MIN_WEIGHT[4] and args.iter_max <= lsmr_mod.NE_MAX_ITER
-        # (k_wcomb: x assembled from the stored vectors; timed for 11)
-        blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS)
-        in_blur = normal and bool(lsmr_mod.USE_BLUR_LANCZOS) and \
-            lsmr_mod.LAST_FORM[0] == "lanczos-in-blur"
-        lean = in_blur and bool(ops.LEAN_LANCZOS_HALVES)
-        if in_blur:
-            per_it = {"k_blur3_lanczos_a": 0 if lean else args.iter_max,
-                      "k_blur3_lanczos_b": 0 if lean else args.iter_max,
-                      "k_blur3_lanczos_b2": args.iter_max if lean else 0,
-                      "k_blur3_dma_norms": args.iter_max if lean else 0, "k_blur3_dma": 0,
-                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0,
-                      "k_tk1_lanczos": 0, "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0,
-                      "k_admm_vw": 1, "k_wcomb": 1}
-            blur_norms = "lean" if lean else True
-        elif normal:
-            per_it = {"k_blur3_dma": args.iter_max + 1,
-                      "k_blur3_dma_epi": 0 if blur_norms else args.iter_max,
-                      "k_tk1_norm": 0 if blur_norms else args.iter_max,
-                      "k_blur3_dma_norms": args.iter_max if blur_norms else 0,
-                      "k_tk1_lanczos": args.iter_max,
-                      "k_blur3_lanczos_a": 0, "k_blur3_lanczos_b": 0,
-                      "k_blur3_lanczos_b2": 0,
-                      "k_lsmr_v": 1, "k_lsmr_u": 0, "k_lsmr_hx": 0, "k_admm_vw": 1,
-                      "k_wcomb": 1}
-        else:
-            per_it = {"k_blur3_dma": 2 * args.iter_max + 1,
-                      "k_lsmr_u": args.iter_max, "k_lsmr_v": args.iter_max + 1,
-                      "k_lsmr_hx": 0 if deferred else args.iter_max,
-                      "k_admm_vw": 1, "k_wcomb": 1 if deferred else 0,
-                      "k_blur3_dma_epi": 0, "k_tk1_norm": 0, "k_tk1_lanczos": 0,
-                      "k_blur3_dma_norms": 0, "k_blur3_lanczos_a": 0,
-                      "k_blur3_lanczos_b": 0, "k_blur3_lanczos_b2": 0}
-        for k, c in per_it.items():
-            kern[k]["launches_per_admm_iteration"] = c
-            kern[k]["ms_per_admm_iteration"] = c * kern[k]["avg_launch_ms"]
-        dom = max(kern, key=lambda k: kern[k]["ms_per_admm_iteration"])
-        run_bytes = bytes_per_admm_iteration(args.iter_max) * nvox
-        run_gbps = run_bytes * args.iterations / med / 1e9
-        traffic, traffic_source = profiled_traffic(dom, n)
-        out["roofline"] = {
-            "bound": "hbm", "kernel": dom,
+                   "iterations": iterations, "iter_max": iter_max,
+                   "minimizer": minimizer, "data_loss": data_loss,
+                   "lsmr_form": lsmr_mod.LAST_FORM[0] if minimizer == "lsmr" else None,
+                   "execution": execution, "inner_solves": inner},
+        "rel_change_vs_input": rel_change, "finite": finite,
+        "roofline": {
+            "bound": "hbm", "kernel": dkey, "entry": dom,
             "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": traffic,
             "traffic_source": traffic_source,
             "frac_traffic": (traffic / (kern[dom]["avg_launch_ms"] * 1e-3) / 1e9 /
                              HBM_PEAK_GBPS) if traffic else None,
             "avg_launch_ms": kern[dom]["avg_launch_ms"],
-            "bytes_per_launch": BYTES[dom] * nvox,
-            "kernels": kern,
-            "whole_run": {
-                "algorithmic_bytes_per_voxel_per_admm_iteration":
-                    bytes_per_admm_iteration(args.iter_max),
-                "bytes_moved_per_voxel_per_admm_iteration":
-                    bytes_moved_per_admm_iteration(
-                        args.iter_max, not args.no_blur_epilogue,
-                        not args.no_prescaled_rhs, deferred, normal, blur_norms),
-                "frac_moved": bytes_moved_per_admm_iteration(
-                    args.iter_max, not args.no_blur_epilogue,
-                    not args.no_prescaled_rhs, deferred, normal, blur_norms) * nvox * args.iterations / med / 1e9 /
-                HBM_PEAK_GBPS,
-                "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS,
-                "kernel_ms_per_admm_iteration_sum":
-                    sum(k["ms_per_admm_iteration"] for k in kern.values())}}
-    if args.minimizer == "L-BFGS-B":
-        kern = time_kernels_lbfgsb(shape)
-        calls = count_lbfgsb_calls(lambda: solver().run())
-        for k in kern:
-            kern[k]["launches_per_run"] = calls[k]
-            kern[k]["ms_per_run_at_full_memory"] = calls[k] * kern[k]["avg_launch_ms"]
-        dom = max(kern, key=lambda k: kern[k]["ms_per_run_at_full_memory"])
-        out["roofline"] = {
-            "bound": "hbm", "kernel": dom,
-            "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None,
-            "traffic_source": None, "avg_launch_ms": kern[dom]["avg_launch_ms"],
-            "bytes_per_launch": kern[dom]["bytes_per_voxel"] * (nvox - nvox % 16),
-            "note": "the O(m n) products of the limited-memory matrix (10 stored "
-                    "pairs = 20 vectors per pass) dominate the branch; launch "
-                    "counts are those of one run, durations those of a full "
-                    "memory (the first iterations of every solve hold fewer pairs)",
-            "kernels": kern}
-    if not args.no_cpu_baseline and args.minimizer == "L-BFGS-B":
-        sn = args.cpu_sample
-        its = cpu_baseline_lbfgsb(sn, args.iter_max)
+            "launches": kern[dom]["launches_per_run"],
+            "bytes_per_launch": kern[dom]["bytes_per_voxel"] * nvox,
+            "how": "event pairs around every C-ABI entry of ONE run of the solver "
+                   "(nsol_amd/_timing.py); the dominant entry is the one with the most "
+                   "time in that run among those with stated algorithmic bytes",
+            "timed_run_wall_s": timed_wall,
+            "timed_run_kernel_ms": kernel_ms,
+            "timed_run_gpu_idle_ms": timed_wall * 1e3 - kernel_ms,
+            "kernels": kern}}
+    if minimizer == "lsmr":
+        deferred = bool(lsmr_mod.DEFER_X)
+        form = lsmr_mod.LAST_FORM[0]
+        normal = form in ("lanczos", "lanczos-in-blur")
+        blur_norms = normal and bool(lsmr_mod.USE_BLUR_NORMS)
+        if form == "lanczos-in-blur":
+            blur_norms = "lean" if ops.LEAN_LANCZOS_HALVES else True
+        prescaled = bool(admm.USE_PRESCALED_RHS)
+        epilogue = bool(LO.USE_BLUR_EPILOGUE)
+        run_bytes = bytes_per_admm_iteration(iter_max) * nvox
+        run_gbps = run_bytes * iterations / med / 1e9
+        moved = bytes_moved_per_admm_iteration(iter_max, epilogue, prescaled, deferred,
+                                               normal, blur_norms)
+        out["roofline"]["whole_run"] = {
+            "algorithmic_bytes_per_voxel_per_admm_iteration":
+                bytes_per_admm_iteration(iter_max),
+            "bytes_moved_per_voxel_per_admm_iteration": moved,
+            "frac_moved": moved * nvox * iterations / med / 1e9 / HBM_PEAK_GBPS,
+            "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS}
+    if cpu_sample and minimizer == "L-BFGS-B":
+        sn = cpu_sample
+        its = cpu_baseline_lbfgsb(sn, iter_max)
         out["cpu_baseline"] = {
             "value": its * (sn ** 3) / float(nvox),
             "unit": "ADMM iterations/s", "cores": 1, "kind": "port",
@@ -560,10 +449,10 @@ def main():
                       "L-BFGS-B, maxiter=%d), Huber loss, dense 13^3 ndimage "
                       "blur (reference op sequence), %d^3 volume, ONE ADMM "
                       "iteration, extrapolated per voxel to %d^3"
-                      % (args.iter_max, sn, n)}
-    if not args.no_cpu_baseline and args.minimizer == "lsmr":
-        sn = args.cpu_sample
-        its = cpu_baseline(sn, args.iter_max)
+                      % (iter_max, sn, n)}
+    if cpu_sample and minimizer == "lsmr":
+        sn = cpu_sample
+        its = cpu_baseline(sn, iter_max)
         out["cpu_baseline"] = {
             "value": its * (sn ** 3) / float(nvox),
             "unit": "ADMM iterations/s", "cores": 1, "kind": "port",
@@ -571,8 +460,8 @@ def main():
             "sample": "oracle admm_lsmr_refstyle (dense 13^3 ndimage blur, "
                       "scipy.sparse.linalg.lsmr, reference op sequence), %d^3 "
                       "volume, ONE ADMM iteration of LSMR(%d), extrapolated "
-                      "per voxel to %d^3" % (sn, args.iter_max, n)}
-    print(json.dumps(out))
+                      "per voxel to %d^3" % (sn, iter_max, n)}
+    return out
 
 
 if __name__ == "__main__":
