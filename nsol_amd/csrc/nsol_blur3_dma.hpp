@@ -37,6 +37,19 @@ constexpr uint32_t kNoLane = 0xC0000000u;
 
 constexpr int kDmaLxb = 16;   // lanes per tile row of the LDS-DMA staged kernel
 
+// Cache policy of the LDS-DMA loads (the builtin's aux operand: 0 = default, 2 = nt):
+// own-position tiles are read by ONE workgroup once (y_prev, q0, b, the old io); the
+// raw tile's and the halo'd tile's edges are read again by the neighbouring tiles.
+#ifndef NSOL_B3_AUX_OWN
+#define NSOL_B3_AUX_OWN 0
+#endif
+#ifndef NSOL_B3_AUX_HALO
+#define NSOL_B3_AUX_HALO 0
+#endif
+#ifndef NSOL_B3_AUX_RAW
+#define NSOL_B3_AUX_RAW 0
+#endif
+
 inline int blur3_cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void *)(pl + src_off[j]),
               (__attribute__((address_space(3))) void *)(raw + (size_t)rbuf + (size_t)k * 64),
-              16, 0, 0);
+              16, 0, NSOL_B3_AUX_RAW);
       }
     }
     if constexpr (RAG) {
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
                                                            old_off),
           (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
                                                      (size_t)wave * 64),
-          16, 0, 0);
+          16, 0, NSOL_B3_AUX_OWN);
   };
   // (EPI 3 / 4) the own-position tile of plane z of `src` -> obuf[ob]
   auto stage_tile = [&](const T *src, int64_t z, int ob) {
@@ -733,7 +746,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         (const __attribute__((address_space(1))) void *)(src + z * plane + old_off),
         (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
                                                    (size_t)wave * 64),
-        16, 0, 0);
+        16, 0, NSOL_B3_AUX_OWN);
   };
   // (EPI 6) plane z of y (clamped into the volume) with its halo -> behind the own tile
   auto stage_yh = [&](int64_t z) {
@@ -747,7 +760,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)(pl + yh_off[j]),
             (__attribute__((address_space(3))) void *)(obuf + (size_t)tile_vecs + (size_t)k * 64),
-            16, 0, 0);
+            16, 0, NSOL_B3_AUX_HALO);
     }
   };
   // a 16-byte store every wave issues (offset kNoLane: dropped by the hardware)

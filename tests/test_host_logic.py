@@ -686,3 +686,108 @@ def test_a_residual_lost_to_cancellation_is_unknown_not_zero():
             assert co.lsmr_tests(normb2)[0] < 1e-2
         vprev, v, beta = v, y / np.float32(beta_new), beta_new
     assert seen_unknown
+
+
+def test_iterate_20_of_the_edge_case_depends_on_rounding_at_the_1e10_level():
+    """Where the float64 gate of test_normal_equations_lsmr_at_the_edge_of_its_guard
+    (tests/test_gpu_parity.py: 1e-8, not 1e-12) comes from, derived here on the CPU.
+
+    The case: sigma = 2 blur at 32^3, B = identity, weight on the guard's bound
+    (tests/golden/cfg4.npz: y_32, ratio_32, the reference's tk_ident_edge_{10,20,32};
+    tikhonov_linear_solver.py:146-158 with SciPy's LSMR).  The same iterates from
+      (a) Lanczos / MINRES on the normal equations (nsol_amd/lsmr.py's recurrence,
+          MinresCoefficients) with A evaluated by FFT,
+      (b) the same with A evaluated separably along x, y, z (what the HIP blur does),
+      (c) (a) with every Lanczos vector reorthogonalised twice against all before it,
+      (d) scipy.sparse.linalg.lsmr on the augmented operator, A by FFT,
+      (e) the reference's own output (dense scipy.ndimage taps; the golden).
+    The three evaluations of A agree to 2e-15.  At k = 10 and k = 32 all five iterates
+    agree to 1e-13; at k = 20 the Krylov process has just found the dominant
+    eigenvalues, its vectors have lost orthogonality (max |v_i'v_j| > 1e-2), and the
+    iterate moves by 1e-10 ... 1e-9 with the rounding of the operator and the form of
+    the recurrence -- five orders of magnitude more than at k = 10 and 32.  The MI355X
+    run lands 1.1e-9 from the golden there (profiles/*_parity_errors.json): a gate of
+    1e-8 holds the implementation to one decade above that sensitivity, 1e-9 sat
+    inside it."""
+    import math
+    import warnings
+    import scipy.sparse.linalg as spla
+    import nsol_amd.kernels as Kn
+    from nsol_amd.lsmr import MinresCoefficients
+    from oracle import nsol_oracle as orc
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "cfg4.npz")))
+    n = 32
+    shape, N = (n, n, n), n ** 3
+    y = g["y_32"].astype(np.float64).reshape(-1)
+    xs = float(y.max())
+    b = y / xs
+    alpha = 0.1 * float(g["ratio_32"])
+    sa = math.sqrt(alpha)
+    taps = orc.gaussian_taps(3, np.diag([4.0, 4.0, 4.0]))            # dense 13^3
+    c = taps.shape[0] // 2
+    K = np.zeros(shape)
+    idx = (np.arange(taps.shape[0]) - c) % n
+    K[np.ix_(idx, idx, idx)] = taps
+    FK = np.fft.rfftn(K)
+    ax3 = (0, 1, 2)
+    A_fft = lambda v: np.fft.irfftn(np.fft.rfftn(v.reshape(shape)) * np.conj(FK),
+                                    s=shape, axes=ax3).reshape(-1)
+    t1 = np.asarray(Kn.Kernels1D().get_gaussian(4.0), dtype=np.float64).reshape(-1)
+
+    def A_sep(v):                       # periodic, symmetric taps: x, then y, then z
+        v = v.reshape(shape)
+        for ax in (2, 1, 0):
+            acc = np.zeros_like(v)
+            for i, w in enumerate(t1):
+                acc = acc + w * np.roll(v, -(i - t1.size // 2), axis=ax)
+            v = acc
+        return v.reshape(-1)
+    probe = np.random.default_rng(0).standard_normal(N)
+    _, _, A_ref, _ = orc.flat_operators(shape, None, np.diag([4.0, 4.0, 4.0]))
+    for A in (A_fft, A_sep):
+        assert np.linalg.norm(A(probe) - A_ref(probe)) <= 1e-14 * np.linalg.norm(probe)
+
+    def lanczos(A, kmax, reorth):
+        gv = A(b)                                       # (A is symmetric: A' = A)
+        beta1 = np.linalg.norm(gv)
+        V, co, beta, vprev = [gv / beta1], MinresCoefficients(kmax + 1, beta1), beta1, 0.0
+        out = {}
+        for k in range(1, kmax + 1):
+            v = V[-1]
+            w = A(A(v)) + alpha * v
+            alfa = float(v @ w)
+            w = w - alfa * v - beta * vprev
+            if reorth:
+                for _ in range(2):
+                    for u in V:
+                        w = w - (u @ w) * u
+            beta = float(np.linalg.norm(w))
+            co.step(alfa, beta)
+            out[k] = np.stack(V, 1) @ co.x[:k]
+            vprev = v
+            V.append(w / beta)
+        G = np.stack(V[:kmax], 1)
+        return out, np.abs(G.T @ G - np.eye(kmax))
+    xa, Ga = lanczos(A_fft, 32, False)
+    xb, _ = lanczos(A_sep, 32, False)
+    xc, Gc = lanczos(A_fft, 32, True)
+    assert Gc.max() < 1e-12                              # (c) stays orthonormal
+    assert Ga[:10, :10].max() < 1e-9 and Ga[:20, :20].max() > 1e-2
+    op = spla.LinearOperator(
+        (2 * N, N), dtype=np.float64,
+        matvec=lambda v: np.concatenate([A_fft(v), sa * v]),
+        rmatvec=lambda u: A_fft(u[:N]) + sa * u[N:])
+    rhs = np.concatenate([b, np.zeros(N)])
+    spread = {}
+    for k in (10, 20, 32):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xd = spla.lsmr(op, rhs, atol=0, btol=0, conlim=1e8, maxiter=k)[0]
+        xe = g["tk_ident_edge_%d" % k].reshape(-1) / xs
+        its = [np.clip(v, 0, np.inf) for v in (xa[k], xb[k], xc[k], xd)] + [xe]
+        nrm = np.linalg.norm(xe)
+        spread[k] = max(np.linalg.norm(p - q) / nrm for i, p in enumerate(its)
+                        for q in its[i + 1:])
+    assert spread[10] < 1e-13 and spread[32] < 1e-13
+    assert 1e-10 < spread[20] < 1e-9
+    assert spread[20] > 1e4 * max(spread[10], spread[32])
