@@ -579,9 +579,11 @@ int nsol_pd_fusedk_tail2_pitched(int elem_size, int64_t nz, int64_t ny, int64_t 
  * ---------------------------------------------------------------------- */
 /* t = grad(x) + w - c;  n = sqrt(sum_a t_a^2);  v_a = n > thr ?
  * max(n - thr, 0) * t_a / n : 0;  w = t - v;  rhs = rhs_scale * (v - w + c).
- * c (b_reg / x_scale) may be NULL (= 0).  w is updated in place; rhs may be
- * NULL, and so may v when rhs is given (the loop of admm_linear_solver.py:165-218
- * reads v only through the next right-hand side: 12 of the 52 bytes per voxel less).
+ * c (b_reg / x_scale) may be NULL (= 0).  w is updated in place; v and rhs may
+ * each be NULL (the loop of admm_linear_solver.py:165-218 reads v only through the
+ * next right-hand side: 12 of the 52 bytes per voxel less; its robust-loss
+ * minimizers ignore b_reg -- tikhonov_linear_solver.py:201-208 -- so there the
+ * right-hand side is not written either: 28 bytes).
  * grad is fused in (x is the primal volume). */
 int nsol_admm_vw_update_f32(const float *x, float *v, float *w, const float *c,
                             float *rhs, int ndim, int64_t nz, int64_t ny,
@@ -592,6 +594,27 @@ int nsol_admm_vw_update_f64(const double *x, double *v, double *w,
                             int64_t ny, int64_t nx, double wx, double wy,
                             double wz, double thr, double rhs_scale,
                             void *stream);
+/* The outer update AND the vector the next x-update's LSMR starts from, in one
+ * pass (3-D volumes whose rows are whole 16-byte vectors; -2 otherwise, nothing
+ * launched): what nsol_admm_vw_update_norm_* (v = NULL) followed by
+ * nsol_lsmr_v_update_to_* (B = gradient, c_v = 0) leave --
+ *   w_out = t - shrink(t) for t = grad(x) + w_in - c,
+ *   g = c_atu * atb + c_btu * grad^T(rhs),  rhs = rhs_scale * (2 shrink(t) - t + c)
+ * (admm_linear_solver.py:208-222 and the right-hand side A^T b + rho B^T(v - w + b_reg)
+ * of tikhonov_linear_solver.py:146-158 on the normal equations) -- with rhs never
+ * written: w_out and g are bit for bit those of the two kernels, result[0] = sum rhs^2,
+ * result[1] = sum g^2 (doubles; ws: nsol_hip_reduce_ws_doubles() doubles).  w_in is
+ * read at neighbouring voxels, so w_out must be another array. */
+int nsol_admm_vw_update_g_f32(const float *x, const float *w_in, float *w_out,
+                              const float *c, const float *atb, float *g, int ndim,
+                              int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                              double wz, double thr, double rhs_scale, double c_atu,
+                              double c_btu, double *result, double *ws, void *stream);
+int nsol_admm_vw_update_g_f64(const double *x, const double *w_in, double *w_out,
+                              const double *c, const double *atb, double *g, int ndim,
+                              int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                              double wz, double thr, double rhs_scale, double c_atu,
+                              double c_btu, double *result, double *ws, void *stream);
 /* The same with *result = the sum of squares of the rhs written (double; ws:
  * nsol_hip_reduce_ws_doubles() doubles): with rhs_scale = sqrt(rho) the rhs is
  * the lower block of the right-hand side LSMR starts from

@@ -24,6 +24,10 @@ from .definitions import EPS
 # the fused outer step hands LSMR its lower right-hand side pre-multiplied by
 # sqrt(rho) together with its norm (False: scale and norm passes per iteration)
 USE_PRESCALED_RHS = True
+# ... and, where the x-update is LSMR on the normal equations, the outer step forms the
+# vector that solve starts from, A^T b + rho B^T(v - w + b_reg), in the same pass and never
+# writes the right-hand side (ops.admm_vw_update_g: 36 B per voxel instead of 40 + 24)
+USE_ONE_PASS_OUTER_STEP = True
 
 
 class ADMMLinearSolver(LinearSolver):
@@ -97,21 +101,39 @@ class ADMMLinearSolver(LinearSolver):
             self._rho > EPS
         sa = float(np.sqrt(self._rho))
         hint = None
+        rhs_read = self._minimizer in ("lsmr", "lsq_linear", "least_squares")
         b2 = ops.dot(self._dev(self._b), self._dev(self._b)) if prescale else None
 
+        start = None
         for i in range(self._iterations):
             if self._verbose:
                 print("ADMM iteration %d/%d" % (i + 1, self._iterations))
-            x = self._solve_tikhonov_least_squares(x, breg, hint)
+            x = self._solve_tikhonov_least_squares(x, breg, hint, start)
             # (v is read only through the next right-hand side: the fused step
             # does not store it)
-            if fused and prescale:
+            start = None
+            if i + 1 == self._iterations:
+                # (admm :208-216 after the last x-update changes v and w only, which
+                # nobody reads any more: not done)
+                self._x = x
+                if self._observer is not None:
+                    self._observer.add_x(self.get_x())
+                break
+            if fused and prescale and USE_ONE_PASS_OUTER_STEP:
+                start = self._one_pass_outer_step(x, w, c, breg, desc, thr, sa)
+            if start is not None:
+                w, n2 = start.pop("w"), start.pop("n2")
+                hint = (sa, b2, n2)        # (breg: written only if the solve asks)
+            elif fused and prescale:
                 n2 = ops.admm_vw_update(x, None, w, c, breg, desc[2], desc[1].w,
                                         thr, sa, want_norm=True)
                 hint = (sa, b2, n2)        # breg holds sqrt(rho) * (v - w + c)
             elif fused:
-                ops.admm_vw_update(x, None, w, c, breg, desc[2], desc[1].w, thr,
-                                   1.0)
+                # (the robust-loss minimizers never read b_reg -- the reference's quirk,
+                # tikhonov :201-208 -- so the next right-hand side is not written for
+                # them: 28 instead of 40 B per voxel)
+                ops.admm_vw_update(x, None, w, c, breg if rhs_read else None, desc[2],
+                                   desc[1].w, thr, 1.0)
             else:
                 Bx = B(x)
                 t = ops.lincomb2(1.0, Bx, 1.0, w)
@@ -134,7 +156,40 @@ class ADMMLinearSolver(LinearSolver):
         """One record per inner solve of the last run (see _solve_tikhonov_least_squares)."""
         return list(self._inner_log)
 
-    def _solve_tikhonov_least_squares(self, x, b_reg, prescaled=None):
+    _w_alt = None
+
+    def _one_pass_outer_step(self, x, w, c, breg, desc, thr, sa):
+        """v / w update and the next x-update's start vector in one pass; None when that
+        kernel does not apply (nothing launched).  Returns what the inner solver needs
+        ("g", "gg", "fill") plus the new w and the sum of squares of the right-hand
+        side it stands for."""
+        import torch
+        if self._observer is not None:
+            return None
+        b = self._dev(self._b)
+        atb = tk._adjoint_of_data(self._A_adj, BridgedCallable(self._A_adj, self._dtype),
+                                  b)
+        if atb.numel() != x.numel():
+            return None
+        if self._w_alt is None or self._w_alt.numel() != w.numel() or \
+                self._w_alt.dtype != w.dtype or self._w_alt.data_ptr() == w.data_ptr():
+            self._w_alt = torch.empty_like(w)
+        g = torch.empty_like(x)
+        sums = torch.empty(2, dtype=torch.float64, device=x.device)
+        if not ops.admm_vw_update_g(x, w, self._w_alt, c, atb, g, desc[2], desc[1].w, thr,
+                                    sa, 1.0, sa, sums):
+            return None
+        w_old, w_new = w, self._w_alt
+        self._w_alt = w_old               # (next step's output; holds the old w until then)
+
+        def fill():
+            # the right-hand side itself after all: the two-kernel step from the old w
+            ops.admm_vw_update(x, None, w_old.clone(), c, breg, desc[2], desc[1].w, thr,
+                               sa)
+        return {"g": g, "gg": sums[1:2], "fill": fill, "w": w_new,
+                "n2": float(sums[0].item())}
+
+    def _solve_tikhonov_least_squares(self, x, b_reg, prescaled=None, start=None):
         # admm :220-237: data_loss_scale and bounds are NOT forwarded
         tikhonov = tk.TikhonovLinearSolver(
             A=self._A, A_adj=self._A_adj, B=self._B, B_adj=self._B_adj,
@@ -143,6 +198,7 @@ class ADMMLinearSolver(LinearSolver):
             minimizer=self._minimizer, verbose=self._verbose,
             dtype=self._dtype, _borrow=True)
         tikhonov._prescaled_b_reg = prescaled
+        tikhonov._lsmr_start = start
         # (minimizer="L-BFGS-B": cost and gradient at the point the last solve
         # returned, see tikhonov_linear_solver.REUSE_OBJECTIVE_AT_X0)
         tikhonov._warm_key = ("admm", id(self), float(self._rho), self._data_loss,

@@ -227,6 +227,27 @@ __device__ __forceinline__ void blur3_loss(int loss, T f2, T s2, T gm, T &rho, T
   }
 }
 
+// LDS vectors of the one-pass blur's tiles at NW waves: three raw tiles (whole 1-KiB
+// pieces) and two x-filtered tiles
+template <int VEC, int NT, int NW>
+constexpr size_t blur3_base_vecs() {
+  constexpr int R = NT / 2, NBH = (R + VEC - 1) / VEC;
+  constexpr int tyr = NW * 64 / kDmaLxb, frows = tyr + 2 * R;
+  return 3 * (size_t)((frows * (kDmaLxb + 2 * NBH) + 63) / 64) * 64 +
+         2 * (size_t)frows * kDmaLxb;
+}
+// EPI 6: a halo'd tile of y per wave (128 slots each) where that fits beside the
+// own-position tile of y_prev; else one shared tile (see the kernel)
+#ifndef NSOL_B3_EPI6_MINI
+#define NSOL_B3_EPI6_MINI 1          // (0: the shared tile everywhere, for A/B runs)
+#endif
+template <typename T, int VEC, int NT, int NW>
+constexpr bool blur3_epi6_mini() {
+  return NSOL_B3_EPI6_MINI && kDmaLxb == 16 &&
+         (blur3_base_vecs<VEC, NT, NW>() + (size_t)NW * 64 + (size_t)NW * 128) * 16 <=
+             160 * 1024;
+}
+
 // phases U .. M-1 of one trip through the loop body (each with its position in the
 // ring as a compile-time constant); stops at the end of the z chunk
 template <int U, int M, typename F>
@@ -470,7 +491,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       case 3: NSOL_B3_WAIT(3); break;
       case 4: NSOL_B3_WAIT(4); break;
       default:
-        if constexpr (!RAG) { NSOL_B3_WAIT(4); break; }
+        if constexpr (!RAG && EPI != 6) { NSOL_B3_WAIT(4); break; }
         switch (newer) {                  // (a smaller count only waits longer)
           case 5: NSOL_B3_WAIT(5); break;
           case 6: NSOL_B3_WAIT(6); break;
@@ -628,19 +649,26 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     k0 = coef[0]; k1 = coef[1]; k2 = coef[2]; k3 = coef[4]; k4 = coef[5];
   }
   const bool has_prev = (EPI == 3 && aux1 != nullptr) || (EPI == 6 && aux2 != nullptr);
-  // (EPI 6) the halo'd tile of y: (tyr + 2) rows of lxb + 2 vectors behind the own-position
-  // tile; piece k = wave + j * NW of it (two at most) from a clamped position
+  // (EPI 6) y with a one-vector / one-row halo, behind the own-position tile.  Where the
+  // LDS has room (MINI) every wave keeps a halo'd tile of ITS OWN four rows -- 6 rows of
+  // lxb + 2 vectors in two 1-KiB pieces (the second one's last 20 lanes land in padding)
+  // -- and reads nothing another wave's piece brought: no barrier between those reads and
+  // the request for the next plane, as with EPI 4's own-position tiles.  Otherwise ONE
+  // tile of (tyr + 2) rows is shared (piece k = wave + j * NW of it, two at most) and a
+  // barrier separates its reads from the next request.  Sources are clamped into the plane.
   constexpr int hrl = lxb + 2;
-  constexpr int halo_vecs = (tyr + 2) * hrl;
+  constexpr bool MINI = blur3_epi6_mini<T, VEC, NT, NW>();
+  static_assert(!MINI || (lxb == 16 && 6 * hrl <= 128), "a wave's halo'd rows: two pieces");
+  constexpr int halo_vecs = MINI ? 6 * hrl : (tyr + 2) * hrl;
   constexpr int hpieces = (halo_vecs + 63) >> 6;
-  static_assert(EPI != 6 || hpieces <= 2 * NW, "halo tile: two pieces per wave");
+  static_assert(EPI != 6 || MINI || hpieces <= 2 * NW, "halo tile: two pieces per wave");
   uint32_t yh_off[2] = {0, 0};
   if constexpr (EPI == 6) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int i = (wave + j * NW) * 64 + lane;
+      int i = MINI ? j * 64 + lane : (wave + j * NW) * 64 + lane;
       if (i >= halo_vecs) i = 0;
-      int64_t yy = y0 + i / hrl - 1;
+      int64_t yy = y0 + (MINI ? wave * 4 : 0) + i / hrl - 1;
       yy = yy < 0 ? 0 : (yy >= ny ? ny - 1 : yy);
       int xx = bx * lxb + i % hrl - 1;
       xx = xx < 0 ? 0 : (xx >= nxv ? nxv - 1 : xx);
@@ -755,14 +783,17 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     const T *pl = aux1 + z * plane;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int k = wave + j * NW;
-      if (k < hpieces)
+      const int k = MINI ? wave * 2 + j : wave + j * NW;
+      if (MINI || k < hpieces)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)(pl + yh_off[j]),
             (__attribute__((address_space(3))) void *)(obuf + (size_t)tile_vecs + (size_t)k * 64),
             16, 0, NSOL_B3_AUX_HALO);
     }
   };
+  // vector-memory operations stage_yh costs this wave (wave-uniform)
+  const int my_yh_ops = MINI ? 2 : (wave < hpieces ? 1 : 0) + (wave + NW < hpieces ? 1 : 0);
+  (void)my_yh_ops;
   // a 16-byte store every wave issues (offset kNoLane: dropped by the hardware)
   auto store_at = [&](T *dst, int64_t z, uint32_t off, V val) {
     if (z < 0) z = 0;
@@ -854,7 +885,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       const bool have = j + 1 >= -1;                // (uniform; j + 1 <= len always)
       V yp1 = splat<V, T>(T(0)), lap1 = splat<V, T>(T(0)), ypv = splat<V, T>(T(0));
       if (have) {
-        const V *o = obuf + (size_t)tile_vecs + (size_t)(row + 1) * hrl + (lx + 1);
+        // (MINI: this wave's tile, its rows 4 wave - 1 .. 4 wave + 4)
+        const V *o = obuf + (size_t)tile_vecs +
+                     (MINI ? (size_t)wave * 128 + (size_t)(row - wave * 4 + 1) * hrl
+                           : (size_t)(row + 1) * hrl) + (lx + 1);
         yp1 = o[0];
         const int64_t zc = zbeg + (j + 1);
         if (j + 1 >= 0 && zc < zend && k0 != T(0)) {   // in-plane part of K'K y, plane j + 1
@@ -883,8 +917,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       }
       if (storing && has_prev) ypv = obuf[(size_t)row * lxb + lx];
       // every wave has taken what it needs from the two tiles: only then may the next
-      // plane be requested into them
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // plane be requested into them (MINI: a wave reads its own pieces only -- its own
+      // reads have to be done, nobody else's)
+      if constexpr (MINI) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (st >= 2 * R - 3 && st + 1 < nsteps) stage_yh(zbeg + (j + 2));
       if (has_prev && st + 1 >= 2 * R && st + 1 < nsteps)
         stage_tile(aux2, zbeg + (j + 1), 0);
@@ -916,7 +952,11 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       }
       store_at(out, zbeg + j, soff, val);
       const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
+#ifdef NSOL_B3_ABLATE_OWNWAIT      // (timing only: the y / y_prev pieces are not waited for)
+      phase_end((more ? my_stage_ops : 0) + 1 + NSOL_B3_ABLATE_OWNWAIT);
+#else
       phase_end((more ? my_stage_ops : 0) + 1);
+#endif
       return;
     }
     if constexpr (EPI == 3) {
@@ -1189,9 +1229,11 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   // EPI 3 two (y_prev, double buffered), EPI 4 two (q0 and y, one buffer each)
   constexpr int otiles = EPI == 1 ? 2 : (EPI == 3 ? 2 : (EPI == 4 ? 2 : (EPI == 5 ? 2 : 0)));
   // (EPI 6: one own-position tile and the halo'd tile of y, whole 1-KiB pieces)
-  constexpr size_t ovecs = EPI == 6 ? (size_t)dtyr * dl +
-                                          (((size_t)(dtyr + 2) * (dl + 2) + 63) / 64) * 64
-                                    : (size_t)otiles * dtyr * dl;
+  constexpr size_t ovecs =
+      EPI == 6 ? (size_t)dtyr * dl + (blur3_epi6_mini<T, VEC, NT, NWD>()
+                                          ? (size_t)NWD * 128
+                                          : (((size_t)(dtyr + 2) * (dl + 2) + 63) / 64) * 64)
+               : (size_t)otiles * dtyr * dl;
   constexpr size_t lds0 = (3 * (size_t)npieces * 64 + 2 * (size_t)frows * dl + ovecs) * 16;
   constexpr size_t lds_patch = 3 * (size_t)((frows * 4 + 63) / 64) * 16 * 16;   // (RAG)
   if constexpr (lds0 > 160 * 1024 || ((EPI == 2 || EPI == 3) && sizeof(T) == 8 && NT >= 15) ||

@@ -273,6 +273,237 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw(const T *__restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------------------
+// The outer step and the next solve's right-hand side vector in ONE pass (3-D, rows of
+// whole vectors): k_admm_vw followed by k_lsmr_v (nsol_lsmr.hip; B = gradient, c_v = 0)
+//   t = grad x + w - c,  v = shrink(t),  w' = t - v,  r = rhs_scale (v - w' + c)
+//   g = c_atu atb + c_btu grad^T r
+// without r ever going to memory (12 B per voxel written and 12 read again).  grad^T r
+// at a voxel needs r_x of the voxel to its left, r_y of the one above and r_z of the one
+// in the plane before; r at a point needs all three components of t there.  A workgroup
+// owns 4 rows of 64 vectors and MARCHES along z, so r_z of the plane before is the lane's
+// own value of the step before (registers), and x of the next plane, loaded for this
+// step's forward difference, is the step after's own x.  r of the row above and of the
+// ONE voxel to the left of the lane's vector are recomputed from x and w there (the
+// arithmetic of k_admm_vw, so every r equals the value that kernel would have stored:
+// w' and g are bit for bit those of the two kernels).  w is read at neighbouring points
+// other lanes update, hence w_in / w_out (the caller alternates two arrays).
+// A z chunk starts with one warm-up step on the plane before it (nothing stored).
+// Sums: ws[block] = sum r^2 (own points), ws[nblocks + block] = sum g^2.
+// ---------------------------------------------------------------------------
+template <typename T, int N>
+__device__ __forceinline__ void vw_point(const T (&gx)[N], const T (&gy)[N], const T (&gz)[N],
+                                         const T (&w)[3][N], const T (&c)[3][N], T thr,
+                                         T rs, T (&wn)[3][N], T (&r)[3][N]) {
+  T t[3][N], n2[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    t[0][k] = gx[k] + w[0][k] - c[0][k];
+    n2[k] = t[0][k] * t[0][k];
+    t[1][k] = gy[k] + w[1][k] - c[1][k];
+    n2[k] = n2[k] + t[1][k] * t[1][k];
+    t[2][k] = gz[k] + w[2][k] - c[2][k];
+    n2[k] = n2[k] + t[2][k] * t[2][k];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const T nrm = t_sqrt(n2[k]);
+    const T mag = t_max(t_abs(nrm) - thr, T(0)) * t_sign(nrm);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const T va = (nrm > thr) ? mag * t[a][k] / nrm : T(0);
+      wn[a][k] = t[a][k] - va;
+      r[a][k] = rs * (va - wn[a][k] + c[a][k]);
+    }
+  }
+}
+
+// component A of r alone (the same operations as above for that component)
+template <typename T, int N, int A>
+__device__ __forceinline__ void vw_point_r(const T (&gx)[N], const T (&gy)[N],
+                                           const T (&gz)[N], const T (&w)[3][N],
+                                           const T (&c)[3][N], T thr, T rs, T (&r)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    T t[3];
+    t[0] = gx[k] + w[0][k] - c[0][k];
+    T n2 = t[0] * t[0];
+    t[1] = gy[k] + w[1][k] - c[1][k];
+    n2 = n2 + t[1] * t[1];
+    t[2] = gz[k] + w[2][k] - c[2][k];
+    n2 = n2 + t[2] * t[2];
+    const T nrm = t_sqrt(n2);
+    const T mag = t_max(t_abs(nrm) - thr, T(0)) * t_sign(nrm);
+    const T va = (nrm > thr) ? mag * t[A] / nrm : T(0);
+    const T wn = t[A] - va;
+    r[k] = rs * (va - wn + c[A][k]);
+  }
+}
+
+template <typename T, int VEC, bool HASC>
+__global__ __launch_bounds__(kBlock) void k_admm_vw_g(
+    const T *__restrict__ x, const T *__restrict__ w_in, T *__restrict__ w_out,
+    const T *__restrict__ c, const T *__restrict__ atb, T *__restrict__ g, Geom<T> G,
+    int64_t zchunk, int nyg, T thr, T rs, T c_atu, T c_btu, double *ws, int64_t nblocks) {
+  constexpr int XT = kBlock / 4;                      // lanes along x, 4 rows per workgroup
+  const int yg = (int)(blockIdx.y % (unsigned)nyg), zc = (int)(blockIdx.y / (unsigned)nyg);
+  const int64_t ix = ((int64_t)blockIdx.x * XT + (threadIdx.x % XT)) * VEC;
+  const int64_t iy = (int64_t)yg * 4 + (threadIdx.x / XT);
+  const bool ok = ix < G.nx && iy < G.ny;
+  const int64_t zbeg = (int64_t)zc * zchunk;
+  int64_t zend = zbeg + zchunk;
+  if (zend > G.nz) zend = G.nz;
+  const bool has_r = ix + VEC < G.nx, has_d = iy + 1 < G.ny, has_u = iy > 0, has_l = ix > 0;
+  const int wl = threadIdx.x % kWave;                 // lane in the wave (= in the row)
+  double acc_r = 0.0, acc_g = 0.0;
+  if (ok) {
+    auto ldv = [&](const T *p, int64_t i, T (&v)[VEC]) { vload<T, VEC>(p + i, v); };
+    // state carried from plane to plane: x of this plane at the own point, the row above
+    // and the voxel to the left; r_z of the plane before at the own point
+    T xc[VEC], xu[VEC], rz_prev[VEC];
+    T xl = T(0);
+    vzero(rz_prev);
+    const int64_t z0 = zbeg > 0 ? zbeg - 1 : 0;       // (warm-up plane)
+    const int64_t row0 = iy * G.sy + ix;
+    ldv(x, z0 * G.sz + row0, xc);
+    vzero(xu);
+    if (has_u) ldv(x, z0 * G.sz + row0 - G.sy, xu);
+    if (has_l) xl = x[z0 * G.sz + row0 - 1];
+    for (int64_t z = z0; z < zend; ++z) {
+      const int64_t i = z * G.sz + row0;
+      const bool has_n = z + 1 < G.nz;
+      // x of the next plane (own, above, left), of the row below, to the right
+      T xn[VEC], xun[VEC], xd[VEC];
+      T xln = T(0);
+      vzero(xn); vzero(xun); vzero(xd);
+      if (has_n) {
+        ldv(x, i + G.sz, xn);
+        if (has_u) ldv(x, i + G.sz - G.sy, xun);
+      }
+      xln = __shfl_up(xn[VEC - 1], 1, kWave);
+      if (wl == 0) xln = (has_n && has_l) ? x[i + G.sz - 1] : T(0);
+      if (has_d) ldv(x, i + G.sy, xd);
+      // (the voxel right of the lane's vector is the next lane's first one: only the
+      // wave's last lane loads it; likewise the values left of the vector below)
+      const T right_sh = __shfl_down(xc[0], 1, kWave);
+      const T right = !has_r ? T(0) : (wl < kWave - 1 ? right_sh : x[i + VEC]);
+      // ---- own point
+      T gx[VEC], gy[VEC], gz[VEC], wv[3][VEC], cv[3][VEC], wn[3][VEC], r[3][VEC];
+      fwd_diff_x<T, VEC>(xc, right, G.wx, gx);
+      fwd_diff<T, VEC>(xc, xd, G.wy, gy);
+      fwd_diff<T, VEC>(xc, xn, G.wz, gz);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        ldv(w_in, a * G.n + i, wv[a]);
+        vzero(cv[a]);
+        if (HASC) ldv(c, a * G.n + i, cv[a]);
+      }
+      vw_point<T, VEC>(gx, gy, gz, wv, cv, thr, rs, wn, r);
+      // ---- the row above: r_y there
+      T ru_y[VEC];
+      vzero(ru_y);
+      if (has_u) {                                    // (uniform in a wave: one row each)
+        const int64_t iu = i - G.sy;
+        const T ru_sh = __shfl_down(xu[0], 1, kWave);
+        const T right_u = !has_r ? T(0) : (wl < kWave - 1 ? ru_sh : x[iu + VEC]);
+        T ux[VEC], uy[VEC], uz[VEC], uw[3][VEC], uc[3][VEC];
+        fwd_diff_x<T, VEC>(xu, right_u, G.wx, ux);
+        fwd_diff<T, VEC>(xu, xc, G.wy, uy);
+        fwd_diff<T, VEC>(xu, xun, G.wz, uz);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          ldv(w_in, a * G.n + iu, uw[a]);
+          vzero(uc[a]);
+          if (HASC) ldv(c, a * G.n + iu, uc[a]);
+        }
+        vw_point_r<T, VEC, 1>(ux, uy, uz, uw, uc, thr, rs, ru_y);
+      }
+      // ---- the voxel to the left: r_x there
+      T rl_x = T(0);
+      {
+        const int64_t il = i - 1;
+        T lx_[1], ly_[1], lz_[1], lw[3][1], lc[3][1], lr[1];
+        const bool edge = wl == 0;                    // (the wave's first lane loads)
+        T below = __shfl_up(xd[VEC - 1], 1, kWave);
+        if (edge) below = (has_l && has_d) ? x[il + G.sy] : T(0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          lw[a][0] = __shfl_up(wv[a][VEC - 1], 1, kWave);
+          lc[a][0] = __shfl_up(cv[a][VEC - 1], 1, kWave);
+          if (edge) {
+            lw[a][0] = has_l ? w_in[a * G.n + il] : T(0);
+            lc[a][0] = (HASC && has_l) ? c[a * G.n + il] : T(0);
+          }
+        }
+        if (has_l) {
+          lx_[0] = xc[0] * G.wx + xl * (-G.wx);
+          ly_[0] = below * G.wy + xl * (-G.wy);
+          lz_[0] = xln * G.wz + xl * (-G.wz);
+          vw_point_r<T, 1, 0>(lx_, ly_, lz_, lw, lc, thr, rs, lr);
+          rl_x = lr[0];
+        }
+      }
+      if (z >= zbeg) {
+        // ---- grad^T r and the new vector, k_lsmr_v's order
+        T val[VEC], ab[VEC];
+        ldv(atb, i, ab);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const T l = (k > 0) ? r[0][(k + VEC - 1) % VEC] : rl_x;
+          T kt = r[0][k] * (-G.wx) + l * G.wx;
+          kt += r[1][k] * (-G.wy) + ru_y[k] * G.wy;
+          kt += r[2][k] * (-G.wz) + rz_prev[k] * G.wz;
+          val[k] = c_atu * ab[k];
+          val[k] += c_btu * kt;
+          val[k] += T(0) * ab[k];
+          acc_g += (double)val[k] * (double)val[k];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) acc_r += (double)r[a][k] * (double)r[a][k];
+        }
+        vstore<T, VEC>(g + i, val);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vstore<T, VEC>(w_out + a * G.n + i, wn[a]);
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        rz_prev[k] = r[2][k];
+        xc[k] = xn[k];
+        xu[k] = xun[k];
+      }
+      xl = xln;
+    }
+  }
+  __shared__ double sred[2][kBlock / kWave];
+  acc_r = wave_sum(acc_r);
+  acc_g = wave_sum(acc_g);
+  const int lane = threadIdx.x & (kWave - 1), wvi = threadIdx.x / kWave;
+  if (lane == 0) { sred[0][wvi] = acc_r; sred[1][wvi] = acc_g; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += sred[threadIdx.x][k];
+    ws[(int64_t)threadIdx.x * nblocks + (int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// result[b] = the sum of the b-th run of n partials, fixed order
+__global__ __launch_bounds__(kBlock) void k_reduce_final2(const double *ws, int64_t n,
+                                                           double *result) {
+  ws += (int64_t)blockIdx.x * n;
+  double v = 0.0;
+  for (int64_t k = threadIdx.x; k < n; k += kBlock) v += ws[k];
+  __shared__ double s[kBlock / kWave];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (lane == 0) s[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += s[k];
+    result[blockIdx.x] = t;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_vector_shrink(const T *__restrict__ t,
                                                            T *__restrict__ v,
@@ -575,7 +806,7 @@ int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
                  double wz, double thr, double rhs_scale, void *stream,
                  double *result = nullptr, double *ws = nullptr) {
   NSOL_CHECK_GEOM(ndim, nz, ny, nx);
-  if (!x || !w || (!v && !rhs) || (result && (!ws || !rhs))) return NSOL_EINVAL;
+  if (!x || !w || (result && (!ws || !rhs))) return NSOL_EINVAL;
   Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
   const bool al = ptr16(x) && (!v || ptr16(v)) && ptr16(w) && (!c || ptr16(c)) &&
                   (!rhs || ptr16(rhs)) && G.n % 4 == 0;
@@ -597,6 +828,49 @@ int admm_vw_impl(const T *x, T *v, T *w, const T *c, T *rhs, int ndim,
                        (double *)nullptr);
     return launch_status();
   });
+}
+
+// -2: the one-pass form does not apply (nothing launched): nsol_admm_vw_update_norm_*
+// and nsol_lsmr_v_update_to_* then
+template <typename T>
+int admm_vw_g_impl(const T *x, const T *w_in, T *w_out, const T *c, const T *atb, T *g,
+                   int ndim, int64_t nz, int64_t ny, int64_t nx, double wx, double wy,
+                   double wz, double thr, double rhs_scale, double c_atu, double c_btu,
+                   double *result, double *ws, void *stream) {
+  NSOL_CHECK_GEOM(ndim, nz, ny, nx);
+  if (!x || !w_in || !w_out || w_in == w_out || !atb || !g || g == atb || g == x ||
+      !result || !ws)
+    return NSOL_EINVAL;
+  constexpr int VEC = 16 / sizeof(T);
+  if (ndim != 3 || nx % VEC != 0 || nx < VEC || !ptr16(x) || !ptr16(w_in) || !ptr16(w_out) ||
+      (c && !ptr16(c)) || !ptr16(atb) || !ptr16(g) || (nz * ny * nx) % 4 != 0)
+    return -2;
+  const Geom<T> G = make_geom<T>(ndim, nz, ny, nx, wx, wy, wz);
+  constexpr int XT = kBlock / 4;
+  const int64_t gx = (nx + (int64_t)XT * VEC - 1) / ((int64_t)XT * VEC);
+  const int64_t nyg = (ny + 3) / 4;
+  // z chunks: enough workgroups to fill the chip a few times over, chunks long enough
+  // for the warm-up plane not to matter
+  // (512^3: 1 024 workgroups 1.26 ms, 2 048 ... 16 384 within 2 % of each other; 512 1.48)
+  int64_t chunks = (8 * 256 + gx * nyg - 1) / (gx * nyg);
+  if (chunks < 1) chunks = 1;
+  int64_t zchunk = (nz + chunks - 1) / chunks;
+  if (zchunk < 16) zchunk = nz < 16 ? nz : 16;
+  chunks = (nz + zchunk - 1) / zchunk;
+  const int64_t nblocks = gx * nyg * chunks;
+  if (gx > 65535 || nyg * chunks > 65535 || 2 * nblocks > kReducePartials) return -2;
+  const dim3 grid((unsigned)gx, (unsigned)(nyg * chunks), 1);
+  if (c)
+    hipLaunchKernelGGL((k_admm_vw_g<T, VEC, true>), grid, dim3(kBlock), 0, as_stream(stream),
+                       x, w_in, w_out, c, atb, g, G, zchunk, (int)nyg, (T)thr, (T)rhs_scale,
+                       (T)c_atu, (T)c_btu, ws, nblocks);
+  else
+    hipLaunchKernelGGL((k_admm_vw_g<T, VEC, false>), grid, dim3(kBlock), 0, as_stream(stream),
+                       x, w_in, w_out, c, atb, g, G, zchunk, (int)nyg, (T)thr, (T)rhs_scale,
+                       (T)c_atu, (T)c_btu, ws, nblocks);
+  hipLaunchKernelGGL(k_reduce_final2, dim3(2), dim3(kBlock), 0, as_stream(stream), ws, nblocks,
+                     result);
+  return launch_status();
 }
 
 template <typename T>
@@ -744,6 +1018,14 @@ int nsol_hip_reduce_ws_doubles(void) { return kReducePartials; }
     if (!res || !ws) return NSOL_EINVAL;                                         \
     return admm_vw_impl<T>(x, v, w, c, rhs, ndim, nz, ny, nx, wx, wy, wz, thr,   \
                            rs, s, res, ws);                                      \
+  }                                                                              \
+  int nsol_admm_vw_update_g_##SUF(const T *x, const T *w_in, T *w_out, const T *c, \
+                                  const T *atb, T *g, int ndim, int64_t nz,      \
+                                  int64_t ny, int64_t nx, double wx, double wy,  \
+                                  double wz, double thr, double rs, double c_atu, \
+                                  double c_btu, double *res, double *ws, void *s) { \
+    return admm_vw_g_impl<T>(x, w_in, w_out, c, atb, g, ndim, nz, ny, nx, wx, wy, \
+                             wz, thr, rs, c_atu, c_btu, res, ws, s);             \
   }                                                                              \
   int nsol_vector_shrink_##SUF(const T *t, T *v, int ndim, int64_t m,            \
                                double thr, void *s) {                            \

@@ -357,10 +357,12 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                 A_axpby=None, atb=None, x_bounds=None, b_bot_scale=1.0,
-                normb2=None, top_norm2=None):
+                normb2=None, top_norm2=None, g0=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
     top_norm2: a callable that returns |b_top|^2 (like atb: the same in every solve of an
-    outer loop around one b).
+    outer loop around one b).  g0 = (g, |g|^2 as a one-element float64 device tensor): the
+    right-hand side vector A^T b_top + sa B^T (b_bot_scale b_bot) when the caller has
+    formed it already (ops.admm_vw_update_g: b_bot then holds nothing and is not read).
     b_top is only read, b_bot too.  atb: a callable that returns A^T b_top (a caller
     that solves around the same b again and again keeps it).  x_bounds: see lsmr_fused.
     Returns (x, istop, itn).
@@ -399,8 +401,11 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
             tuple(getattr(A_axpby, "shape", ())) == tuple(shape))):
         norms = getattr(A_axpby, "norms", None)
     # g = A^T b_top + sa B^T b_bot
-    atu = atb() if atb is not None else A_adj(b_top)
-    g = torch.empty_like(x_like)
+    if g0 is None:
+        atu = atb() if atb is not None else A_adj(b_top)
+        g = torch.empty_like(x_like)
+    else:
+        atu, g = None, g0[0]
 
     def rhs_norm2():
         # (right-hand side [b_top; b_bot_scale * b_bot]; the caller's figure if it has one)
@@ -422,16 +427,22 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         # device's scalar board and the steps are enqueued behind it, unseen by the host
         lb = ops.LanczosBoard(x_like, maxiter, rho if grad_mode else 0.0,
                               0.0 if grad_mode else rho)
-        ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0, sa * b_bot_scale, 0.0,
-                          out=g, result=lb.slot_norm2(0))
+        if g0 is None:
+            ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0, sa * b_bot_scale, 0.0,
+                              out=g, result=lb.slot_norm2(0))
+        else:
+            lb.slot_norm2(0).copy_(g0[1])
         del atu
         got = _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds)
         if got is not None:
             return got
         beta1 = math.sqrt(float(lb.board[0].item()))     # (the kernels do not apply)
     else:
-        beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0,
-                                            sa * b_bot_scale, 0.0, out=g))
+        if g0 is None:
+            beta1 = math.sqrt(ops.lsmr_v_update(atu, b_bot, atu, bmode, shape, w, 1.0,
+                                                sa * b_bot_scale, 0.0, out=g))
+        else:
+            beta1 = math.sqrt(float(g0[1].item()))
         del atu
     if beta1 == 0:
         return _clipped(torch.zeros_like(x_like), x_bounds), 0, 0
@@ -652,7 +663,7 @@ def _operators_in_float64(A, A_adj, x_like):
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None, top_norm2=None,
                own_b=True, atb=None, x_bounds=None, b_bot_scale=1.0,
-               allow_normal=True):
+               allow_normal=True, g0=None, b_bot_fill=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
@@ -666,7 +677,9 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     the pass that assembles it from the stored vectors where there is one.
     b_bot_scale: the lower block of the right-hand side is b_bot_scale * b_bot (the
     caller's array is then only read: the normal-equations form folds the factor into a
-    coefficient, the bidiagonalisation scales into a copy)."""
+    coefficient, the bidiagonalisation scales into a copy).  g0: see lsmr_normal; b_bot
+    then holds nothing until b_bot_fill() has written it -- called here when the solve
+    cannot stay with the normal equations and needs the block itself."""
     import torch
     wide = None
     if bmode == ops.B_NONE and PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 \
@@ -685,11 +698,14 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
                                     x_like, maxiter, A_axpby=A_axpby, atb=atb,
                                     x_bounds=x_bounds, b_bot_scale=b_bot_scale,
-                                    normb2=normb2, top_norm2=top_norm2)
+                                    normb2=normb2, top_norm2=top_norm2, g0=g0)
         if x is not None:
             return x, istop, itn
         # (the weight is below the guard or the condition estimate came out too high:
         # nothing was consumed)
+        if g0 is not None and b_bot_fill is not None:
+            b_bot_fill()                  # (the lower block itself is needed from here on)
+            b_bot_fill = None
         if PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 and \
                 maxiter > PROMOTE_FROM_ITERATIONS:
             wide = _operators_in_float64(A, A_adj, x_like)
@@ -706,6 +722,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                 conlim=conlim, A_axpby=A_axpby, normb2=None, own_b=True, atb=None,
                 x_bounds=x_bounds, b_bot_scale=b_bot_scale, allow_normal=False)
             return x64.to(x_like.dtype), istop, itn
+    if g0 is not None and b_bot_fill is not None:
+        b_bot_fill()
     if not own_b:                 # (the caller's b: consumed below, so work in a copy)
         b_top = b_top.clone()
     if b_bot is not None and b_bot_scale != 1.0:

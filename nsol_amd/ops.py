@@ -1093,6 +1093,38 @@ def admm_vw_update(x, v, w_, c, rhs, shape, w, thr, rhs_scale, want_norm=False):
     _wrote(v, w_, rhs)
 
 
+def admm_vw_update_g(x, w_in, w_out, c, atb, g, shape, w, thr, rhs_scale, c_atu, c_btu,
+                     result):
+    """The outer update and the vector the next x-update's LSMR starts from in one pass
+    (nsol_admm_vw_update_g_*): w_out, g as admm_vw_update(x, None, w, c, rhs, ...,
+    rhs_scale) followed by lsmr_v_update(atb, rhs, atb, B_GRAD, ..., c_atu, c_btu, 0,
+    out=g) leave them, rhs never written; result[0] = sum rhs^2, result[1] = sum g^2
+    (the caller's two-element float64 device tensor, not read back here).  False when
+    the kernel does not apply (nothing launched)."""
+    _same(x, atb, g)
+    _same(w_in, w_out)
+    if c is not None:
+        _same(w_in, c)
+    ndim, nz, ny, nx = dims3(shape)
+    if w_in.dtype != x.dtype or w_in.numel() != ndim * x.numel() or \
+            nz * ny * nx != x.numel():
+        raise ValueError("admm_vw_update_g: operand sizes do not fit shape %r" %
+                         (tuple(shape),))
+    _chk(result)
+    if result.numel() != 2 or result.dtype != torch.float64:
+        raise ValueError("admm_vw_update_g: result must hold two float64 values")
+    ws, _ = _workspace(x.device)
+    rc = _fn("admm_vw_update_g", x)(
+        _p(x), _p(w_in), _p(w_out), _p(c), _p(atb), _p(g), ndim, nz, ny, nx, w[0], w[1],
+        w[2], float(thr), float(rhs_scale), float(c_atu), float(c_btu), _p(result), _p(ws),
+        stream_ptr())
+    if rc == -2:
+        return False
+    _lib.check(rc, "nsol_admm_vw_update_g")
+    _wrote(w_out, g)
+    return True
+
+
 def vector_shrink(t, ndim, thr, out=None):
     _chk(t)
     if out is None:

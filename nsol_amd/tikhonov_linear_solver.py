@@ -100,6 +100,7 @@ class TikhonovLinearSolver(LinearSolver):
         self._prescaled_b_reg = None
 
     _x0_clip_pending = False
+    _lsmr_start = None
 
     def _clip_x0(self):
         self._x0_clip_pending = False
@@ -197,6 +198,11 @@ class TikhonovLinearSolver(LinearSolver):
     def _run_lsmr(self, x0):
         fused = self._fused_lsmr_setup(x0) if USE_FUSED_LSMR else None
         pre = self._prescaled_b_reg
+        # (set by ADMMLinearSolver's one-pass outer step: the vector LSMR starts from is
+        # formed already and b_reg is not -- "fill" writes it should the solve need it)
+        start = self._lsmr_start if fused is not None and pre is not None else None
+        if start is None and self._lsmr_start is not None:
+            self._lsmr_start["fill"]()
         if fused is not None:
             # (b is handed over as it is: the bidiagonalisation takes a copy to work
             # in, the normal-equations form only reads it -- and A^T b, the same in
@@ -210,7 +216,9 @@ class TikhonovLinearSolver(LinearSolver):
                                                               b_top),
                                  top_norm2=lambda: _norm2_of_data(b_top),
                                  x_bounds=self._bounds,
-                                 b_bot_scale=self._lower_scale)
+                                 b_bot_scale=self._lower_scale,
+                                 g0=None if start is None else (start["g"], start["gg"]),
+                                 b_bot_fill=None if start is None else start["fill"])
             self._lsmr_stop = (istop, itn)     # (SciPy's istop, iterations taken)
             return x
         if pre is not None:            # (not expected: undo the pre-multiplication)

@@ -3469,3 +3469,83 @@ def test_solve_batch_gathers_over_rccl(nsol, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out = p.stdout.decode()
     assert p.returncode == 0 and "RCCL_OK" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("shape", [(20, 24, 64), (9, 7, 8), (33, 50, 260), (64, 64, 512),
+                                   (1, 5, 16), (6, 1, 128)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("with_c", [False, True])
+def test_one_pass_outer_step_matches_the_two_kernels(nsol, shape, dtype, with_c):
+    """nsol_admm_vw_update_g_*: ADMM's v / w update (admm_linear_solver.py:208-216) and the
+    vector the next x-update's LSMR starts from, A^T b + rho B^T(v - w + b_reg)
+    (tikhonov_linear_solver.py:146-158 on the normal equations), in one pass with the
+    right-hand side never written -- against nsol_admm_vw_update_norm_* followed by
+    nsol_lsmr_v_update_to_*: w and g bit for bit, both sums to summation order; several
+    z chunks, rows of one vector, single rows and planes."""
+    import torch
+    from nsol_amd import ops
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    n = int(np.prod(shape))
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    r = lambda m: torch.randn(m, device="cuda", dtype=td, generator=gen)
+    x, atb = 3.0 * r(n), r(n)
+    w0 = r(3 * n)
+    c = 0.3 * r(3 * n) if with_c else None
+    wgt = (1.0, 1.0, 1.0) if not with_c else (1.0, 0.5, 2.0)
+    thr, sa = 0.7, float(np.sqrt(0.1))
+    # the two kernels
+    w_ref, rhs = w0.clone(), torch.empty_like(w0)
+    n2_ref = ops.admm_vw_update(x, None, w_ref, c, rhs, shape, wgt, thr, sa, want_norm=True)
+    g_ref = torch.empty_like(x)
+    gg_ref = ops.lsmr_v_update(atb, rhs, atb, ops.B_GRAD, shape, wgt, 1.0, sa, 0.0,
+                               out=g_ref)
+    # one pass
+    w_new, g = torch.full_like(w0, float("nan")), torch.full_like(x, float("nan"))
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    assert ops.admm_vw_update_g(x, w0, w_new, c, atb, g, shape, wgt, thr, sa, 1.0, sa, sums)
+    assert torch.equal(w_new, w_ref)
+    assert torch.equal(g, g_ref)
+    got = sums.cpu().numpy()
+    assert abs(got[0] - n2_ref) <= 1e-12 * n2_ref
+    assert abs(got[1] - gg_ref) <= 1e-12 * gg_ref
+    # w alone (robust-loss branch: neither v nor the right-hand side is written)
+    w_only = w0.clone()
+    ops.admm_vw_update(x, None, w_only, c, None, shape, wgt, thr, 1.0)
+    assert torch.equal(w_only, w_ref)
+
+
+def test_one_pass_outer_step_declines_what_it_does_not_cover(nsol):
+    import torch
+    from nsol_amd import ops
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    for shape in ((8, 8, 7), (16, 16)):                 # ragged rows, 2-D
+        n = int(np.prod(shape))
+        x, w0 = torch.rand(n, device="cuda"), torch.rand(len(shape) * n, device="cuda")
+        assert not ops.admm_vw_update_g(x, w0, torch.empty_like(w0), None, x.clone(),
+                                        torch.empty_like(x), shape, (1.0, 1.0, 1.0), 0.5,
+                                        1.0, 1.0, 1.0, sums)
+
+
+@pytest.mark.parametrize("iter_max", [10, 40])
+def test_admm_with_the_one_pass_outer_step_is_bit_identical(nsol, monkeypatch, iter_max):
+    """ADMMLinearSolver (LSMR x-update, config 4's operators at 40^3) with the one-pass
+    outer step against the two-kernel step: the same x bit for bit -- also where the
+    x-update leaves the normal equations (iter_max = 40 > lsmr.NE_MAX_ITER: the
+    bidiagonalisation needs the right-hand side itself, which is then written after
+    all)."""
+    import nsol_amd.admm_linear_solver as admm
+    import nsol_amd.lsmr as L
+    from nsol_amd.synthetic import synth_volume
+    A, Aa, D, Da = _cfg4_ops(40)
+    y = synth_volume(40, 0, "gauss").reshape(-1)
+    outs = []
+    for one_pass in (True, False):
+        monkeypatch.setattr(admm, "USE_ONE_PASS_OUTER_STEP", one_pass)
+        L.LAST_FORM[0] = None
+        s = admm.ADMMLinearSolver(A=A, A_adj=Aa, b=y, B=D, B_adj=Da, x0=y, dimension=3,
+                                  alpha=0.01, rho=0.1, iterations=4, iter_max=iter_max,
+                                  x_scale=float(y.max()), dtype=np.float32)
+        s.run()
+        outs.append(s.get_x())
+        assert (L.LAST_FORM[0] == "lanczos-in-blur") == (iter_max == 10)
+    assert np.array_equal(outs[0], outs[1])

@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_declared_symbols():
                  "lincomb2", "lincomb3", "scale", "clip", "prox_dual_clamp",
                  "prox_ell1", "prox_ell2", "dot", "pd_dual_step",
                  "pd_primal_step", "pd_fused_iter", "pd_run",
-                 "admm_vw_update", "vector_shrink", "loss_cost_grad",
+                 "admm_vw_update", "admm_vw_update_g", "vector_shrink", "loss_cost_grad",
                  "loss_eval", "vector_norm_sum", "pd_fused2_iter",
                  "pd_fusedk_iter", "corr3_wrap", "lb_masked_gram", "lb_mdot",
                  "tk1_reg_cost_grad", "lb_diff_dots",
