@@ -432,10 +432,18 @@ def measure(n, iterations=10, iter_max=10, minimizer="lsmr", data_loss="linear",
         run_gbps = run_bytes * iterations / med / 1e9
         moved = bytes_moved_per_admm_iteration(iter_max, epilogue, prescaled, deferred,
                                                normal, blur_norms)
+        # the step after the last x-update is not computed (40 B once per run); with the
+        # one-pass outer step (nsol_admm_vw_update_g_*) the other steps and the start
+        # vector of the solve behind them move 36 B instead of 40 + 24
+        one_pass = bool(admm.USE_ONE_PASS_OUTER_STEP) and prescaled and normal
+        moved -= 40.0 / iterations
+        if one_pass:
+            moved -= 28.0 * (iterations - 1) / iterations
         out["roofline"]["whole_run"] = {
             "algorithmic_bytes_per_voxel_per_admm_iteration":
                 bytes_per_admm_iteration(iter_max),
             "bytes_moved_per_voxel_per_admm_iteration": moved,
+            "one_pass_outer_step": one_pass,
             "frac_moved": moved * nvox * iterations / med / 1e9 / HBM_PEAK_GBPS,
             "achieved": run_gbps, "frac": run_gbps / HBM_PEAK_GBPS}
     if cpu_sample and minimizer == "L-BFGS-B":
