@@ -346,7 +346,21 @@ __global__ __launch_bounds__(kBlock) void k_admm_vw_g(
     const T *__restrict__ c, const T *__restrict__ atb, T *__restrict__ g, Geom<T> G,
     int64_t zchunk, int nyg, T thr, T rs, T c_atu, T c_btu, double *ws, int64_t nblocks) {
   constexpr int XT = kBlock / 4;                      // lanes along x, 4 rows per workgroup
-  const int yg = (int)(blockIdx.y % (unsigned)nyg), zc = (int)(blockIdx.y / (unsigned)nyg);
+  // Which XCD runs a workgroup is its linear id (blockIdx.x + gridDim.x * blockIdx.y) mod 8:
+  // with row groups in their natural order the group above a workgroup's rows runs on
+  // ANOTHER XCD and everything the first row re-reads there is a second trip to memory.
+  // The P values of blockIdx.y one XCD cycle spans stand for P slabs of consecutive row
+  // groups instead (as voxel_at does for the stand-alone stencils).
+  int yg = (int)(blockIdx.y % (unsigned)nyg);
+  const int zc = (int)(blockIdx.y / (unsigned)nyg);
+  {
+    const unsigned gxd = gridDim.x;
+    const unsigned P = gxd == 1 ? 8u : (gxd == 2 ? 4u : (gxd == 4 ? 2u : 1u));
+    if (P > 1 && (unsigned)nyg % P == 0) {
+      const unsigned per = (unsigned)nyg / P;
+      yg = (int)(((unsigned)yg % P) * per + (unsigned)yg / P);
+    }
+  }
   const int64_t ix = ((int64_t)blockIdx.x * XT + (threadIdx.x % XT)) * VEC;
   const int64_t iy = (int64_t)yg * 4 + (threadIdx.x / XT);
   const bool ok = ix < G.nx && iy < G.ny;
