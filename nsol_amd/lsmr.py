@@ -409,8 +409,8 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
 
     def rhs_norm2():
         # (right-hand side [b_top; b_bot_scale * b_bot]; the caller's figure if it has one)
-        if normb2 is not None:
-            return normb2
+        if normb2 is not None:            # (a callable: the caller's figure, fetched late)
+            return normb2() if callable(normb2) else normb2
         r = top_norm2() if top_norm2 is not None else ops.dot(b_top, b_top)
         if b_bot is not None and bmode != ops.B_NONE:
             r += b_bot_scale ** 2 * ops.dot(b_bot, b_bot)
@@ -670,7 +670,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     A, A_adj: device callables (flat tensor -> flat tensor).  A_axpby(v, io, ca,
     cb) -> sum of squares or None: io = ca * A v + cb * io formed by the blur
     itself (its epilogue), when A is nsol_amd's one-pass blur.  normb2: the squared
-    norm of the right-hand side when the caller has it already.  own_b: b_top may be
+    norm of the right-hand side when the caller has it already (or a callable that
+    returns it: asked for when the stopping tests first need it, not before).  own_b: b_top may be
     consumed (False: it is the caller's and gets copied where the bidiagonalisation
     overwrites it).  atb: see lsmr_normal.  x_bounds = (lo, hi): the solution comes back
     projected onto them (tikhonov_linear_solver.py:142-143 applied to the result), in
@@ -730,7 +731,7 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         b_bot = ops.scale(b_bot, b_bot_scale)
     ut, ub = b_top, b_bot
     if normb2 is not None:           # ||[b_top; b_bot]||^2 known to the caller
-        normb = math.sqrt(normb2)
+        normb = math.sqrt(normb2() if callable(normb2) else normb2)
     else:
         normb = math.sqrt(ops.dot(ut, ut) +
                           (ops.dot(ub, ub) if ub is not None else 0.0))

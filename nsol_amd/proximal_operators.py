@@ -113,6 +113,9 @@ class ProximalOperators(object):
             bounds=bounds,
             dtype=(np.float32 if is_device_tensor(x) and "32" in str(x.dtype)
                    else (np.float64 if is_device_tensor(x) else None)))
+        # (on the solvers' device path the caller is a loop that goes on enqueueing and
+        # synchronises at the end of its own run)
+        tikhonov._sync_after_run = not is_device_tensor(x)
         tikhonov.run()
         if is_device_tensor(x):
             return tikhonov.get_x_device()

@@ -98,10 +98,15 @@ class Solver(object):
         import torch
         t0 = time.time()
         self._run()
-        torch.cuda.synchronize()
-        # (a persistent-kernel run that timed out is repeated here, before anyone
-        # can consume its result on the device or on the host)
-        ops.settle_persist_runs(synchronize=False)
+        if self._sync_after_run and not self._borrow:
+            torch.cuda.synchronize()
+            # (a persistent-kernel run that timed out is repeated here, before anyone
+            # can consume its result on the device or on the host)
+            ops.settle_persist_runs(synchronize=False)
+        # (_borrow / _sync_after_run = False: an inner solve of an outer solver of this
+        # package, which goes on enqueueing behind it and synchronises at the end of ITS
+        # run: draining the device here left it idle while the outer loop prepared its
+        # next step)
         self._computational_time = datetime.timedelta(
             seconds=time.time() - t0)
         if self._verbose:
@@ -110,6 +115,8 @@ class Solver(object):
         if self._observer is not None:
             self._observer.set_computational_time(
                 self.get_computational_time())
+
+    _sync_after_run = True
 
     def _run(self):
         raise NotImplementedError

@@ -210,7 +210,9 @@ class TikhonovLinearSolver(LinearSolver):
             b_top = fused[2]
             x, istop, itn = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
                                  A_axpby=self._blur_epilogue(x0.numel()),
-                                 normb2=None if pre is None else pre[1] + pre[2],
+                                 normb2=None if pre is None else (
+                                     (lambda: pre[1] + pre[2]()) if callable(pre[2])
+                                     else pre[1] + pre[2]),
                                  own_b=False,
                                  atb=lambda: _adjoint_of_data(self._A_adj, fused[1],
                                                               b_top),
