@@ -237,7 +237,9 @@ int nsol_corr3_wrap_lanczos_b_f64(const double *t, const double *q0, const doubl
  * nsol_corr3_wrap_norms_*) and coef[4..5] for the second half -- no q0;  _b2:
  * y_new = ca A t + (c1 K'K y + c0 y + c2 y_prev) + cy y with sum y_new^2, the step's
  * K'K y formed from a halo'd tile of y inside the kernel (y_prev may be NULL).  25 B per
- * voxel and step instead of 33.  Return -2 as _a / _b do. */
+ * voxel and step instead of 33.  y_new may be NULL: only its sum of squares (the next
+ * beta) is wanted -- the last step of a solve, whose vector nobody reads.  Return -2 as
+ * _a / _b do. */
 int nsol_corr3_wrap_lanczos_a2_f32(const float *y, float *t, int64_t nz, int64_t ny,
                                    int64_t nx, const double *taps_z, const double *taps_y,
                                    const double *taps_x, int ntaps, double rho_grad,

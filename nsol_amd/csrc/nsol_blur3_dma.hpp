@@ -948,7 +948,9 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
 #pragma unroll
           for (int e = 0; e < VEC; ++e) sacc = fma1(val[e], val[e], sacc);
         }
-        soff = own_off;
+        // (aux_out set: only the sum of squares is wanted -- the last step of a solve,
+        // whose vector nobody reads; the store is issued with every lane out of range)
+        soff = aux_out ? kNoLane : own_off;
       }
       store_at(out, zbeg + j, soff, val);
       const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
@@ -1420,9 +1422,12 @@ int blur3_loss_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                        const Taps<T> &tx, int ntaps, double rho_g, double rho_i,             \
                        double *board, int step, T *coef, double *part, int64_t part_doubles, \
                        hipStream_t st) {                                                     \
-    const LanczosArgs<T> lz{y, y_prev, nullptr, coef, board, step, rho_g, rho_i};            \
-    return blur3_lanczos_dispatch<T, 6>(t, y_new, nz, ny, nx, tz, ty, tx, ntaps, lz, part,   \
-                                        part_doubles, st);                                   \
+    /* y_new == NULL: the sum of squares alone (aux_out doubles as that flag; the kernel's  \
+       stores then go nowhere and `out` only has to be a valid, aligned address) */         \
+    const LanczosArgs<T> lz{y, y_prev, y_new ? nullptr : const_cast<T *>(t), coef, board,    \
+                            step, rho_g, rho_i};                                             \
+    return blur3_lanczos_dispatch<T, 6>(t, y_new ? y_new : const_cast<T *>(t), nz, ny, nx,   \
+                                        tz, ty, tx, ntaps, lz, part, part_doubles, st);      \
   }                                                                                          \
   int blur3_lanczos_a2_close(const double *sums2, double *board, int step, double rho_g,     \
                              double rho_i, T *coef, hipStream_t st) {                        \

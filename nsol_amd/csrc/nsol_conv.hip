@@ -810,7 +810,7 @@ int lanczos_b2_impl(const T *t, const T *y, const T *y_prev, T *y_new, int64_t n
                     const double *tx_host, int ntaps, double rho_grad, double rho_ident,
                     double *board, int step, T *coef, double *ws, int64_t ws_doubles,
                     void *stream) {
-  if (!t || !y || !y_new || y_new == t || y_new == y || y_new == y_prev || !tz_host ||
+  if (!t || !y || (y_new && (y_new == t || y_new == y || y_new == y_prev)) || !tz_host ||
       !ty_host || !tx_host || !board || !coef || !ws || step < 0 || nz < 1 || ny < 1 || nx < 1)
     return NSOL_EINVAL;
   Taps<T> tz, ty, tx;

@@ -560,6 +560,7 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
     # (the lean halves keep no q0 array: the second half forms the step's K'K y itself)
     t = torch.empty_like(x_like)
     q0 = None if getattr(half_a, "lean", False) else torch.empty_like(x_like)
+    assert maxiter >= 1
     fetchers = ops.scalar_fetchers(x_like.device, 4, _LAG + 1)
     state = {"co": None, "betas": None, "istop": 7, "normb2": None, "verdict": None}
 
@@ -593,8 +594,11 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
         return False
 
     done, stopped = 0, False
+    lean = getattr(half_a, "lean", False)
     for j in range(maxiter):
-        ynew = torch.empty_like(x_like)
+        # (the last step's vector is never read -- x is assembled from y_0 .. y_{k-1} --
+        # only its norm, the next beta, is: the lean second half then stores nothing)
+        ynew = None if (lean and j == maxiter - 1) else torch.empty_like(x_like)
         if not half_a(ys[-1], ys[-2] if j > 0 else None, t, q0, lb, j):
             if j == 0:
                 return None

@@ -310,8 +310,10 @@ def corr3_lanczos_a2(y, t, shape, taps_z, taps_y, taps_x, lb, step):
 
 def corr3_lanczos_b2(t, y, y_prev, y_new, shape, taps_z, taps_y, taps_x, lb, step):
     """Second half, lean form: y_new = ca blur(t) + (c1 K'K y + c0 y + c2 y_prev) + cy y
-    with |y_new|^2 onto the board (y_prev may be None)."""
-    _same(t, y, y_new)
+    with |y_new|^2 onto the board (y_prev may be None; y_new None: the sum alone)."""
+    _same(t, y)
+    if y_new is not None:
+        _same(t, y_new)
     if y_prev is not None:
         _same(y, y_prev)
     ndim, nz, ny, nx = dims3(shape)

@@ -724,6 +724,16 @@ def test_lanczos_halves_in_the_blur_match_their_parts(nsol, shape, sigma2, dtype
         c = lb.coef[0:3].cpu().double().numpy()
         bn = np.sqrt(board[3 * step + 3])
         assert np.allclose(c, [rg / bn, ri / bn, -bn / np.sqrt(nb2)], rtol=10 * tol)
+        if lean:
+            # the last step of a solve: no vector stored, the same sum and coefficients
+            keep = (t.clone(), y.clone(), None if prev is None else prev.clone())
+            lb.board[3 * step + 3] = 0.0
+            lb.coef[0:3] = torch.tensor([c1, c0, c2], dtype=td, device="cuda")
+            assert half_b(t, q0, y, None, lb, step)
+            assert float(lb.board[3 * step + 3]) == board[3 * step + 3]
+            assert torch.equal(lb.coef[0:3].cpu().double(), torch.from_numpy(c))
+            assert torch.equal(t, keep[0]) and torch.equal(y, keep[1])
+            assert prev is None or torch.equal(prev, keep[2])
 
 
 def test_golden_lsmr_solves_run_through_the_blur_with_the_lanczos_sums(nsol, golden,
