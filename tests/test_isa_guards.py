@@ -156,3 +156,23 @@ def test_one_pass_blur_instantiations_do_not_spill(tmp_path_factory):
         ls = {n: int(p) for n, p in zip(names, scratch)
               if re.search(r"k_blur3_dmaI%sLi\d+ELi16ELb[01]ELi5ELb0E" % t, n)}
         assert len(ls) == (5 if t[0] == "f" else 3) * 2 and not any(ls.values()), (src, ls)
+
+
+def test_one_pass_outer_step_does_not_spill(tmp_path_factory):
+    """k_admm_vw_g (nsol_ops.hip: ADMM's outer step and the next solve's start vector in
+    one pass) carries a plane of state per lane: every instantiation must stay out of
+    scratch memory, and the float32 form without b_reg -- BASELINE config 4's -- within the
+    128 registers that keep four waves on a SIMD."""
+    asm = _assembly("nsol_ops.hip", tmp_path_factory)
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*k_admm_vw_g\S*)(.*?)\.end_amdhsa_kernel",
+                         asm, re.S):
+        name, body = m.group(1), m.group(2)
+        seen += 1
+        scratch = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert scratch and int(scratch.group(1)) == 0, name
+        vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert vg, name
+        if "IfLi4ELb0E" in name:                    # <float, 4, false>
+            assert int(vg.group(1)) <= 128, (name, vg.group(1))
+    assert seen == 4

@@ -59,13 +59,29 @@ def main():
         runs.append(time.time() - t0)
     x = s.get_x_device()
     best = min(runs)
+    # durations of the C-ABI entries inside one more run (event pairs: nsol_amd/_timing.py)
+    from nsol_amd import _timing
+    s2 = pd.PrimalDualSolver(prox_f=pf, prox_g_conj=prox.prox_tv_conj, B=D_, B_conj=Da_, L2=16,
+                             alpha=0.01, x0=y, iterations=args.iterations, x_scale=xs,
+                             dtype=np.float32)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with _timing.KernelTimer({"lincomb_clip": 2}) as kt:
+        s2.run()
+        torch.cuda.synchronize()
+        wall = time.time() - t0
+    table = {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
+                 "ms_per_run": round(v["total_ms"], 3)}
+             for k, v in sorted(kt.summary().items(), key=lambda kv: -kv[1]["total_ms"])}
+    kernel_ms = sum(v["ms_per_run"] for v in table.values())
     print(json.dumps({
         "metric": "PD-deconvolution iterations/sec on %d^3 fp32" % n,
         "value": args.iterations / best, "unit": "PD iterations/s",
         "seconds_per_run": best, "runs": runs, "execution": s.get_execution(),
         "config": {"iterations": args.iterations, "iter_max": args.iter_max,
                    "workload": "synth_volume(%d,0,'clean') blurred sigma=2 + 2%% noise, TV, alpha=0.01" % n},
-        "finite": bool(torch.isfinite(x).all())}))
+        "finite": bool(torch.isfinite(x).all()),
+        "in_run": {"wall_s": wall, "kernel_ms": kernel_ms, "entries": table}}))
 
 
 if __name__ == "__main__":
