@@ -142,6 +142,19 @@ int blur3_lanczos_b2(const double *t, const double *y, const double *y_prev, dou
                      const Taps<double> &ty, const Taps<double> &tx, int ntaps, double rho_g,
                      double rho_i, double *board, int step, double *coef, double *part,
                      int64_t part_doubles, hipStream_t st);
+// ... as ONE launch behind the blur: t = A y (epi 2) and the kernel that sums its partials
+// onto board[3 step + 1 .. 2] and forms coef[4 .. 5] (instead of the generic reduction of
+// epi 2 followed by blur3_lanczos_a2_close)
+__attribute__((visibility("hidden")))
+int blur3_lanczos_a2(const float *y, float *t, int64_t nz, int64_t ny, int64_t nx,
+                     const Taps<float> &tz, const Taps<float> &ty, const Taps<float> &tx,
+                     int ntaps, double rho_g, double rho_i, double *board, int step,
+                     float *coef, double *part, int64_t part_doubles, hipStream_t st);
+__attribute__((visibility("hidden")))
+int blur3_lanczos_a2(const double *y, double *t, int64_t nz, int64_t ny, int64_t nx,
+                     const Taps<double> &tz, const Taps<double> &ty, const Taps<double> &tx,
+                     int ntaps, double rho_g, double rho_i, double *board, int step,
+                     double *coef, double *part, int64_t part_doubles, hipStream_t st);
 __attribute__((visibility("hidden")))
 int blur3_lanczos_a2_close(const double *sums2, double *board, int step, double rho_g,
                            double rho_i, float *coef, hipStream_t st);
@@ -1323,6 +1336,13 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                      nz, ny, nx, tz, ty, tx, (int)dntx, (int)dnty, (int)nzc, (int)zchunk,
                      per_xcd, (T)ca, (T)cb, (T)cc, part, (const T *)nullptr,
                      (const T *)nullptr, (T *)nullptr, (const T *)nullptr);
+  if constexpr (EPI == 2) {
+    if (lz) {                    // the first Lanczos half: sums -> board, coefficients
+      hipLaunchKernelGGL(k_blur3_lanczos_final<T>, dim3(1), dim3(kBlock), 0, st, part,
+                         (int)tiles, 1, lz->board, lz->step, lz->rho_g, lz->rho_i, lz->coef);
+      return launch_status();
+    }
+  }
   if (EPI != 0)
     hipLaunchKernelGGL(k_blur3_epi_final, dim3(EPI == 2 ? 2 : 1), dim3(kBlock), 0, st, part,
                        (int)tiles, result, 1.0);
@@ -1334,13 +1354,14 @@ template <typename T>
 int blur3_dma_dispatch(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
                        const Taps<T> &tz, const Taps<T> &ty, const Taps<T> &tx, int ntaps,
                        int epi, double ca, double cb, double cc, double *result,
-                       double *part, int64_t part_doubles, hipStream_t st) {
+                       double *part, int64_t part_doubles, hipStream_t st,
+                       const LanczosArgs<T> *lz = nullptr) {
   constexpr int VEC = 16 / sizeof(T);
 #define NSOL_B3D_CASE(N)                                                                  \
   case N:                                                                                 \
     return epi == 2 ? launch_blur3_dma<T, VEC, N, 16, 2>(x, out, nz, ny, nx, tz, ty, tx, st, \
                                                          ca, cb, cc, result, part,         \
-                                                         part_doubles)                     \
+                                                         part_doubles, lz)                 \
            : epi    ? launch_blur3_dma<T, VEC, N, 16, 1>(x, out, nz, ny, nx, tz, ty, tx, st, \
                                                          ca, cb, 0.0, result, part,        \
                                                          part_doubles)                     \

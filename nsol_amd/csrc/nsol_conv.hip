@@ -796,12 +796,10 @@ int lanczos_a2_impl(const T *y, T *t, int64_t nz, int64_t ny, int64_t nx,
     return -2;                                     // (as the other halves: no ragged form)
   // (unit spacing: the squared weights of the difference sums are 1; the sums land on
   // board[3 step + 1], [3 step + 2])
-  const int rc = blur3_dma_run(y, t, nz, ny, nx, tz, ty, tx, ntaps, 2, 1.0, 1.0, 1.0,
-                               board + 3 * (int64_t)step + 1, ws, ws_doubles,
-                               as_stream(stream));
-  if (rc != 0) return rc;
-  return blur3_lanczos_a2_close(board + 3 * (int64_t)step + 1, board, step, rho_grad,
-                                rho_ident, coef, as_stream(stream));
+  // (one launch behind the blur: its partials summed onto the board and the second half's
+  // coefficients formed -- nsol_blur3::k_blur3_lanczos_final, as after the half with q0)
+  return blur3_lanczos_a2(y, t, nz, ny, nx, tz, ty, tx, ntaps, rho_grad, rho_ident, board,
+                          step, coef, ws, ws_doubles, as_stream(stream));
 }
 
 template <typename T>
