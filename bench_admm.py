@@ -62,6 +62,7 @@ PMC_NAMES = {"k_tk1_lanczos": "k_tk1_reg<float, 4, 4, false, 2>",
              "k_blur3_dma_epi": "k_blur3_dma<float, 4, 13, 16, true, 1, false>",
              "k_wcomb": "k_wcomb<float, 4, true>",
              "k_admm_vw": "k_admm_vw<float, 4, 4, false, true>",
+             "k_admm_vw_g": "k_admm_vw_g<float, 4, false>",
              "k_lsmr_v": "k_lsmr_v<float, 4, 4, false>",
              "k_lsmr_u": "k_lsmr_u<float, 4, 4, false>"}
 
@@ -148,6 +149,9 @@ ENTRIES = {
     "lsmr_v_update": ("k_lsmr_v", 24), "lsmr_v_update_to": ("k_lsmr_v", 24),
     "lsmr_hx_update": ("k_lsmr_hx", 28),
     "admm_vw_update": ("k_admm_vw", 40), "admm_vw_update_norm": ("k_admm_vw", 40),
+    # the outer step and the next solve's start vector in one pass: x, w (3), A^T b read;
+    # w (3), g written
+    "admm_vw_update_g": ("k_admm_vw_g", 36),
     "lincomb_clip": ("k_wcomb", lambda k: 4 * (k + 1)),
     "lb_wcomb": ("k_wcomb", lambda k: 4 * (k + 2) + 1),
     "lb_mdots": ("k_mdots", lambda k: 4 * (k + 1) + 1),
