@@ -54,10 +54,17 @@
 
 using namespace nsol;
 
-// Timing experiments only (wrong results): -DPDK_ABLATE=1 no global loads,
+// Timing experiments only (wrong results): -DPDK_ABLATE=32 no stage-1 halo loads, =1 no global loads,
 // 2 no global stores, 4 no barrier, 8 no arithmetic (memory pattern + LDS exchange
 // + barrier only), 16 with 8: no LDS exchange and no barrier either; bits combine
 // (DESIGN.md section 5).
+// Stage 1's halo (the old xbar of the rows above / below, the old p_y of the row above,
+// the x neighbours of a wave's first / last lane) exchanged through the LDS inside the
+// 12-wave depth-3 workgroup instead of re-loaded from global memory; only the footprint's
+// outermost rows and lanes still load theirs (0: every lane loads its halo, for A/B runs)
+#ifndef PDK_LH
+#define PDK_LH 1
+#endif
 #ifndef PDK_ABLATE
 #define PDK_ABLATE 0
 #endif
@@ -202,6 +209,26 @@ __device__ __forceinline__ void dual_vec(T (&out)[V], const T (&p_old)[V],
 }
 
 // LDS rows are padded by one (zero) row above and below the footprint
+// lane in `mask` ? s : 0, formed where it is used: volatile, so that the compiler neither
+// hoists it out of the plane loop nor keeps it in a register across a step (the
+// LDS-halo form of the kernel has no register to spare for nine such per-lane constants)
+__device__ __forceinline__ float masked_scalar(float s, uint64_t mask) {
+  float r;
+  // (one scalar operand per VOP3 instruction on gfx9: the value moves first)
+  asm volatile("v_mov_b32 %0, %1\n\tv_cndmask_b32_e64 %0, 0, %0, %2"
+               : "=&v"(r) : "s"(s), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ double masked_scalar(double s, uint64_t mask) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, s);
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, %1\n\tv_cndmask_b32_e64 %0, 0, %0, %2"
+               : "=&v"(lo) : "s"((uint32_t)b), "s"(mask));
+  asm volatile("v_mov_b32 %0, %1\n\tv_cndmask_b32_e64 %0, 0, %0, %2"
+               : "=&v"(hi) : "s"((uint32_t)(b >> 32)), "s"(mask));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 template <int NT, int K>
 struct LdsShape {
   static constexpr int LXM = NT / (2 * K);          // widest row (lanes)
@@ -226,9 +253,18 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   constexpr int H = K - 1;
   constexpr int HX = ((H + VEC - 1) / VEC) * VEC;
   constexpr int LN = LdsShape<NT, K>::N;
-  __shared__ __attribute__((aligned(16))) T s_xb[2][K - 1][LN * VEC];
-  __shared__ __attribute__((aligned(16))) T s_py[2][K - 1][LN * VEC];
-  __shared__ T s_px[2][K - 1][LN];   // last p_x^(k-1) of every lane's vector
+  // LH (see PDK_LH): a second barrier per step separates the exchange of stage 1's inputs
+  // from that of the later stages' -- the arrays then need no second copy by step parity,
+  // which is what makes room for the stage-0 arrays (108 KB instead of 144)
+  // (float, whole-vector rows: the double and the ragged-row instantiations would spill)
+  constexpr bool LH = PDK_LH && K == 3 && NW == 12 && !PF2 && sizeof(T) == 4 && !RAG;
+  constexpr int NB = LH ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) T s_xb[NB][K - 1][LN * VEC];
+  __shared__ __attribute__((aligned(16))) T s_py[NB][K - 1][LN * VEC];
+  __shared__ T s_px[NB][K - 1][LN];   // last p_x^(k-1) of every lane's vector
+  __shared__ __attribute__((aligned(16))) T s_xb0[LH ? LN * VEC : VEC];   // old xbar[s]
+  __shared__ __attribute__((aligned(16))) T s_py0[LH ? LN * VEC : VEC];   // old p_y[s]
+  __shared__ T s_px0[LH ? LN : 1];                                        // old p_x[s], last
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -299,6 +335,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     sig_m[k] = rin ? S.sigma[k] : T(0);
     tau_m[k] = rin ? S.tau[k] : T(0);
   }
+  // (LH: the same values from lane masks in scalar registers at every use, see
+  // masked_scalar)
+  const uint64_t m_rin = __builtin_amdgcn_ballot_w64(rin);
+  auto sigm = [&](int k) -> T {
+    if constexpr (LH) return masked_scalar(S.sigma[k], m_rin); else return sig_m[k];
+  };
+  auto taum = [&](int k) -> T {
+    if constexpr (LH) return masked_scalar(S.tau[k], m_rin); else return tau_m[k];
+  };
 
   // plane indices fit in 32 bits (the host checks nz < 2^30): scalar registers
   // are the scarce resource here (11 buffer descriptors)
@@ -337,10 +382,22 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   const bool row_beg = (lx == 0) || lane == 0 || lone;
   const uint32_t o0 = (uint32_t)((y * G.sy + x0) * (int64_t)sizeof(T));
   const uint32_t v_own = rin ? o0 : kInvalid;
-  const uint32_t v_up = (rin && y > 0) ? o0 - syb : kInvalid;
-  const uint32_t v_down = (rin && y + 1 < G.ny) ? o0 + syb : kInvalid;
-  const uint32_t v_right = (rin && row_end && x0 + VEC < G.nx) ? o0 + 16u : kInvalid;
-  const uint32_t v_left = (rin && row_beg && x0 > 0) ? o0 - (uint32_t)sizeof(T) : kInvalid;
+  // (LH: only the footprint's first / last row and first / last lane load their halo;
+  // everybody else's comes out of the LDS)
+  const bool e_up = !LH || row == 0, e_down = !LH || row == Q.rows - 1;
+  const bool e_right = LH ? lx == lxb - 1 : row_end, e_left = LH ? lx == 0 : row_beg;
+  uint32_t v_up = (rin && y > 0 && e_up) ? o0 - syb : kInvalid;
+  const uint32_t v_down = (rin && y + 1 < G.ny && e_down) ? o0 + syb : kInvalid;
+  uint32_t v_right = (rin && e_right && x0 + VEC < G.nx) ? o0 + 16u : kInvalid;
+  const uint32_t v_left = (rin && e_left && x0 > 0) ? o0 - (uint32_t)sizeof(T) : kInvalid;
+  // (LH: a lane sits in at most one outermost row and is at most one outermost lane, so
+  // the row beyond the footprint -- above OR below -- lands in one register vector and
+  // the x neighbour beyond it -- right OR left -- in one register: four vector registers
+  // and a load less per lane and step)
+  const bool last_row = row == Q.rows - 1;
+  if (LH && last_row && row != 0) v_up = v_down;
+  if (LH && lx == 0 && lxb > 1) v_right = v_left;
+  const uint32_t v_pyup = (LH && row != 0) ? kInvalid : v_up;
   const uint32_t v_st = rvalid ? o0 : kInvalid;
   // RAG: rows are not a multiple of the vector width, so the row's last vector
   // sticks out by VEC - nval elements (they belong to the next row).  Their xbar
@@ -388,6 +445,11 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   sig_u[0] = g_u ? S.sigma[0] : T(0);
 #pragma unroll
   for (int k = 1; k < K; ++k) sig_u[k] = v_u ? S.sigma[k] : T(0);
+  const uint64_t m_gu = __builtin_amdgcn_ballot_w64(g_u), m_vu = __builtin_amdgcn_ballot_w64(v_u);
+  auto sigu = [&](int k) -> T {
+    if constexpr (LH) return masked_scalar(S.sigma[k], k == 0 ? m_gu : m_vu);
+    else return sig_u[k];
+  };
   // Stage k is exact -- and its result used -- only k-1 rows inside the footprint
   // (and, for the last stage, off the x halo lanes): the outer rows run stage 1
   // only, the next ones stages 1-2, ...  A wave none of whose lanes needs a stage
@@ -404,7 +466,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   }
 
   // zero rows above and below the footprint, once
-  for (int i = tid; i < 2 * (K - 1) * 2 * lxb * VEC; i += NT) {
+  for (int i = tid; i < NB * (K - 1) * 2 * lxb * VEC; i += NT) {
     const int e = i % (lxb * VEC);
     int r = i / (lxb * VEC);
     const int side = r & 1; r >>= 1;
@@ -413,6 +475,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     const int at = side ? (Q.rows + 1) * lxb * VEC + e : e;
     s_xb[b][kk][at] = T(0);
     s_py[b][kk][at] = T(0);
+    if (LH && b == 0 && kk == 0) { s_xb0[at] = T(0); s_py0[at] = T(0); }
   }
 
   // State carried from one plane step to the next.  The 8-wave variants keep two
@@ -459,23 +522,49 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
   // stage-1 arithmetic of plane s (a full step of latency hiding; +36 VGPRs).
   typedef PlaneLoads<T, VEC> Loads;
   Loads LA, LB;
+  // stage 1's halo of plane `a`
+  auto issue_halo = [&](Loads &L, uint32_t a) {
+#if PDK_ABLATE & 32
+    // (timing experiment, wrong results: stage 1 without its halo loads -- what an
+    // exchange of the old xbar / p_y rows inside the workgroup could save at most)
+    L.xright = L.xleft = L.pxleft = T(0);
+    zero(L.xdown); zero(L.xup); zero(L.pyup);
+#else
+    if constexpr (LH) {
+      // (every wave issues them, nine of the twelve with every lane out of range: a
+      // wave-uniform branch around them cost more than it saved -- 1.250 against
+      // 1.168 ms per launch, the form without the exchange 1.193)
+      L.xright = bld1<T>(r_xb, v_right, a);
+      L.pxleft = bld1<T>(r_px, v_left, a);
+      bld<T, VEC>(r_xb, v_up, a, L.xup);
+      bld<T, VEC>(r_py, v_pyup, a, L.pyup);
+    } else {
+      L.xright = bld1<T>(r_xb, v_right, a);
+      L.xleft = bld1<T>(r_xb, v_left, a);
+      L.pxleft = bld1<T>(r_px, v_left, a);
+      bld<T, VEC>(r_xb, v_down, a, L.xdown);
+      bld<T, VEC>(r_xb, v_up, a, L.xup);
+      bld<T, VEC>(r_py, v_up, a, L.pyup);
+    }
+#endif
+  };
   auto issue_loads = [&](Loads &L, int sp, uint32_t a) {
     // sp: plane; a: its scalar offset.  The plane above the volume is zero.
 #if PDK_PRIO & 1
     __builtin_amdgcn_s_setprio(3);
 #endif
+    // (LH: the halo loads first.  They are what the next step publishes first, under
+    // lane masks, and the compiler waits for the LAST load of a step with vmcnt(0) --
+    // the stores issued behind it drained at the top of every step; the own planes'
+    // loads it counts)
+    if constexpr (LH) issue_halo(L, a);
     bld<T, VEC>(r_xb, (sp + 1 < nzi) ? v_own : kInvalid, a + szb, L.xn);
     bld<T, VEC>(r_x, v_own, a, L.xv);
     bld<T, VEC>(r_bt, v_own, a, L.btn);
     bld<T, VEC>(r_px, v_own, a, L.pxo);
     bld<T, VEC>(r_py, v_own, a, L.pyo);
     bld<T, VEC>(r_pz, v_own, a, L.pzo);
-    L.xright = bld1<T>(r_xb, v_right, a);
-    L.xleft = bld1<T>(r_xb, v_left, a);
-    L.pxleft = bld1<T>(r_px, v_left, a);
-    bld<T, VEC>(r_xb, v_down, a, L.xdown);
-    bld<T, VEC>(r_xb, v_up, a, L.xup);
-    bld<T, VEC>(r_py, v_up, a, L.pyup);
+    if constexpr (!LH) issue_halo(L, a);
 #if PDK_PRIO & 1
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -499,7 +588,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         acc[j] = L.xn[j] + L.xv[j] + L.btn[j] + L.pxo[j] + L.pyo[j] + L.pzo[j] + L.xdown[j] +
                  L.xup[j] + L.pyup[j] + L.xright + L.xleft + L.pxleft + P.xc[j];
       if constexpr (HAVE1) issue_loads(L, more ? s + 1 : s, more ? adv + szb : adv);
-      const int buf = (int)(s & 1);
+      const int buf = LH ? 0 : (int)(s & 1);
 #if !(PDK_ABLATE & 16)
 #pragma unroll
       for (int k = 2; k <= K; ++k) {
@@ -546,25 +635,84 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       // prefetch plane s+1 (after the last plane: re-reads it, unused)
       const bool more = s + 1 <= s_hi;
       if constexpr (PF2) issue_loads(LN, more ? s + 1 : s, more ? adv + szb : adv);
+#if PDK_ABLATE & 64
+      {
+        // (timing experiment, with bit 32: what an exchange of stage 1's halo through
+        // the LDS would cost -- two vectors and a scalar published, a SECOND barrier in
+        // the step, three vectors and three scalars read back)
+        const int b0 = LH ? 0 : (int)(s & 1);
+        stv<T, VEC>(&s_xb[b0][0][li], P.xc);
+        stv<T, VEC>(&s_py[b0][0][li], L.pyo);
+        s_px[b0][0][slot] = L.pxo[VEC - 1];
+        __syncthreads();
+        ldv<T, VEC>(&s_xb[b0][0][li + lxb * VEC], L.xdown);
+        ldv<T, VEC>(&s_xb[b0][0][li - lxb * VEC], L.xup);
+        ldv<T, VEC>(&s_py[b0][0][li - lxb * VEC], L.pyup);
+        L.xright = s_xb[b0][0][li + VEC];
+        L.xleft = s_xb[b0][0][li - 1];
+        L.pxleft = s_px[b0][0][slot - 1];
+      }
+#endif
       // ================= stage 1: iteration n+1 on plane s ===================
+      // its halo: loaded (every lane its own), or -- LH -- the old values every lane
+      // holds anyway exchanged through the LDS: own xbar[s], p_y[s] and the last p_x[s]
+      // published, the footprint's outermost rows also put the row they loaded from
+      // beyond it into the padding row, a barrier, the neighbours read
+      T h_down[VEC], h_up[VEC], h_pyup[VEC];
+      T h_right = L.xright, h_left = LH ? L.xright : L.xleft, h_pxleft = L.pxleft;
+      if constexpr (LH) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+          stv<T, VEC>(&s_xb0[li], P.xc);
+          stv<T, VEC>(&s_py0[li], L.pyo);
+          s_px0[slot] = L.pxo[VEC - 1];
+          if (row == 0) {
+            stv<T, VEC>(&s_xb0[li - lxb * VEC], L.xup);
+            stv<T, VEC>(&s_py0[li - lxb * VEC], L.pyup);
+          }
+          // (the last row's L.xup holds the row BELOW the footprint; a one-row footprint
+          // would need both and does not exist: rows >= 2 K - 1)
+          if (last_row && row != 0) stv<T, VEC>(&s_xb0[li + lxb * VEC], L.xup);
+        }
+        __syncthreads();
+        ldv<T, VEC>(&s_xb0[li + lxb * VEC], h_down);
+        ldv<T, VEC>(&s_xb0[li - lxb * VEC], h_up);
+        ldv<T, VEC>(&s_py0[li - lxb * VEC], h_pyup);
+        if (lx != lxb - 1) h_right = s_xb0[li + VEC];
+        if (lx != 0) {
+          h_left = s_xb0[li - 1];
+          h_pxleft = s_px0[slot - 1];
+        }
+        // (the halo-free parts of stage 1 stay below the exchange: hoisted above the
+        // barrier they hold their results across it and the kernel spills)
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          h_down[j] = L.xdown[j];
+          h_up[j] = L.xup[j];
+          h_pyup[j] = L.pyup[j];
+        }
+      }
       T nb = __shfl_down(P.xc[0], 1, kWave);
-      if (row_end) nb = L.xright;
+      if (row_end) nb = h_right;
+      const T sm0 = sigm(0), tm0 = taum(0), su0 = sigu(0);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const T hx = (j + 1 < VEC) ? P.xc[(j + 1) % VEC] : nb;
-        f_px[j] = dual_update_u<HUBER, UNIT>(L.pxo[j], hx, P.xc[j], G.wx, sig_m[0], S.hden[0]);
+        f_px[j] = dual_update_u<HUBER, UNIT>(L.pxo[j], hx, P.xc[j], G.wx, sm0, S.hden[0]);
       }
-      dual_vec<HUBER, UNIT>(f_py, L.pyo, L.xdown, P.xc, G.wy, sig_m[0], S.hden[0]);
-      dual_vec<HUBER, UNIT>(pzn[0], L.pzo, L.xn, P.xc, G.wz, sig_m[0], S.hden[0]);
+      dual_vec<HUBER, UNIT>(f_py, L.pyo, h_down, P.xc, G.wy, sm0, S.hden[0]);
+      dual_vec<HUBER, UNIT>(pzn[0], L.pzo, L.xn, P.xc, G.wz, sm0, S.hden[0]);
       T pxl = __shfl_up(f_px[VEC - 1], 1, kWave);
       if (row_beg)
-        pxl = g_l ? dual_update_u<HUBER, UNIT>(L.pxleft, P.xc[0], L.xleft, G.wx, S.sigma[0],
+        pxl = g_l ? dual_update_u<HUBER, UNIT>(h_pxleft, P.xc[0], h_left, G.wx, S.sigma[0],
                                          S.hden[0])
                   : T(0);
       // the upper neighbour's new dual; without one, pyup = xup = 0 (offset out
       // of range) and sig_u = 0 make it exactly zero
       T puv[VEC];
-      dual_vec<HUBER, UNIT>(puv, L.pyup, P.xc, L.xup, G.wy, sig_u[0], S.hden[0]);
+      dual_vec<HUBER, UNIT>(puv, h_pyup, P.xc, h_up, G.wy, su0, S.hden[0]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const T pu = puv[j];
@@ -572,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
         T kt = adj_term<UNIT>(f_px[j], pl, G.wx);
         kt += adj_term<UNIT>(f_py[j], pu, G.wy);
         kt += adj_term<UNIT>(pzn[0][j], P.pz[0][j], G.wz);
-        const T u = L.xv[j] - tau_m[0] * kt;
+        const T u = L.xv[j] - tm0 * kt;
         const T xnew = prox_data_s<L1>(u, L.btn[j], S.tl[0], S.optl[0]);
         fr_x[0][j] = xnew;
         fr_xb[0][j] = xnew + S.theta[0] * (xnew - L.xv[j]);
@@ -584,6 +732,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       if constexpr (K > 1) cut_tail(fr_xb[0]);
       if constexpr (!PF2) issue_loads(L, more ? s + 1 : s, more ? adv + szb : adv);
     } else {
+      // (LH: the arrays of the later stages have one copy -- the barrier that stage 1's
+      // exchange brings in a full step separates this step's writes from the reads of
+      // the step before here too)
+      if constexpr (LH) __syncthreads();
       zero(fr_xb[0]); zero(fr_x[0]); zero(fr_bt[0]); zero(pzn[0]);
       zero(f_px); zero(f_py);
 #pragma unroll
@@ -598,12 +750,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       const bool inr = f >= 0 && f < nzi;
       // the last stage needs no per-lane masks: what it computes for a voxel
       // outside the volume is neither stored nor read by anyone
-      const T sk = inr ? (k == K ? S.sigma[K - 1] : sig_m[k - 1]) : T(0);
-      const T tk = inr ? (k == K ? S.tau[K - 1] : tau_m[k - 1]) : T(0);
+      // (wneed first: sigm / taum are formed by volatile instructions)
       if (!wneed[k - 1]) {                         // wave-uniform
         zero(fr_x[k - 1]); zero(fr_xb[k - 1]); zero(fr_bt[k - 1]); zero(pzn[k - 1]);
         continue;
       }
+      const T sk = inr ? (k == K ? S.sigma[K - 1] : sigm(k - 1)) : T(0);
+      const T tk = inr ? (k == K ? S.tau[K - 1] : taum(k - 1)) : T(0);
       T pkz[VEC];
       dual_vec<HUBER, UNIT>(pkz, P.pz[k - 2], fr_xb[k - 2], P.c_xb[k - 1], G.wz, sk,
                             S.hden[k - 1]);
@@ -628,7 +781,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     }
 
     // ================= IP_k: in-plane part of iteration n+k on plane s-(k-2) =
-    const int buf = (int)(s & 1);
+    const int buf = LH ? 0 : (int)(s & 1);
 #pragma unroll
     for (int k = 2; k <= K; ++k) {
       stv<T, VEC>(&s_xb[buf][k - 2][li], fr_xb[k - 2]);
@@ -662,7 +815,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
                                                S.sigma[k - 1], S.hden[k - 1])
                         : T(0);
       T pkx[VEC], pky[VEC], puv[VEC];
-      const T sgk = (k == K) ? S.sigma[K - 1] : sig_m[k - 1];   // see F_k
+      const T sgk = (k == K) ? S.sigma[K - 1] : sigm(k - 1);    // see F_k
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const T px_old = (k == 2) ? f_px[j] : P.c_px[k - 1][j];
@@ -675,7 +828,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
       else
         dual_vec<HUBER, UNIT>(pky, P.c_py[k - 1], below, fr_xb[k - 2], G.wy, sgk,
                               S.hden[k - 1]);
-      dual_vec<HUBER, UNIT>(puv, above_py, fr_xb[k - 2], above, G.wy, sig_u[k - 1],
+      dual_vec<HUBER, UNIT>(puv, above_py, fr_xb[k - 2], above, G.wy, sigu(k - 1),
                             S.hden[k - 1]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
