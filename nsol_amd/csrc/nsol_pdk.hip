@@ -531,11 +531,14 @@ __global__ __launch_bounds__(NW * 64, WPE) void k_pd_fusedk(
     zero(L.xdown); zero(L.xup); zero(L.pyup);
 #else
     if constexpr (LH) {
-      // (every wave issues them, nine of the twelve with every lane out of range: a
-      // wave-uniform branch around them cost more than it saved -- 1.250 against
-      // 1.168 ms per launch, the form without the exchange 1.193)
-      L.xright = bld1<T>(r_xb, v_right, a);
-      L.pxleft = bld1<T>(r_px, v_left, a);
+      // The rows beyond the footprint (every wave issues the two loads, nine of the
+      // twelve with every lane out of range: a wave-uniform branch around them cost more
+      // than it saved -- 1.250 against 1.168 ms per launch, without the exchange 1.193).
+      // The VOXELS beyond the footprint's first / last lane are not loaded at all: they
+      // only reach stage 1 of the footprint's outermost voxel, and with HX >= K what a
+      // stored value depends on ends one voxel short of it (static_assert below).
+      static_assert(!LH || HX >= K, "LH: the x halo must be wider than the dependency cone");
+      L.xright = L.pxleft = T(0);
       bld<T, VEC>(r_xb, v_up, a, L.xup);
       bld<T, VEC>(r_py, v_pyup, a, L.pyup);
     } else {
