@@ -209,6 +209,65 @@ __device__ __forceinline__ V splat(T w) {
   return r;
 }
 
+// s * a and fma(s, a, c) for a wave-uniform s.  Four floats are two packed operations, and
+// both take the SAME (s, s) register pair: written on the halves, the pair is one value the
+// compiler keeps once -- the four-wide splat became (s, s, s, s) in four scalar registers
+// per tap and coefficient, which at 13 taps pushed some seventy scalars out into lanes of a
+// vector register, each read back with a v_readlane (a vector issue slot) per use.
+template <typename V, typename T>
+__device__ __forceinline__ V smul(T s, V a) {
+  if constexpr (sizeof(T) == 4 && sizeof(V) == 16) {
+    typedef T P2 __attribute__((ext_vector_type(2)));
+    const P2 w = P2{s, s};
+    const P2 lo = w * P2{a[0], a[1]}, hi = w * P2{a[2], a[3]};
+    return V{lo[0], lo[1], hi[0], hi[1]};
+  } else {
+    return splat<V, T>(s) * a;
+  }
+}
+template <typename V, typename T>
+__device__ __forceinline__ V sfma(T s, V a, V c) {
+  if constexpr (sizeof(T) == 4 && sizeof(V) == 16) {
+    typedef T P2 __attribute__((ext_vector_type(2)));
+    const P2 w = P2{s, s};
+    const P2 lo = __builtin_elementwise_fma(w, P2{a[0], a[1]}, P2{c[0], c[1]});
+    const P2 hi = __builtin_elementwise_fma(w, P2{a[2], a[3]}, P2{c[2], c[3]});
+    return V{lo[0], lo[1], hi[0], hi[1]};
+  } else {
+    return __builtin_elementwise_fma(splat<V, T>(s), a, c);
+  }
+}
+
+// The z window's planes as two register PAIRS per lane (four floats): held as whole
+// four-wide values the two packed operations of a tap were folded back into one four-wide
+// operation whose splat took four scalars again -- 28 scalar registers for the z pass alone
+// beside the 14 the x and y passes share.
+template <typename T, typename V, bool PK>
+struct Halves {
+  V v;
+  __device__ __forceinline__ void set(V a) { v = a; }
+  __device__ __forceinline__ V get() const { return v; }
+  __device__ __forceinline__ void mul(T s, const Halves &a) { v = smul(s, a.v); }
+  __device__ __forceinline__ void fma(T s, const Halves &a) { v = sfma(s, a.v, v); }
+};
+template <typename T, typename V>
+struct Halves<T, V, true> {
+  typedef T P2 __attribute__((ext_vector_type(2)));
+  P2 lo, hi;
+  __device__ __forceinline__ void set(V a) { lo = P2{a[0], a[1]}; hi = P2{a[2], a[3]}; }
+  __device__ __forceinline__ V get() const { return V{lo[0], lo[1], hi[0], hi[1]}; }
+  __device__ __forceinline__ void mul(T s, const Halves &a) {
+    const P2 w = P2{s, s};
+    lo = w * a.lo;
+    hi = w * a.hi;
+  }
+  __device__ __forceinline__ void fma(T s, const Halves &a) {
+    const P2 w = P2{s, s};
+    lo = __builtin_elementwise_fma(w, a.lo, lo);
+    hi = __builtin_elementwise_fma(w, a.hi, hi);
+  }
+};
+
 __device__ __forceinline__ float fma1(float a, float b, float c) {
   return __builtin_fmaf(a, b, c);
 }
@@ -251,6 +310,12 @@ constexpr size_t blur3_base_vecs() {
 }
 // EPI 6: a halo'd tile of y per wave (128 slots each) where that fits beside the
 // own-position tile of y_prev; else one shared tile (see the kernel)
+#ifndef NSOL_B3_STEADY
+#define NSOL_B3_STEADY 0             // (1: whole trips of steady-state phases take an instantiation
+                                     // of their own; measured with the plain blur and EPI 2 only --
+                                     // EPI 6 has no registers for it: 308 bytes of scratch, whose
+                                     // loads and stores would also break the counted waits)
+#endif
 #ifndef NSOL_B3_EPI6_MINI
 #define NSOL_B3_EPI6_MINI 1          // (0: the shared tile everywhere, for A/B runs)
 #endif
@@ -263,12 +328,13 @@ constexpr bool blur3_epi6_mini() {
 
 // phases U .. M-1 of one trip through the loop body (each with its position in the
 // ring as a compile-time constant); stops at the end of the z chunk
-template <int U, int M, typename F>
+// (S: a trip whose phases are all in the steady state -- see the kernel's loop)
+template <int U, int M, bool S, typename F>
 __device__ __forceinline__ void blur3_phases(int st0, int nsteps, F &f) {
   if constexpr (U < M) {
-    if (st0 + U < nsteps) {
-      f(st0 + U, std::integral_constant<int, U>());
-      blur3_phases<U + 1, M>(st0, nsteps, f);
+    if (S || st0 + U < nsteps) {
+      f(st0 + U, std::integral_constant<int, U>(), std::integral_constant<bool, S>());
+      blur3_phases<U + 1, M, S>(st0, nsteps, f);
     }
   }
 }
@@ -403,6 +469,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   const int64_t y0 = (int64_t)by * tyr;
   const bool owner = xv < nxv && (y0 + row < ny);
   const int64_t plane = ny * nx;
+  const int plane_i = (int)plane;              // (< 2^31: checked by the launcher)
   // (RAG) elements of this lane's output vector inside the row; the tile column that
   // holds the row's partial vector; the raw-row slot that straddles the row end
   const int nvalid = RAG ? (int)(nx - (int64_t)xv * VEC) : VEC;
@@ -460,8 +527,9 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   }
   // pieces this wave issues per plane (wave-uniform)
   const int my_pieces = (npieces - wave + NW - 1) / NW;
-  auto stage = [&](int64_t z, int rbuf) {      // plane z -> raw tile at vector offset rbuf
-    const T *pl = x + z * plane;
+  // (plane indices are 32-bit: a 64-bit comparison of scalars is a vector instruction)
+  auto stage = [&](int z, int rbuf) {          // plane z -> raw tile at vector offset rbuf
+    const T *pl = x + (int64_t)z * plane_i;
 #pragma unroll
     for (int j = 0; j < MAXP; ++j) {
       if (j * NW >= npieces) break;              // (compile time)
@@ -530,7 +598,11 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     const V *pslot = rb + patch0 + fr;
     auto wload = [&](int b) -> V {
       if constexpr (ps) return *((lx + b == cs) ? pslot : w + b);
+#ifdef NSOL_B3_ABLATE_XREADS       // (timing only: 3 vectors read for the window's 5)
+      else return w[b & ~1];
+#else
       else return w[b];
+#endif
     };
     constexpr int off = NBH * VEC - R;             // window index of output 0, tap 0
     V res;
@@ -612,20 +684,22 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     }
   };
 
-  const int64_t zbeg = (int64_t)bz * zchunk;
-  int64_t zend = zbeg + zchunk;
-  if (zend > nz) zend = nz;
-  const int nsteps = (int)(zend - zbeg) + 2 * R;    // planes zbeg - R .. zend + R - 1
-  int zw = (int)((zbeg - R) % nz);                  // plane of the next stage()
-  if (zw < 0) zw += (int)nz;
+  const int nzi = (int)nz;                          // (< 2^31: checked by the launcher)
+  const int zbeg = bz * zchunk;
+  int zend = zbeg + zchunk;
+  if (zend > nzi) zend = nzi;
+  const int nsteps = (zend - zbeg) + 2 * R;    // planes zbeg - R .. zend + R - 1
+  int zw = (zbeg - R) % nzi;                        // plane of the next stage()
+  if (zw < 0) zw += nzi;
   auto next_plane = [&]() {
     const int z = zw;
-    if (++zw == (int)nz) zw = 0;
-    return (int64_t)z;
+    if (++zw == nzi) zw = 0;
+    return z;
   };
-  V ring[NT - 1];                                   // xy-filtered planes, oldest first
+  typedef Halves<T, V, sizeof(T) == 4 && VEC == 4> RV;
+  RV ring[NT - 1];                                  // xy-filtered planes, oldest first
 #pragma unroll
-  for (int t = 0; t + 1 < NT; ++t) ring[t] = splat<V, T>(T(0));
+  for (int t = 0; t + 1 < NT; ++t) ring[t].set(splat<V, T>(T(0)));
   // output: one buffer descriptor per plane and a 32-bit offset inside it; lanes
   // that own no voxel carry an out-of-range offset (the store is dropped by the
   // hardware), so EVERY wave issues exactly one store per output plane -- the
@@ -689,8 +763,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     }
   }
   V ym1 = splat<V, T>(T(0)), y0c = splat<V, T>(T(0)), lap0 = splat<V, T>(T(0));
-  auto put = [&](int64_t z, V val, int ob) {
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + z * plane, 0, plane_bytes,
+  auto put = [&](int z, V val, int ob) {
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)z * plane_i, 0, plane_bytes,
                                                         0x00020000);
     if constexpr (EPI == 1) {
       V old = obuf[(size_t)ob * tile_vecs + (size_t)row * lxb + lx];
@@ -706,7 +780,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
             }
         }
       }
-      val = splat<V, T>(ca) * val + splat<V, T>(cb) * old;
+      val = smul(ca, val) + smul(cb, old);
     }
     if constexpr (EPI == 5) {
       const V bv = obuf[(size_t)ob * tile_vecs + (size_t)row * lxb + lx];
@@ -772,28 +846,29 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     if (RAG && xe + VEC > nx) xe = nx - VEC;
     old_off = (uint32_t)(yy * nx + xe);
   }
-  auto stage_old = [&](int64_t z, int ob) {
+  auto stage_old = [&](int z, int ob) {
     if constexpr (EPI == 1 || EPI == 5)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)((EPI == 5 ? aux1 : out) + z * plane +
+          (const __attribute__((address_space(1))) void *)((EPI == 5 ? aux1 : out) +
+                                                           (int64_t)z * plane_i +
                                                            old_off),
           (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
                                                      (size_t)wave * 64),
           16, 0, NSOL_B3_AUX_OWN);
   };
   // (EPI 3 / 4) the own-position tile of plane z of `src` -> obuf[ob]
-  auto stage_tile = [&](const T *src, int64_t z, int ob) {
+  auto stage_tile = [&](const T *src, int z, int ob) {
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)(src + z * plane + old_off),
+        (const __attribute__((address_space(1))) void *)(src + (int64_t)z * plane_i + old_off),
         (__attribute__((address_space(3))) void *)(obuf + (size_t)ob * tile_vecs +
                                                    (size_t)wave * 64),
         16, 0, NSOL_B3_AUX_OWN);
   };
   // (EPI 6) plane z of y (clamped into the volume) with its halo -> behind the own tile
-  auto stage_yh = [&](int64_t z) {
+  auto stage_yh = [&](int z) {
     if (z < 0) z = 0;
-    if (z >= nz) z = nz - 1;
-    const T *pl = aux1 + z * plane;
+    if (z >= nzi) z = nzi - 1;
+    const T *pl = aux1 + (int64_t)z * plane_i;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = MINI ? wave * 2 + j : wave + j * NW;
@@ -808,10 +883,10 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   const int my_yh_ops = MINI ? 2 : (wave < hpieces ? 1 : 0) + (wave + NW < hpieces ? 1 : 0);
   (void)my_yh_ops;
   // a 16-byte store every wave issues (offset kNoLane: dropped by the hardware)
-  auto store_at = [&](T *dst, int64_t z, uint32_t off, V val) {
+  auto store_at = [&](T *dst, int z, uint32_t off, V val) {
     if (z < 0) z = 0;
-    if (z >= nz) z = nz - 1;
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst + z * plane, 0, plane_bytes,
+    if (z >= nzi) z = nzi - 1;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst + (int64_t)z * plane_i, 0, plane_bytes,
                                                         0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, off, 0, 2);
     asm volatile("s_nop 1");
@@ -832,30 +907,48 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   // compile-time constants (no register moves: they were a third of the vector
   // instructions), like the x-filtered buffer's index.
   constexpr int M = NT - 1;
-  auto phase = [&](int st, auto U) {
+  // SS: a phase of the steady state, 2R <= st and st + max(R + 1, 3) < nsteps -- every
+  // pipeline stage is at work (a plane to request, one to filter along x, one to store, the
+  // difference sums and K'K inside the chunk's own planes), so none of the conditions
+  // below is evaluated and the zeros of the idle cases are not merged in: the loop runs
+  // its whole trips of steady phases through this instantiation (12 phases at 13 taps,
+  // 10 of a 128-plane chunk's 12 trips) and keeps the general one for the first and
+  // last trips.
+  auto phase = [&](int st, auto U, auto S) {
     constexpr int u = decltype(U)::value;           // = st mod M
     constexpr int q = u & 1;                        // = st & 1 (M is even)
-    const bool more = st + 3 < nsteps;
-    const bool storing = st >= 2 * R;
+    constexpr bool SS = decltype(S)::value;
+    const bool more = SS || st + 3 < nsteps;
+    const bool storing = SS || st >= 2 * R;
+    const bool next_x = SS || st + 1 < nsteps;      // a plane st + 1 to filter along x
     // y pass of plane st from the x-filtered tile, z pass over the ring: the value of
     // output plane st - 2R (meaningful from st = 2R on); the ring takes plane st
     auto yz_value = [&]() -> V {
       const V *col = xf + (size_t)q * xf_stride + (size_t)row * lxb + lx;
-      V v = splat<V, T>(ty.w[0]) * col[0];
+      V v = smul(ty.w[0], col[0]);
 #pragma unroll
       for (int t = 1; t < NT; ++t)
-        v = __builtin_elementwise_fma(splat<V, T>(ty.w[sym(t)]), col[(size_t)t * lxb], v);
-      V acc = splat<V, T>(T(0));
-      if (st >= 2 * R) {
+#ifdef NSOL_B3_ABLATE_YREADS       // (timing only: 7 rows read for the 13 taps)
+        v = sfma(ty.w[sym(t)], col[(size_t)(t & ~1) * lxb], v);
+#else
+        v = sfma(ty.w[sym(t)], col[(size_t)t * lxb], v);
+#endif
+      RV vh, acc;
+      vh.set(v);
+      acc.set(splat<V, T>(T(0)));
+      if (storing) {
         // window of plane st: the ring from its oldest slot (u), then v
-        acc = splat<V, T>(tz.w[0]) * ring[u];
+        acc.mul(tz.w[0], ring[u]);
 #pragma unroll
         for (int t = 1; t < M; ++t)
-          acc = __builtin_elementwise_fma(splat<V, T>(tz.w[sym(t)]), ring[(u + t) % M], acc);
-        acc = __builtin_elementwise_fma(splat<V, T>(tz.w[0]), v, acc);
+#ifdef NSOL_B3_ABLATE_ZFMA         // (timing only: half of the z pass's multiply-adds)
+          if (t & 1)
+#endif
+          acc.fma(tz.w[sym(t)], ring[(u + t) % M]);
+        acc.fma(tz.w[0], vh);
       }
-      ring[u] = v;                                  // replaces plane st - M
-      return acc;
+      ring[u] = vh;                                 // replaces plane st - M
+      return acc.get();
     };
     if constexpr (EPI == 4) {
       // ---- second half of a Lanczos step: y_new = ca A x + q0 + cy y.  The lane's
@@ -867,7 +960,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         q0v = obuf[(size_t)row * lxb + lx];
         yv = obuf[(size_t)tile_vecs + (size_t)row * lxb + lx];
       }
-      if (st + 1 >= 2 * R && st + 1 < nsteps) {
+      if (SS || (st + 1 >= 2 * R && st + 1 < nsteps)) {
         // (a wave only reads what its own piece brought: its reads above are done
         // before its next piece can land, and the wait makes that explicit)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -875,11 +968,11 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         stage_tile(aux2, zbeg + (st + 1 - 2 * R), 1);
       }
       if (more) stage(next_plane(), r_cur);         // plane st + 3
-      if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+      if (next_x) xpass(r_next, q ^ 1);
       V val = yz_value();
       uint32_t soff = kNoLane;
       if (storing) {
-        val = (splat<V, T>(k0) * val + q0v) + splat<V, T>(k1) * yv;
+        val = (smul(k0, val) + q0v) + smul(k1, yv);
         if (owner) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) sacc = fma1(val[e], val[e], sacc);
@@ -895,7 +988,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       // ---- second half with K'K y: output plane j = st - 2R; the halo'd tile holds
       //      plane j + 1 of y (requested in the phase before, from phase 2R - 3 on)
       const int j = st - 2 * R;
-      const bool have = j + 1 >= -1;                // (uniform; j + 1 <= len always)
+      const bool have = SS || j + 1 >= -1;                // (uniform; j + 1 <= len always)
       V yp1 = splat<V, T>(T(0)), lap1 = splat<V, T>(T(0)), ypv = splat<V, T>(T(0));
       if (have) {
         // (MINI: this wave's tile, its rows 4 wave - 1 .. 4 wave + 4)
@@ -903,8 +996,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
                      (MINI ? (size_t)wave * 128 + (size_t)(row - wave * 4 + 1) * hrl
                            : (size_t)(row + 1) * hrl) + (lx + 1);
         yp1 = o[0];
-        const int64_t zc = zbeg + (j + 1);
-        if (j + 1 >= 0 && zc < zend && k0 != T(0)) {   // in-plane part of K'K y, plane j + 1
+        const int zc = zbeg + (j + 1);
+        if ((SS || (j + 1 >= 0 && zc < zend)) && k0 != T(0)) {   // in-plane part of K'K y, plane j + 1
                                                     // (k0 = 0: B = identity, no K'K term)
           // (EPI 3's values; the 0 / 1 factors of the volume's edges as lane masks, which
           // live in scalar registers: a * 1 - b = a - b, a * 0 - b = -b for finite a)
@@ -934,29 +1027,29 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       // reads have to be done, nobody else's)
       if constexpr (MINI) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (st >= 2 * R - 3 && st + 1 < nsteps) stage_yh(zbeg + (j + 2));
-      if (has_prev && st + 1 >= 2 * R && st + 1 < nsteps)
+      if (SS || (st >= 2 * R - 3 && st + 1 < nsteps)) stage_yh(zbeg + (j + 2));
+      if (has_prev && (SS || (st + 1 >= 2 * R && st + 1 < nsteps)))
         stage_tile(aux2, zbeg + (j + 1), 0);
       if (more) stage(next_plane(), r_cur);         // plane st + 3
       // q0 of the output plane now, the window moved on: four vectors fewer are live
       // through the passes below (the kernel sits at the 128 registers of 16 waves)
       V q0v = splat<V, T>(T(0));
       if (storing) {
-        const int64_t zc = zbeg + j;
-        const T zm = (zc + 1 < nz) ? T(1) : T(0);
+        const int zc = zbeg + j;
+        const T zm = (zc + 1 < nzi) ? T(1) : T(0);
         const T zlm = zc > 0 ? T(1) : T(0);
-        const V dz = __builtin_elementwise_fma(yp1, splat<V, T>(zm), -y0c);
-        const V dpz = (y0c - ym1) * splat<V, T>(zlm);
+        const V dz = sfma(zm, yp1, -y0c);
+        const V dpz = smul(zlm, y0c - ym1);
         const V lap = lap0 + (dpz - dz);
-        q0v = splat<V, T>(k0) * lap + splat<V, T>(k1) * y0c;
-        if (has_prev) q0v = q0v + splat<V, T>(k2) * ypv;    // (uniform)
+        q0v = smul(k0, lap) + smul(k1, y0c);
+        if (has_prev) q0v = q0v + smul(k2, ypv);    // (uniform)
       }
       if (have) { ym1 = y0c; y0c = yp1; lap0 = lap1; }      // (ym1: y of plane j from here on)
-      if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+      if (next_x) xpass(r_next, q ^ 1);
       V val = yz_value();
       uint32_t soff = kNoLane;
       if (storing) {
-        val = (splat<V, T>(k3) * val + q0v) + splat<V, T>(k4) * ym1;
+        val = (smul(k3, val) + q0v) + smul(k4, ym1);
         if (owner) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) sacc = fma1(val[e], val[e], sacc);
@@ -978,16 +1071,16 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       // ---- first half: K'K x of plane st (z part now, in-plane part from the phase
       //      before) -> q0; the difference sums of EPI 2 from the same values.  The
       //      y_prev tile of plane st + 1 is requested first (two tiles alternate).
-      if (has_prev && st + 1 >= R && st + 1 < nsteps - R)
+      if (has_prev && (SS || (st + 1 >= R && st + 1 < nsteps - R)))
         stage_tile(aux1, zbeg + (st + 1 - R), q ^ 1);
       if (more) stage(next_plane(), r_cur);         // plane st + 3
       V q0v = splat<V, T>(T(0));
       uint32_t qoff = kNoLane;
-      if (st + 1 < nsteps) {
+      if (next_x) {
         const V *o = raw + (size_t)r_next + (size_t)(row + R) * rl + lx + NBH;
         const V own = o[0];
         V lapxy = splat<V, T>(T(0));
-        if (st + 1 >= R && st + 1 < nsteps - R) {          // in-plane part, plane st + 1
+        if (SS || (st + 1 >= R && st + 1 < nsteps - R)) {  // in-plane part, plane st + 1
           const V right = o[1], left = o[-1], down = o[rl], up = o[-rl];
           const V dy = __builtin_elementwise_fma(down, splat<V, T>(ym), -own);
           const V dpy = (own - up) * splat<V, T>(um);
@@ -1008,21 +1101,20 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
             lapxy[k] = (l - dx[k]) + (dpy[k] - dy[k]);
           }
         }
-        if (st >= R && st < nsteps - R) {                  // z part, plane st
-          const int64_t zc = zbeg + (st - R);
-          const T zm = (zc + 1 < nz) ? T(1) : T(0);
+        if (SS || (st >= R && st < nsteps - R)) {          // z part, plane st
+          const int zc = zbeg + (st - R);
+          const T zm = (zc + 1 < nzi) ? T(1) : T(0);
           const T zlm = zc > 0 ? T(1) : T(0);
-          const V dz = __builtin_elementwise_fma(own, splat<V, T>(zm), -prev_own);
-          const V dpz = (prev_own - prev2_own) * splat<V, T>(zlm);
+          const V dz = sfma(zm, own, -prev_own);
+          const V dpz = smul(zlm, prev_own - prev2_own);
           T sz = T(0);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) sz = fma1(dz[k], dz[k], sz);
           gacc = fma1(gz2, sz, gacc);
           const V lap = lapxy_prev + (dpz - dz);
-          q0v = splat<V, T>(k0) * lap + splat<V, T>(k1) * prev_own;
+          q0v = smul(k0, lap) + smul(k1, prev_own);
           if (has_prev)                                      // (uniform)
-            q0v = q0v + splat<V, T>(k2) *
-                            obuf[(size_t)q * tile_vecs + (size_t)row * lxb + lx];
+            q0v = q0v + smul(k2, obuf[(size_t)q * tile_vecs + (size_t)row * lxb + lx]);
           qoff = own_off;
         }
         prev2_own = prev_own;
@@ -1030,22 +1122,22 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         lapxy_prev = lapxy;
       }
       store_at(aux_out, zbeg + (st - R), qoff, q0v);
-      if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+      if (next_x) xpass(r_next, q ^ 1);
       const V acc = yz_value();
       if (storing) put(zbeg + (st - 2 * R), acc, q);
       const int t_ = r_cur; r_cur = r_next; r_next = r_after; r_after = t_;
       phase_end((more ? my_stage_ops : 0) + 1 + (storing ? my_store_ops : 0));
       return;
     }
-    if ((EPI == 1 || EPI == 5) && st + 1 >= 2 * R && st + 1 < nsteps)
+    if ((EPI == 1 || EPI == 5) && (SS || (st + 1 >= 2 * R && st + 1 < nsteps)))
       stage_old(zbeg + (st + 1 - 2 * R), q ^ 1);    // old io (b) of the next output plane
     if (more) stage(next_plane(), r_cur);           // plane st + 3, two phases ahead
     // (The x pass of plane st + 1 and the y / z passes of plane st are independent,
     // but letting half of the waves of a SIMD run them in the opposite order, so that
     // not everybody waits for the LDS at the same time, measured no faster.)
-    if (st + 1 < nsteps) xpass(r_next, q ^ 1);
+    if (next_x) xpass(r_next, q ^ 1);
     if constexpr (EPI == 2) {
-      if (st + 1 < nsteps) {
+      if (next_x) {
         // plane j of the chunk's nsteps planes is one of its own for R <= j < nsteps - R
         const V *rbase = raw + (size_t)r_next;
         const V *o = rbase + (size_t)(row + R) * rl + lx + NBH;
@@ -1066,7 +1158,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
           }
         };
         const V own = rd(0, 0);
-        if (st + 1 >= R && st + 1 < nsteps - R) {          // d_x, d_y of plane st + 1
+        if (SS || (st + 1 >= R && st + 1 < nsteps - R)) {  // d_x, d_y of plane st + 1
           const V right = rd(1, 0);
           const V down = rd(0, 1);
           const V dy = __builtin_elementwise_fma(down, splat<V, T>(ym), -own);
@@ -1080,9 +1172,9 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
           }
           gacc = fma1(gx2, sx, fma1(gy2, sy, gacc));
         }
-        if (st >= R && st < nsteps - R) {                  // d_z of plane st
-          const T zm = (zbeg + (st - R) + 1 < nz) ? T(1) : T(0);
-          const V dz = __builtin_elementwise_fma(own, splat<V, T>(zm), -prev_own);
+        if (SS || (st >= R && st < nsteps - R)) {          // d_z of plane st
+          const T zm = (zbeg + (st - R) + 1 < nzi) ? T(1) : T(0);
+          const V dz = sfma(zm, own, -prev_own);
           T sz = T(0);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) sz = fma1(dz[k], dz[k], sz);
@@ -1100,9 +1192,13 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     // its pieces are this phase's pieces and this phase's store
     phase_end((more ? my_stage_ops : 0) + (storing ? my_store_ops : 0));
   };
+  const int steady_end = nsteps - (R + 1 > 3 ? R + 1 : 3);   // steady: 2R <= st < steady_end
 #pragma unroll 1
   for (int st0 = 0; st0 < nsteps; st0 += M) {
-    blur3_phases<0, M>(st0, nsteps, phase);
+    if (NSOL_B3_STEADY && EPI < 3 && st0 >= 2 * R && st0 + M - 1 < steady_end)
+      blur3_phases<0, M, true>(st0, nsteps, phase);
+    else
+      blur3_phases<0, M, false>(st0, nsteps, phase);
     if constexpr (EPI >= 2 && EPI != 5) {
       sumsq += (double)sacc;
       gsum += (double)gacc;
@@ -1277,6 +1373,7 @@ int launch_blur3_dma(const T *x, T *out, int64_t nz, int64_t ny, int64_t nx,
   const int64_t nxv = (nx + VEC - 1) / VEC;
   const int64_t dntx = (nxv + dl - 1) / dl, dnty = (ny + dtyr - 1) / dtyr;
   if (ny * nx >= ((int64_t)1 << 31)) return -2;          // 32-bit offsets in a plane
+  if (nz >= ((int64_t)1 << 30)) return -2;               // 32-bit plane indices
   // z chunks by the round model: `slots` workgroups run at a time, a launch takes
   // ceil(workgroups / slots) rounds of (chunk + 2R) plane steps
   const int per_cu = (int)((160 * 1024) / lds) < (32 / NWD) ? (int)((160 * 1024) / lds)
