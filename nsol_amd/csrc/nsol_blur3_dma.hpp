@@ -988,40 +988,45 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       // ---- second half with K'K y: output plane j = st - 2R; the halo'd tile holds
       //      plane j + 1 of y (requested in the phase before, from phase 2R - 3 on)
       const int j = st - 2 * R;
-      const bool have = SS || j + 1 >= -1;                // (uniform; j + 1 <= len always)
-      V yp1 = splat<V, T>(T(0)), lap1 = splat<V, T>(T(0)), ypv = splat<V, T>(T(0));
-      if (have) {
-        // (MINI: this wave's tile, its rows 4 wave - 1 .. 4 wave + 4)
-        const V *o = obuf + (size_t)tile_vecs +
-                     (MINI ? (size_t)wave * 128 + (size_t)(row - wave * 4 + 1) * hrl
-                           : (size_t)(row + 1) * hrl) + (lx + 1);
-        yp1 = o[0];
-        const int zc = zbeg + (j + 1);
-        if ((SS || (j + 1 >= 0 && zc < zend)) && k0 != T(0)) {   // in-plane part of K'K y, plane j + 1
+      // (Nothing here is conditional on the phase: before the first plane has landed --
+      // phases up to 2R - 3 -- the tile reads return whatever the LDS holds, and what is
+      // made of it has left ym1 / y0c / lap0 again by the first phase that stores; a
+      // merge of "not yet" zeros per value and phase cost more than the arithmetic.)
+      // (MINI: this wave's tile, its rows 4 wave - 1 .. 4 wave + 4)
+      const V *o = obuf + (size_t)tile_vecs +
+                   (MINI ? (size_t)wave * 128 + (size_t)(row - wave * 4 + 1) * hrl
+                         : (size_t)(row + 1) * hrl) + (lx + 1);
+      const V yp1 = o[0];
+      V lap1 = splat<V, T>(T(0)), ypv = splat<V, T>(T(0));
+      if (k0 != T(0)) {                             // in-plane part of K'K y, plane j + 1
                                                     // (k0 = 0: B = identity, no K'K term)
-          // (EPI 3's values; the 0 / 1 factors of the volume's edges as lane masks, which
-          // live in scalar registers: a * 1 - b = a - b, a * 0 - b = -b for finite a)
-          const bool e_r = xv + 1 < nxv, e_d = y0 + row + 1 < ny, e_l = xv > 0,
-                     e_u = y0 + row > 0;
-          const V down = o[hrl], up = o[-hrl];
-          const T right0 = reinterpret_cast<const T *>(o + 1)[0],
-                  left3 = reinterpret_cast<const T *>(o)[-1];
-          const V dy = e_d ? down - yp1 : -yp1;
-          const V dpy = e_u ? yp1 - up : splat<V, T>(T(0));
-          T dx[VEC];
+        // (EPI 3's values.  Its 0 / 1 factors for the volume's edges are lane masks here,
+        // which live in scalar registers -- four more vector registers and the kernel
+        // spills: a * 1 - b = a - b, a * 0 - b = -b for finite a.  Both candidates are
+        // formed and one is selected: left to choose, the compiler branched on the masks
+        // with the tile reads inside the branches.)
+        const bool e_r = xv + 1 < nxv, e_d = y0 + row + 1 < ny, e_l = xv > 0,
+                   e_u = y0 + row > 0;
+        const V down = o[hrl], up = o[-hrl];
+        const T right0 = reinterpret_cast<const T *>(o + 1)[0],
+                left3 = reinterpret_cast<const T *>(o)[-1];
+        const V dyf = down - yp1, dpyf = yp1 - up;
+        const T dxr = right0 - yp1[VEC - 1], dlf = yp1[0] - left3;
+        T dx[VEC], dy[VEC], dpy[VEC];
 #pragma unroll
-          for (int k = 0; k < VEC; ++k)
-            dx[k] = (k + 1 < VEC) ? yp1[(k + 1) % VEC] - yp1[k]
-                                  : (e_r ? right0 - yp1[k] : -yp1[k]);
-          const T dl = e_l ? yp1[0] - left3 : T(0);
+        for (int k = 0; k < VEC; ++k) {
+          dy[k] = e_d ? dyf[k] : -yp1[k];
+          dpy[k] = e_u ? dpyf[k] : T(0);
+          dx[k] = (k + 1 < VEC) ? yp1[(k + 1) % VEC] - yp1[k] : (e_r ? dxr : -yp1[k]);
+        }
+        const T dl = e_l ? dlf : T(0);
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) {
-            const T l = (k > 0) ? dx[(k + VEC - 1) % VEC] : dl;
-            lap1[k] = (l - dx[k]) + (dpy[k] - dy[k]);
-          }
+        for (int k = 0; k < VEC; ++k) {
+          const T l = (k > 0) ? dx[(k + VEC - 1) % VEC] : dl;
+          lap1[k] = (l - dx[k]) + (dpy[k] - dy[k]);
         }
       }
-      if (storing && has_prev) ypv = obuf[(size_t)row * lxb + lx];
+      if (has_prev) ypv = obuf[(size_t)row * lxb + lx];      // (uniform)
       // every wave has taken what it needs from the two tiles: only then may the next
       // plane be requested into them (MINI: a wave reads its own pieces only -- its own
       // reads have to be done, nobody else's)
@@ -1033,8 +1038,8 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       if (more) stage(next_plane(), r_cur);         // plane st + 3
       // q0 of the output plane now, the window moved on: four vectors fewer are live
       // through the passes below (the kernel sits at the 128 registers of 16 waves)
-      V q0v = splat<V, T>(T(0));
-      if (storing) {
+      V q0v;
+      {
         const int zc = zbeg + j;
         const T zm = (zc + 1 < nzi) ? T(1) : T(0);
         const T zlm = zc > 0 ? T(1) : T(0);
@@ -1044,12 +1049,12 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
         q0v = smul(k0, lap) + smul(k1, y0c);
         if (has_prev) q0v = q0v + smul(k2, ypv);    // (uniform)
       }
-      if (have) { ym1 = y0c; y0c = yp1; lap0 = lap1; }      // (ym1: y of plane j from here on)
+      ym1 = y0c; y0c = yp1; lap0 = lap1;            // (ym1: y of plane j from here on)
       if (next_x) xpass(r_next, q ^ 1);
       V val = yz_value();
+      val = (smul(k3, val) + q0v) + smul(k4, ym1);
       uint32_t soff = kNoLane;
       if (storing) {
-        val = (smul(k3, val) + q0v) + smul(k4, ym1);
         if (owner) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) sacc = fma1(val[e], val[e], sacc);
