@@ -1235,21 +1235,34 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   }
 }
 
+// The sum of one value per thread of a kBlock workgroup in a FIXED order (the same for
+// every kernel that closes a blur: their sums are compared for equality): a shuffle tree
+// inside each wave, then the waves' sums in turn; valid in thread 0.  (One thread adding
+// kBlock values from the LDS one after the other took 8 of such a kernel's 12 microseconds
+// -- 200 of them in a config-4 run.)
+__device__ __forceinline__ double blur3_block_sum(double t, double *s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = t;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) r += s[w];
+  }
+  return r;
+}
+
 // sum of the per-tile partials in a fixed order (block b: the b-th run of n partials)
 __global__ __launch_bounds__(kBlock) void k_blur3_epi_final(const double *part, int n,
                                                             double *result,
                                                             double scale = 1.0) {
-  __shared__ double s[kBlock];
+  __shared__ double s[kBlock / 64];
   part += (size_t)blockIdx.x * n;
   double t = 0.0;
   for (int i = threadIdx.x; i < n; i += kBlock) t += part[i];
-  s[threadIdx.x] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double r = 0.0;
-    for (int i = 0; i < kBlock; ++i) r += s[i];
-    result[blockIdx.x] = r * scale;
-  }
+  const double r = blur3_block_sum(t, s);
+  if (threadIdx.x == 0) result[blockIdx.x] = r * scale;
 }
 
 
@@ -1266,18 +1279,17 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_blur3_lanczos_final(
     const double *part, int n, int which, double *board, int j, double rho_g, double rho_i,
     T *coef) {
-  __shared__ double s[2][kBlock];
+  __shared__ double s[2][kBlock / 64];
   const int nsum = which == 1 ? 2 : (which == 2 ? 1 : 0);
+  // (the board value the coefficients need, requested ahead of the sums)
+  const double nb2_j = (which != 0 && threadIdx.x == 0) ? board[3 * j] : 0.0;
+  double r[2] = {0.0, 0.0};
   for (int a = 0; a < nsum; ++a) {
     double t = 0.0;
     for (int i = threadIdx.x; i < n; i += kBlock) t += part[(size_t)a * n + i];
-    s[a][threadIdx.x] = t;
+    r[a] = blur3_block_sum(t, s[a]);
   }
-  __syncthreads();
   if (threadIdx.x != 0) return;
-  double r[2] = {0.0, 0.0};
-  for (int a = 0; a < nsum; ++a)
-    for (int i = 0; i < kBlock; ++i) r[a] += s[a][i];
   if (which == 0) {
     const double b0 = sqrt(board[0]);
     coef[0] = (T)(rho_g / b0);
@@ -1286,14 +1298,14 @@ __global__ __launch_bounds__(kBlock) void k_blur3_lanczos_final(
   } else if (which == 1) {
     board[3 * j + 1] = r[0];
     board[3 * j + 2] = r[1];
-    const double nb2 = board[3 * j];
+    const double nb2 = nb2_j;
     const double alpha = (r[0] + rho_g * r[1]) / nb2 + rho_i;
     const double beta = sqrt(nb2);
     coef[4] = (T)(1.0 / beta);
     coef[5] = (T)(-alpha / beta);
   } else {
     board[3 * j + 3] = r[0];
-    const double bn = sqrt(r[0]), beta = sqrt(board[3 * j]);
+    const double bn = sqrt(r[0]), beta = sqrt(nb2_j);
     coef[0] = (T)(rho_g / bn);
     coef[1] = (T)(rho_i / bn);
     coef[2] = (T)(-bn / beta);
