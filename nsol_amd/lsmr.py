@@ -357,7 +357,7 @@ def normal_equations_ok(bmode, sa, maxiter, x_like):
 
 def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                 A_axpby=None, atb=None, x_bounds=None, b_bot_scale=1.0,
-                normb2=None, top_norm2=None, g0=None):
+                normb2=None, top_norm2=None, g0=None, out_scale=None):
     """The iterates of lsmr_fused from Lanczos on the normal equations (see above).
     top_norm2: a callable that returns |b_top|^2 (like atb: the same in every solve of an
     outer loop around one b).  g0 = (g, |g|^2 as a one-element float64 device tensor): the
@@ -433,7 +433,8 @@ def lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         else:
             lb.slot_norm2(0).copy_(g0[1])
         del atu
-        got = _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds)
+        got = _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds,
+                               out_scale=out_scale)
         if got is not None:
             return got
         beta1 = math.sqrt(float(lb.board[0].item()))     # (the kernels do not apply)
@@ -537,7 +538,8 @@ def _scipy_stop(co, normb2, eps=2.220446049250313e-16):
     return stop
 
 
-def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
+def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds,
+                     out_scale=None):
     """lsmr_normal's loop with both halves of every step inside the blur
     (nsol_corr3_wrap_lanczos_a / _b, nsol_blur3_dma.hpp): per step
         t = A y_j, |t|^2, |grad y_j|^2, q0 = (rho / beta_j) K'K y_j - (beta_j / beta_{j-1}) y_{j-1}
@@ -607,7 +609,15 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
             raise RuntimeError("nsol_corr3_wrap_lanczos_b does not apply")
         ys.append(ynew)
         fetchers[j % (_LAG + 1)].start(lb.board[3 * j:3 * j + 4])
-        if j >= _LAG:
+        if j == 0 and rho < NE_MIN_WEIGHT[x_like.element_size()]:
+            # (a weight that the guard may refuse -- it holds |A y_0|^2 / |y_0|^2 against
+            # it, at most |A|^2: step 0's sums are waited for before more is enqueued; a
+            # refused solve used to cost the _LAG steps already on their way)
+            stopped = digest(0, fetchers[0].wait())
+            done = 1
+            if stopped:
+                break
+        elif j >= _LAG:
             stopped = digest(done, fetchers[done % (_LAG + 1)].wait())
             done += 1
             if stopped:
@@ -630,7 +640,13 @@ def _lanczos_in_blur(halves, lb, g, rho, x_like, maxiter, rhs_norm2, x_bounds):
     LAST_FORM[0] = "lanczos-in-blur"
     if LAST_NE_COND[0] > NE_MAX_COND[x_like.element_size()]:
         return None, -1, k
-    x = ops.lincomb_many(ys[:k], [co.x[j] / betas[j] for j in range(k)],
+    s = 1.0
+    if out_scale is not None and out_scale[0] > 0 and math.isfinite(out_scale[0]):
+        s = float(out_scale[0])
+        out_scale[1] = True
+        if x_bounds is not None:
+            x_bounds = (x_bounds[0] * s, x_bounds[1] * s)
+    x = ops.lincomb_many(ys[:k], [s * co.x[j] / betas[j] for j in range(k)],
                          bounds=x_bounds)
     return x, state["istop"], k
 
@@ -667,7 +683,7 @@ def _operators_in_float64(A, A_adj, x_like):
 def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
                atol=0.0, btol=0.0, conlim=1e8, A_axpby=None, normb2=None, top_norm2=None,
                own_b=True, atb=None, x_bounds=None, b_bot_scale=1.0,
-               allow_normal=True, g0=None, b_bot_fill=None):
+               allow_normal=True, g0=None, b_bot_fill=None, out_scale=None):
     """Same algorithm for the augmented system [A; sa*B] with B in {none, grad,
     identity}, on the fused kernels of nsol_lsmr.hip.  The Golub-Kahan vectors
     are held unnormalised (ut = su*u, vt = sv*v); b_top / b_bot are consumed.
@@ -684,7 +700,10 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
     caller's array is then only read: the normal-equations form folds the factor into a
     coefficient, the bidiagonalisation scales into a copy).  g0: see lsmr_normal; b_bot
     then holds nothing until b_bot_fill() has written it -- called here when the solve
-    cannot stay with the normal equations and needs the block itself."""
+    cannot stay with the normal equations and needs the block itself.  out_scale =
+    [s, False], s > 0: the caller wants s * x; where x is assembled from stored vectors the
+    factor goes into their coefficients (and the bounds) and out_scale[1] becomes True --
+    otherwise x comes back as it is and the caller multiplies."""
     import torch
     wide = None
     if bmode == ops.B_NONE and PROMOTE_WEAK_REGULARISERS and x_like.element_size() == 4 \
@@ -703,7 +722,8 @@ def lsmr_fused(A, A_adj, b_top, b_bot, bmode, shape, w, sa, x_like, maxiter,
         x, istop, itn = lsmr_normal(A, A_adj, b_top, b_bot, bmode, shape, w, sa,
                                     x_like, maxiter, A_axpby=A_axpby, atb=atb,
                                     x_bounds=x_bounds, b_bot_scale=b_bot_scale,
-                                    normb2=normb2, top_norm2=top_norm2, g0=g0)
+                                    normb2=normb2, top_norm2=top_norm2, g0=g0,
+                                    out_scale=out_scale)
         if x is not None:
             return x, istop, itn
         # (the weight is below the guard or the condition estimate came out too high:

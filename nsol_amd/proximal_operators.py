@@ -112,13 +112,14 @@ class ProximalOperators(object):
             data_loss_scale=data_loss_scale, minimizer=minimizer,
             bounds=bounds,
             dtype=(np.float32 if is_device_tensor(x) and "32" in str(x.dtype)
-                   else (np.float64 if is_device_tensor(x) else None)))
+                   else (np.float64 if is_device_tensor(x) else None)),
+            _defer_scaling=is_device_tensor(x))
         # (on the solvers' device path the caller is a loop that goes on enqueueing and
         # synchronises at the end of its own run)
         tikhonov._sync_after_run = not is_device_tensor(x)
         tikhonov.run()
         if is_device_tensor(x):
-            return tikhonov.get_x_device()
+            return tikhonov.take_x_device()       # (the solver is dropped here)
         return tikhonov.get_x()
 
     @staticmethod

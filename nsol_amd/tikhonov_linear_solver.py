@@ -20,7 +20,7 @@ import scipy.sparse.linalg
 from . import _caches, ops
 from .bridge import BridgedCallable
 from .definitions import EPS
-from .device import is_device_tensor, to_device, to_numpy
+from .device import is_device_tensor, to_device, to_numpy, torch_dtype
 from .linear_solver import LinearSolver
 from .lsmr import lsmr, lsmr_fused
 from .solver import Solver
@@ -85,7 +85,7 @@ class TikhonovLinearSolver(LinearSolver):
     def __init__(self, A, A_adj, b, B, B_adj, x0, alpha=0.01, b_reg=0,
                  data_loss="linear", data_loss_scale=1, minimizer="lsmr",
                  iter_max=10, x_scale=1, verbose=0, bounds=(0, np.inf),
-                 dtype=None, _borrow=False):
+                 dtype=None, _borrow=False, _defer_scaling=False):
         LinearSolver.__init__(
             self, A=A, A_adj=A_adj, b=b, x0=x0, alpha=alpha, iter_max=iter_max,
             minimizer=minimizer, data_loss=data_loss,
@@ -93,7 +93,18 @@ class TikhonovLinearSolver(LinearSolver):
             dtype=dtype, _borrow=_borrow)
         self._B = B
         self._B_adj = B_adj
-        self._b_reg = self._scaled(b_reg)          # tikhonov :91
+        # _defer_scaling (a solver built for ONE solve around device data, e.g. by
+        # prox_linear_least_squares): b_reg / x_scale is not formed here -- the LSMR
+        # kernels take the factor as a coefficient -- but when somebody asks for it;
+        # and the solution may come back in the caller's units (see _run_lsmr)
+        self._fold_x_scale = bool(_defer_scaling) and float(self._x_scale) > 0 and \
+            float(self._x_scale) != 1.0
+        if self._fold_x_scale and is_device_tensor(b_reg) and self._borrowed(b_reg) is None:
+            self._b_reg_val = None
+            self._b_reg_lazy = (b_reg.to(torch_dtype(self._dtype)).contiguous().view(-1),
+                                float(self._x_scale))
+        else:
+            self._b_reg = self._scaled(b_reg)          # tikhonov :91
         self._bounds = bounds
         # (sqrt(alpha), ||b||^2, ||sqrt(alpha) b_reg||^2) when b_reg already holds
         # sqrt(alpha) * b_reg (set by ADMMLinearSolver's fused outer step)
@@ -101,6 +112,41 @@ class TikhonovLinearSolver(LinearSolver):
 
     _x0_clip_pending = False
     _lsmr_start = None
+    _b_reg_lazy = None
+    _x_in_callers_units = False
+
+    @property
+    def _b_reg(self):
+        if self._b_reg_lazy is not None:
+            raw, xs = self._b_reg_lazy
+            self._b_reg_lazy = None
+            self._b_reg_val = ops.scale(raw, xs, divide=True)
+        return self._b_reg_val
+
+    @_b_reg.setter
+    def _b_reg(self, v):
+        self._b_reg_lazy = None
+        self._b_reg_val = v
+
+    def get_x_device(self):
+        if self._x_in_callers_units and self._x is not None:
+            return self._x.clone()
+        return LinearSolver.get_x_device(self)
+
+    def take_x_device(self):
+        """The solution in the caller's units as a flat device tensor the caller may
+        keep -- for a solver that is dropped after the call (no copy where the
+        solution was assembled in those units already)."""
+        if self._x_in_callers_units and self._x is not None:
+            x, self._x = self._x, None
+            self._x_in_callers_units = False
+            return x
+        return LinearSolver.get_x_device(self)
+
+    def get_x(self):
+        if self._x_in_callers_units and self._x is not None:
+            return to_numpy(self._x)
+        return LinearSolver.get_x(self)
 
     def _clip_x0(self):
         self._x0_clip_pending = False
@@ -208,7 +254,11 @@ class TikhonovLinearSolver(LinearSolver):
             # in, the normal-equations form only reads it -- and A^T b, the same in
             # every solve of an outer loop around one b, is kept)
             b_top = fused[2]
+            # (x_scale folded into the coefficients that assemble x, where the solve
+            # gets that far: out_scale[1] says whether it did)
+            out_scale = [float(self._x_scale), False] if self._fold_x_scale else None
             x, istop, itn = lsmr_fused(*fused, x_like=x0, maxiter=self._iter_max,
+                                 out_scale=out_scale,
                                  A_axpby=self._blur_epilogue(x0.numel()),
                                  normb2=None if pre is None else (
                                      (lambda: pre[1] + pre[2]()) if callable(pre[2])
@@ -222,6 +272,7 @@ class TikhonovLinearSolver(LinearSolver):
                                  g0=None if start is None else (start["g"], start["gg"]),
                                  b_bot_fill=None if start is None else start["fill"])
             self._lsmr_stop = (istop, itn)     # (SciPy's istop, iterations taken)
+            self._x_in_callers_units = bool(out_scale and out_scale[1])
             return x
         if pre is not None:            # (not expected: undo the pre-multiplication)
             self._b_reg = ops.scale(self._dev(self._b_reg), 1.0 / pre[0])
@@ -299,7 +350,12 @@ class TikhonovLinearSolver(LinearSolver):
             return None
         sa = float(np.sqrt(self._alpha))
         self._lower_scale = 1.0
-        if self._prescaled_b_reg is not None and \
+        lazy = self._b_reg_lazy
+        if self._prescaled_b_reg is None and lazy is not None and lazy[0].numel() == rows:
+            # (b_reg as the caller gave it; 1 / x_scale rides with sqrt(alpha))
+            lower = lazy[0]
+            self._lower_scale = sa / lazy[1]
+        elif self._prescaled_b_reg is not None and \
                 is_device_tensor(self._b_reg) and self._b_reg.numel() == rows:
             # already sqrt(alpha) * b_reg; consumed by LSMR (it becomes u's lower
             # block), which is fine: the caller rewrites it before the next solve
