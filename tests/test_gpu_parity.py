@@ -1282,6 +1282,57 @@ def test_large_host_observation_is_scaled_on_the_device(nsol):
     assert rel_l2(host.get_x(), dev.get_x()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_prox_least_squares_folds_x_scale_into_coefficients(nsol, dtype):
+    """prox_linear_least_squares on the device (proximal_operators.py:43-78) builds its
+    Tikhonov solver for ONE solve: b_reg / x_scale and x * x_scale ride on coefficients
+    of kernels that run anyway instead of taking a pass each.  Same result as the solver
+    used the plain way (b_reg divided first, get_x multiplying) up to rounding; and what
+    the deferred form hands out on request is what the plain form holds."""
+    import torch
+    import nsol_amd.linear_operators as LO
+    import nsol_amd.tikhonov_linear_solver as tk
+    from nsol_amd import lsmr
+    from nsol_amd.proximal_operators import ProximalOperators as prox
+    shape = (48, 64, 64)
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(21)
+    clean = np.clip(rng.standard_normal(shape).cumsum(axis=2), -5, 5) + 10.0
+    lo = LO.LinearOperators3D()
+    A, A_adj = lo.get_gaussian_blurring_operators(np.diag([1.0, 1.0, 1.0]))
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    b = A(torch.from_numpy(clean).to("cuda", td)).flatten()
+    xs = float(b.max())
+    x = (b + 0.3 * torch.randn(n, device="cuda", dtype=td,
+                               generator=torch.Generator(device="cuda").manual_seed(3)))
+    A_ = lambda v: A(v.reshape(*shape)).flatten()
+    Aa_ = lambda v: A_adj(v.reshape(*shape)).flatten()
+    ident = lambda v: v.flatten()
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    for tau in (0.5, 40.0):              # (40: a weight the float32 guard refuses)
+        got = prox.prox_linear_least_squares(x, tau, A_, Aa_, b, b, iter_max=6, x_scale=xs)
+        form = lsmr.LAST_FORM[0]
+        plain = tk.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=ident, B_adj=ident, x0=b / xs,
+                                        b=b / xs, b_reg=x, alpha=1.0 / tau, iter_max=6,
+                                        x_scale=xs, dtype=dtype)
+        plain.run()
+        assert not plain._x_in_callers_units
+        assert rel_l2(got.cpu().numpy(), plain.get_x()) < tol, (tau, form)
+    # the deferred form on request: b_reg as the plain form holds it, x in both units
+    s = tk.TikhonovLinearSolver(A=A_, A_adj=Aa_, B=ident, B_adj=ident, x0=b / xs, b=b / xs,
+                                b_reg=x, alpha=2.0, iter_max=4, x_scale=xs, dtype=dtype,
+                                _defer_scaling=True)
+    assert s._b_reg_lazy is not None
+    s.run()
+    assert s._x_in_callers_units and s._b_reg_lazy is not None      # (never divided)
+    assert rel_l2(s.get_b_reg(), x.cpu().numpy()) < (1e-6 if dtype == np.float32 else 1e-15)
+    assert s._b_reg_lazy is None                                    # (... until asked for)
+    a, c = s.get_x(), s.get_x_device()
+    assert np.array_equal(a, c.cpu().numpy().astype(np.float64))
+    t = s.take_x_device()
+    assert torch.equal(t, c) and t.data_ptr() != c.data_ptr()
+
+
 def test_admm_with_vector_b_reg(nsol, golden):
     import nsol_amd.admm_linear_solver as admm
     g = golden("extra")
