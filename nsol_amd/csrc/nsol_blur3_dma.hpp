@@ -429,7 +429,12 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   const int total = ntx * nty * nzc;
   const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (logical >= total) return;
+#ifdef NSOL_B3_PERMUTE_BX        // (measurement only: tile column != dispatch slot; 8 columns)
+  const int bxs = logical % ntx;
+  const int bx = ntx == 8 ? ((bxs & 1) << 2 | (bxs & 2) | (bxs & 4) >> 2) : bxs;
+#else
   const int bx = logical % ntx;
+#endif
   const int by = (logical / ntx) % nty;
   const int bz = logical / (ntx * nty);
 
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
   // so its 16 lanes read 16 consecutive 16-byte slots -- conflict-free whatever the
   // row stride (20 slots in the raw tile).  With the plain map (row = lane / 16) half
   // of each group sat a row further and a fifth of the LDS cycles were conflicts.
+  static_assert(lxb == 16, "a wave covers 4 rows of 16 lanes");
   const int lx = lane & 15;
   const int quad = (lane >> 2) & 3;
   const int rsel = ((quad == 1 || quad == 2) ? 1 : 0) ^ ((lane >> 4) & 1);
@@ -755,10 +761,21 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
     for (int j = 0; j < 2; ++j) {
       int i = MINI ? j * 64 + lane : (wave + j * NW) * 64 + lane;
       if (i >= halo_vecs) i = 0;
+      // (Positions outside the volume are WRAPPED like the raw tile's, not clamped: what
+      // they hold is never used -- the edge masks select the boundary's form -- but a
+      // clamped position repeats a line the tile holds anyway, and the tile columns at
+      // the volume's edges then ask for a tenth fewer lines than the others, run 9 %
+      // ahead of them (7 phases after 70) and the halo lines neighbouring columns share
+      // stop meeting in the L2: tools/_probe/drift_probe.py, HISTORY.)
       int64_t yy = y0 + (MINI ? wave * 4 : 0) + i / hrl - 1;
-      yy = yy < 0 ? 0 : (yy >= ny ? ny - 1 : yy);
       int xx = bx * lxb + i % hrl - 1;
+#ifdef NSOL_B3_CLAMP_YH           // (the clamped form, for A/B runs)
+      yy = yy < 0 ? 0 : (yy >= ny ? ny - 1 : yy);
       xx = xx < 0 ? 0 : (xx >= nxv ? nxv - 1 : xx);
+#else
+      yy = ((yy % ny) + ny) % ny;
+      xx = ((xx % nxv) + nxv) % nxv;
+#endif
       yh_off[j] = (uint32_t)(yy * nx + (int64_t)xx * VEC);
     }
   }
@@ -984,6 +1001,12 @@ __global__ __launch_bounds__(NW * 64) void k_blur3_dma(
       phase_end((more ? my_stage_ops : 0) + 1);
       return;
     }
+#ifdef NSOL_B3_DRIFT_PROBE        // (measurement only: when does each workgroup reach phases 0 / N?)
+    if constexpr (EPI == 6) {
+      if (tid == 0 && (st == 0 || st == NSOL_B3_DRIFT_PROBE))
+        part[(st == 0 ? 3 : 2) * (size_t)total + logical] = (double)wall_clock64();
+    }
+#endif
     if constexpr (EPI == 6) {
       // ---- second half with K'K y: output plane j = st - 2R; the halo'd tile holds
       //      plane j + 1 of y (requested in the phase before, from phase 2R - 3 on)
