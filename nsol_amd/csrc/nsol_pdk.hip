@@ -1205,7 +1205,7 @@ constexpr int kRounds = 2;
 // ... and the finalists -- whoever is within 6 % of the best after those -- are sampled
 // up to kFinalRounds times, taking turns: two samples each, minutes apart on a part whose
 // clock drifts, settled 511^3 on plans 14 % apart from run to run
-constexpr int kFinalRounds = 5;
+constexpr int kFinalRounds = 6;     // (the first sample of a configuration is cold: 5 that count)
 constexpr float kFinalBand = 1.06f;
 std::map<PlanKey, Plan> g_plans;
 
@@ -1252,13 +1252,17 @@ inline void plan_poll(Plan &P, int K) {
   for (int i = 0; i < n; ++i)
     if (P.done[i] < plan_target(P, i, best_now)) all = false;
   if (all) {
-    // the finalists by the MEDIAN of their samples (one lucky launch must not decide
-    // either); everybody else by the minimum of two
+    // the finalists by the SECOND SMALLEST of their warm samples -- the first launch of a
+    // configuration is always slow (1.2 - 1.5 ms where the others take 1.13), and what
+    // disturbs a launch afterwards only ever slows it down: the median of five let two or
+    // three disturbed launches decide (a battery settled on 12 : 3 : 256, 1.20 ms, once in
+    // three runs); one lucky launch must not decide either.  Everybody else by the minimum
+    // of two.
     auto score = [&](int i) {
-      std::vector<float> v = P.samples[i];
-      if ((int)v.size() < kFinalRounds) return P.best_ms[i] * kFinalBand;
+      if ((int)P.samples[i].size() < kFinalRounds) return P.best_ms[i] * kFinalBand;
+      std::vector<float> v(P.samples[i].begin() + 1, P.samples[i].end());
       std::sort(v.begin(), v.end());
-      return v[v.size() / 2];
+      return v[1];
     };
     int arg = 0;
     for (int i = 0; i < n; ++i)
@@ -1266,9 +1270,13 @@ inline void plan_poll(Plan &P, int K) {
     P.chosen = arg;
     if (g_tunek.verbose) {
       for (int i = 0; i < n; ++i)
-        fprintf(stderr, "k_pd_fusedk tune K=%d waves=%d ntx=%d zchunk=%lld: %.3f ms%s\n",
+      {
+        fprintf(stderr, "k_pd_fusedk tune K=%d waves=%d ntx=%d zchunk=%lld: %.3f ms%s  [",
                 K, P.cand[i].nw, P.cand[i].q.ntx, (long long)P.cand[i].zchunk,
                 P.best_ms[i], i == arg ? "  <- kept" : (P.dropped[i] ? "  (dropped)" : ""));
+        for (float v : P.samples[i]) fprintf(stderr, " %.3f", v);
+        fprintf(stderr, " ]\n");
+      }
     }
   }
 }
